@@ -1,0 +1,242 @@
+"""ctypes binding of oracle/libsmc_oracle.so -- the CPU checker.
+
+TEST INFRASTRUCTURE: imported only by tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg.  The product never touches it.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+RAND_MAX = 2147483647
+
+# wall-strength fixture, SURVEY.md 8a row W (real reference output, glibc 2.35)
+W_FIXTURE = np.array([
+    962.2264072645321, 57.35316319850277,
+    874.39446992695275, 52.11797177356199,
+    857.36680597299653, 51.103043912231705,
+    1024.1964124687327, 61.046863345428257,
+    925.40789594507817, 55.158608910148025,
+    913.63518965684239, 54.456900933792724,
+    848.90539177252572, 50.598704324515197,
+    992.35137245273086, 59.148751047416368,
+    844.42493013196849, 50.331648000000015,
+], dtype=np.float64)
+
+A0_PLANE = 5.960464477539063e-9   # SMC.h:32
+B0_PLANE = 2.44140625e-5          # SMC.h:33
+
+
+class OrcRng(C.Structure):
+    _fields_ = [("s", C.c_uint32 * 31), ("f", C.c_int32), ("r", C.c_int32)]
+
+
+class OrcSys(C.Structure):
+    _fields_ = [("N", C.c_int32), ("M", C.c_int32), ("L", C.c_double), ("Lz", C.c_double),
+                ("cutoff", C.c_double), ("a0", C.c_double), ("b0", C.c_double),
+                ("Ncx", C.c_int32), ("Ncz", C.c_int32)]
+
+
+class OrcMoveTrace(C.Structure):
+    _fields_ = [("n", C.c_int32), ("accepted", C.c_int32), ("Um", C.c_double),
+                ("Fm", C.c_double * 3), ("delta", C.c_double * 3), ("prop", C.c_double * 3),
+                ("Un", C.c_double), ("Fn", C.c_double * 3), ("ap", C.c_double), ("u", C.c_double)]
+
+
+class OrcChainResult(C.Structure):
+    _fields_ = [("E0", C.c_double), ("meanE", C.c_double), ("dE", C.c_double),
+                ("acceptance_ratio", C.c_double), ("therm_acceptance", C.c_double),
+                ("Efinal", C.c_double), ("accepted", C.c_uint64), ("gathers", C.c_uint64),
+                ("oob", C.c_uint64)]
+
+
+TRACE_DTYPE = np.dtype([("n", "i4"), ("accepted", "i4"), ("Um", "f8"), ("Fm", "f8", 3),
+                        ("delta", "f8", 3), ("prop", "f8", 3), ("Un", "f8"), ("Fn", "f8", 3),
+                        ("ap", "f8"), ("u", "f8")], align=True)
+assert TRACE_DTYPE.itemsize == C.sizeof(OrcMoveTrace)
+
+_dp = C.POINTER(C.c_double)
+
+
+def _ptr(a, t=C.c_double):
+    return a.ctypes.data_as(C.POINTER(t)) if a is not None else None
+
+
+def build(force=False):
+    so = os.path.join(ORACLE_DIR, "libsmc_oracle.so")
+    src = os.path.join(ORACLE_DIR, "smc_oracle.c")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-s", "-C", ORACLE_DIR, "libsmc_oracle.so"])
+    return so
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        L = C.CDLL(build())
+        L.orc_srand.argtypes = [C.POINTER(OrcRng), C.c_uint]
+        L.orc_rand.argtypes = [C.POINTER(OrcRng)]
+        L.orc_rand.restype = C.c_int
+        for f in (L.orc_vec_box_muller, L.orc_vec_box_muller_nw):
+            f.argtypes = [C.POINTER(OrcRng), C.c_double, C.c_size_t, _dp]
+        sp = C.POINTER(OrcSys)
+        L.orc_energy_single.argtypes = [sp, _dp, C.c_int]
+        L.orc_energy_single.restype = C.c_double
+        L.orc_force_single.argtypes = [sp, _dp, C.c_int, _dp]
+        L.orc_walls_energy_single.argtypes = [sp, C.c_double, C.c_double, C.c_double, _dp]
+        L.orc_walls_energy_single.restype = C.c_double
+        L.orc_walls_force.argtypes = [sp, C.c_double, C.c_double, C.c_double, _dp, _dp]
+        L.orc_energy.argtypes = [sp, _dp]
+        L.orc_energy.restype = C.c_double
+        L.orc_walls_energy.argtypes = [sp, _dp, _dp]
+        L.orc_walls_energy.restype = C.c_double
+        L.orc_one_particle_moves.argtypes = [sp, C.POINTER(OrcRng), _dp, _dp, _dp, C.c_double,
+                                             C.c_double, C.POINTER(C.c_int), _dp,
+                                             C.POINTER(OrcMoveTrace)]
+        L.orc_local_density.argtypes = [sp, _dp, C.POINTER(C.c_uint64), C.POINTER(C.c_int32),
+                                        C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        L.orc_chain.argtypes = [sp, C.c_uint, _dp, _dp, C.c_double, C.c_double, C.c_int, C.c_int,
+                                C.c_int, C.c_uint, _dp, C.POINTER(C.c_int32),
+                                C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
+                                C.POINTER(C.c_uint64), C.POINTER(OrcChainResult)]
+        L.orc_chain.restype = C.c_int
+        L.orc_fcc_init.argtypes = [C.c_int, C.c_int, C.c_double, C.c_double, _dp]
+        L.orc_fcc_init.restype = C.c_int
+        L.orc_initialize_box_ref.argtypes = [C.c_double, C.c_double, C.c_int, _dp]
+        L.orc_initialize_box_ref.restype = C.c_int
+        L.orc_initialize_walls.argtypes = [C.c_double] * 4 + [C.c_int, C.c_double, _dp]
+        L.orc_nw_energy_single.argtypes = [C.c_int, _dp, C.c_double, C.c_int]
+        L.orc_nw_energy_single.restype = C.c_double
+        L.orc_nw_force.argtypes = [C.c_int, _dp, C.c_double, C.c_int, _dp]
+        L.orc_nw_energy.argtypes = [C.c_int, _dp, C.c_double]
+        L.orc_nw_energy.restype = C.c_double
+        L.orc_nw_one_particle_moves.argtypes = [C.c_int, C.POINTER(OrcRng), _dp, _dp, C.c_double,
+                                                C.c_double, C.c_double, C.POINTER(C.c_int),
+                                                C.POINTER(OrcMoveTrace)]
+        L.orc_nw_fcc_init.argtypes = [C.c_int, C.c_double, _dp]
+        L.orc_nw_fcc_init.restype = C.c_int
+        L.orc_time_sweeps.argtypes = [sp, C.c_uint, _dp, _dp, C.c_double, C.c_double, C.c_int,
+                                      C.POINTER(C.c_uint64)]
+        L.orc_time_sweeps.restype = C.c_double
+        _lib = L
+    return _lib
+
+
+def make_sys(N, M=3, L=33.0, Lz=240.0, cutoff=3.0, a0=A0_PLANE, b0=B0_PLANE, Ncx=33, Ncz=33):
+    return OrcSys(N, M, L, Lz, cutoff, a0, b0, Ncx, Ncz)
+
+
+class Rng:
+    def __init__(self, seed):
+        self.g = OrcRng()
+        lib().orc_srand(C.byref(self.g), seed)
+
+    def rand(self):
+        return lib().orc_rand(C.byref(self.g))
+
+    def draws(self, n):
+        return np.array([self.rand() for _ in range(n)], dtype=np.int64)
+
+    def box_muller(self, sigma, length, fill=np.nan, nw=False):
+        A = np.full(length, fill, dtype=np.float64)
+        f = lib().orc_vec_box_muller_nw if nw else lib().orc_vec_box_muller
+        f(C.byref(self.g), sigma, length, _ptr(A))
+        return A
+
+
+def fcc(Na, Nz, L=33.0, Lz=240.0):
+    N = 4 * Na * Na * Nz
+    X = np.zeros(3 * N)
+    assert lib().orc_fcc_init(Na, Nz, L, Lz, _ptr(X)) == N
+    return X
+
+
+def box_ref(N, L, Lz):
+    X = np.zeros(3 * N)
+    placed = lib().orc_initialize_box_ref(L, Lz, N, _ptr(X))
+    return X, placed
+
+
+def walls(M=3, uninit=0.0, x0m=1.6, x0sigma=0.0, ymm=3.0, ymsigma=0.5):
+    W = np.zeros(2 * M * M)
+    lib().orc_initialize_walls(x0m, x0sigma, ymm, ymsigma, M, uninit, _ptr(W))
+    return W
+
+
+def energy_single(s, R, i):
+    return lib().orc_energy_single(C.byref(s), _ptr(R), i)
+
+
+def force_single(s, R, i):
+    F = np.zeros(3)
+    lib().orc_force_single(C.byref(s), _ptr(R), i, _ptr(F))
+    return F
+
+
+def walls_energy_single(s, p, W):
+    return lib().orc_walls_energy_single(C.byref(s), p[0], p[1], p[2], _ptr(W))
+
+
+def walls_force(s, p, W, F=None):
+    F = np.zeros(3) if F is None else F
+    lib().orc_walls_force(C.byref(s), p[0], p[1], p[2], _ptr(W), _ptr(F))
+    return F
+
+
+def total_energy(s, R, W):
+    return lib().orc_energy(C.byref(s), _ptr(R)) + lib().orc_walls_energy(C.byref(s), _ptr(R), _ptr(W))
+
+
+def eval_move(s, R, W, n, prop):
+    """Um,Fm at R[n]; Un,Fn with particle n placed at prop (the K1-K4 calls of SMC.c:300-321)."""
+    R = np.array(R, dtype=np.float64, copy=True)
+    Um = energy_single(s, R, n) + walls_energy_single(s, R[3 * n:3 * n + 3], W)
+    Fm = walls_force(s, R[3 * n:3 * n + 3], W, force_single(s, R, n))
+    R[3 * n:3 * n + 3] = prop
+    Un = energy_single(s, R, n) + walls_energy_single(s, prop, W)
+    Fn = walls_force(s, prop, W, force_single(s, R, n))
+    return Um, Fm, Un, Fn
+
+
+def sweep(s, rng, R, W, A, T, E=0.0, trace=False):
+    """One oneParticleMoves call. R is updated in place. Returns (accepted, E, trace|None)."""
+    N = s.N
+    Rn = np.zeros(3 * N)
+    j = C.c_int(0)
+    Ed = C.c_double(E)
+    tr = np.zeros(N, dtype=TRACE_DTYPE) if trace else None
+    tp = tr.ctypes.data_as(C.POINTER(OrcMoveTrace)) if trace else None
+    lib().orc_one_particle_moves(C.byref(s), C.byref(rng.g), _ptr(R), _ptr(Rn), _ptr(W), A, T,
+                                 C.byref(j), C.byref(Ed), tp)
+    return j.value, Ed.value, tr
+
+
+def chain(s, seed, R0, W, T, A, eqsteps, maxsteps, gather_lapse, e0_restart=True, full_hist=False):
+    R = np.array(R0, dtype=np.float64, copy=True)
+    E = np.zeros(maxsteps + 1)
+    jj = np.zeros(max(maxsteps, 1), dtype=np.int32)
+    zh = np.zeros(s.Ncz, dtype=np.uint64)
+    Nc = s.Ncx * s.Ncx * s.Ncz
+    D = np.zeros(Nc, dtype=np.uint64) if full_hist else None
+    Mu = np.zeros(Nc, dtype=np.uint64) if full_hist else None
+    res = OrcChainResult()
+    rc = lib().orc_chain(C.byref(s), seed, _ptr(R), _ptr(W), T, A, eqsteps, maxsteps, gather_lapse,
+                         1 if e0_restart else 0, _ptr(E), _ptr(jj, C.c_int32),
+                         _ptr(zh, C.c_uint64), _ptr(D, C.c_uint64), _ptr(Mu, C.c_uint64),
+                         C.byref(res))
+    assert rc == 0
+    out = {k: getattr(res, k) for k, _ in OrcChainResult._fields_}
+    out.update(R=R, E=E, jj=jj[:maxsteps], zhist=zh, D=D, Mu=Mu)
+    return out
+
+
+def time_sweeps(s, seed, R, W, T, A, sweeps):
+    acc = C.c_uint64(0)
+    t = lib().orc_time_sweeps(C.byref(s), seed, _ptr(R), _ptr(W), T, A, sweeps, C.byref(acc))
+    return t, acc.value
