@@ -1,0 +1,167 @@
+/*
+ * smcx.h -- C ABI of the MI355X-native Smart-Monte-Carlo engine.
+ *
+ * This is the drop-in boundary for the hot path of Kryohi/MonteCarlo-Surfacer:
+ * the force-biased single-particle sweep `oneParticleMoves` and the kernels it
+ * calls, the chain bookkeeping of `sMC`, and the density histogram -- batched
+ * over many independent replica chains on one GPU.  The reference has no
+ * plugin/FFI layer; what this header replaces are the plain C prototypes of
+ * SMC.h:92-114.  Each entry point below names the reference interface it
+ * stands in for.  See INTEGRATION.md for the binding a reference maintainer
+ * would add.
+ *
+ * Conventions
+ *  - plain C types only; every call returns an int status (SMCX_OK == 0);
+ *    nothing aborts or exits (the reference returns void and prints,
+ *    SMC.c:99-100, 428, 463).
+ *  - positions are the reference layout: AoS double r[3N] = x0,y0,z0,x1,...
+ *    (SMC.c:44, 567-571), one block of 3N per replica.
+ *  - wall strengths W[2*M*M] = a0,b0,a1,b1,... (SMC.c:495-496).
+ *  - N, M, cutoff, a0, b0, Ncx, Ncz are run-time fields here; the reference
+ *    bakes them in as macros (SMC.h:26-58).
+ *  - RNG: each replica owns a glibc-compatible rand() stream (TYPE_3 additive
+ *    feedback, what srand()/rand() are on glibc 2.35); it is explicit state in
+ *    the handle, not libc's hidden global (SMC.c:40, 290, 335).
+ *  - a handle is confined to one host thread and one GPU.
+ */
+#ifndef SMCX_H
+#define SMCX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SMCX_VERSION 100 /* 0.1.0 */
+
+/* status codes */
+#define SMCX_OK 0
+#define SMCX_ERR_PARAM 1       /* invalid argument / parameter combination */
+#define SMCX_ERR_HIP 2         /* a HIP runtime call failed (smcx_last_error_string) */
+#define SMCX_ERR_STATE 3       /* call order violated (e.g. run before upload) */
+#define SMCX_ERR_NOMEM 4
+#define SMCX_ERR_UNSUPPORTED 5 /* valid request this build cannot serve */
+#define SMCX_ERR_NODEVICE 6    /* no HIP device visible */
+
+/* flags */
+#define SMCX_FLAG_WALLS 0x1u      /* K3/K4 wall terms on (SMC.c:300-304); off = particles only */
+#define SMCX_FLAG_E0_RESTART 0x2u /* production energy series restarts from the pre-
+                                     thermalisation energy, as SMC.c:116-117 vs 194 does */
+#define SMCX_FLAG_SERIES 0x4u     /* keep per-sweep E and accepted-count series (data_*.csv
+                                     columns, SMC.c:214-215) for the last smcx_run */
+#define SMCX_FLAGS_REFERENCE (SMCX_FLAG_WALLS | SMCX_FLAG_E0_RESTART)
+
+typedef struct smcx_params {
+    int32_t N;       /* particles per replica            (SMC.h:29)  even, >= 2 */
+    int32_t M;       /* wall sites per side, M*M total   (SMC.h:26)  M*M+1 <= 30 */
+    int32_t nrep;    /* replica chains held by this handle (the reference: one per MPI rank) */
+    int32_t device;  /* HIP device ordinal */
+    double L, Lz;    /* box: L x L x Lz, periodic in x,y only (main.c:35-44) */
+    double T;        /* temperature (main.c:18) */
+    double A;        /* SMC step parameter A = gamma*T (main.c:48-51) */
+    double cutoff;   /* LJ_CUTOFF (SMC.h:38) */
+    double a0, b0;   /* featureless-plane 12-6 coefficients (SMC.h:32-33) */
+    int32_t Ncx, Ncz; /* histogram cells (SMC.h:53-55); Ncx,Ncz <= 255 */
+    uint32_t flags;  /* SMCX_FLAG_* */
+    uint32_t base_seed;     /* replica r is seeded srand(base_seed + first_replica + r) */
+    uint32_t first_replica; /* global index of this handle's first replica (multi-GPU shard) */
+    int32_t tune_slots;     /* 0 = auto; else particles per lane (1,2,4,...,64) */
+    int32_t tune_waves;     /* 0 = auto; else wavefronts per replica (1,2,4,8,16) */
+} smcx_params;
+
+/* fills *p with the reference's defaults (SMC.h macros, main.c:35-51: L=33,
+ * Lz=240, T=A=1.1, cutoff 3, M=3, 33x33x33 cells, seed 12345) for given N,nrep */
+void smcx_default_params(smcx_params *p, int32_t N, int32_t nrep);
+
+typedef struct smcx_handle smcx_handle;
+
+int smcx_device_count(int *count);
+int smcx_create(const smcx_params *p, smcx_handle **out);
+int smcx_destroy(smcx_handle *h);
+const char *smcx_strerror(int status);
+/* text of the last HIP error seen by this handle (h may be NULL: process-wide) */
+const char *smcx_last_error_string(const smcx_handle *h);
+
+/* Load initial state: R0 (shared [3N] if r0_per_replica==0, else [nrep][3N]),
+ * W[2*M*M] (may be NULL when walls are off), seeds[nrep] (NULL = base_seed
+ * rule).  Seeds the RNG streams, zeroes observables and evaluates
+ * E[0] = energy + wallsEnergy on the device (SMC.c:44-48). */
+int smcx_upload(smcx_handle *h, const double *R0, int r0_per_replica, const double *W,
+                const uint32_t *seeds);
+
+/* The loop of sMC (SMC.c:108-126, 134-196) for every replica:
+ * `eqsteps` thermalisation sweeps at 2A, then `maxsteps` production sweeps at
+ * A with the density histogram taken when (n+1) % gather_lapse == 0, before
+ * that sweep's moves.  Observables are reset at entry and describe this call. */
+int smcx_run(smcx_handle *h, int eqsteps, int maxsteps, int gather_lapse);
+
+/* Results of the last smcx_run; any pointer may be NULL.
+ *  acceptance_ratio[nrep] = intmean(jj)/N                      (SMC.c:248)
+ *  meanE[nrep]            = mean(E[0..maxsteps] + 3NT/2)       (SMC.c:210-211, 244)
+ *  dE[nrep]               = sqrt(variance(E))                  (SMC.c:245)
+ *  zhist[nrep][Ncz]       = sum over i,j of the cumulative D[i][j][k] of
+ *                           localDensityAndMobility (SMC.c:912-927; plotting.jl:134-166)
+ *  accepted[nrep]         = total accepted moves in production
+ *  E_last[nrep]           = last entry of the energy series (without 3NT/2) */
+int smcx_observables(smcx_handle *h, double *acceptance_ratio, double *meanE, double *dE,
+                     uint64_t *zhist, uint64_t *accepted, double *E_last);
+/* thermalisation acceptance of the last run, intmean(jt)/N (SMC.c:124) */
+int smcx_therm_acceptance(smcx_handle *h, double *ratio);
+/* number of histogram calls and of out-of-range cells (undefined behaviour in
+ * the reference: counted, not written) per replica; either may be NULL */
+int smcx_hist_info(smcx_handle *h, uint64_t *gathers, uint64_t *oob);
+
+/* per-sweep series of the last run (needs SMCX_FLAG_SERIES):
+ * E_series[nrep][maxsteps+1] without 3NT/2, jj[nrep][maxsteps] */
+int smcx_series(smcx_handle *h, double *E_series, int32_t *jj);
+
+/* current positions, [nrep][3N] (struct Sim.Rfinal, SMC.h:84) */
+int smcx_download_positions(smcx_handle *h, double *R);
+
+/* energy + wallsEnergy of the current positions, recomputed from scratch
+ * (SMC.c:626-646, 822-859), E[nrep] */
+int smcx_total_energy(smcx_handle *h, double *E);
+
+/* RNG checkpoint: 32 words per replica (31 most recent outputs' state words,
+ * oldest first, then the count of generated-but-unconsumed words) */
+int smcx_rng_export(smcx_handle *h, uint32_t *state);
+int smcx_rng_import(smcx_handle *h, const uint32_t *state);
+
+/* Copy packed per-replica observables of the last run into DEVICE memory the
+ * caller owns (for an RCCL gather across ranks): nrep records of
+ * SMCX_OBS_RECORD_DOUBLES doubles {accepted, nsamples, sumE, sumE2, E_last,
+ * therm_accepted, gathers, oob} followed by nrep*Ncz doubles of zhist.
+ * bytes must be smcx_obs_device_bytes(h). */
+#define SMCX_OBS_RECORD_DOUBLES 8
+size_t smcx_obs_device_bytes(const smcx_handle *h);
+int smcx_export_observables_device(smcx_handle *h, void *dst_device, size_t bytes);
+
+/* timing of the sweep kernel(s) of the last smcx_run, HIP events on the
+ * launch stream: total milliseconds and number of launches */
+int smcx_last_kernel_ms(smcx_handle *h, double *ms, int *launches);
+/* the launch geometry chosen for this handle */
+int smcx_geometry(const smcx_handle *h, int *slots, int *waves_per_replica, int *lds_bytes);
+
+/* Teacher-forced evaluator (stateless; tests and debugging): for each of nrep
+ * replicas evaluates what SMC.c:300-304 and 319-321 evaluate for particle
+ * n[r]: Um,Fm at R[r][n] and Un,Fn with particle n placed at prop[r].
+ * R [nrep][3N], n [nrep], prop [nrep][3], out [nrep][8] = Um,Fmx,Fmy,Fmz,Un,Fnx,Fny,Fnz */
+int smcx_eval_moves(const smcx_params *p, const double *R, const double *W, const int32_t *n,
+                    const double *prop, double *out);
+
+/* Single-chain shim with the contract of
+ *   void oneParticleMoves(double *R, double *Rn, const double *W, double L,
+ *                         double Lz, double A, double T, int *j, double *U)   (SMC.h:102)
+ * plus what its macros and libc's hidden rand() state carried implicitly.
+ * R and Rn are updated in place, *j and *U are accumulated into, rng (32
+ * words, smcx_rng_export layout) is advanced by the 4N+1 draws of one sweep. */
+void smcx_rng_seed(uint32_t *rng, uint32_t seed); /* srand(seed) */
+int smcx_one_particle_moves(const smcx_params *p, uint32_t *rng, double *R, double *Rn,
+                            const double *W, double A, double T, int *j, double *U);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SMCX_H */

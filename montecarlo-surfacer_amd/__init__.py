@@ -1,0 +1,259 @@
+"""montecarlo-surfacer_amd -- MI355X-native Smart-Monte-Carlo engine (Python glue).
+
+The product is the C-ABI shared library ``libsmcx.so`` (HIP kernels for gfx950 +
+``include/smcx.h``); this module is only a ctypes binding of that ABI used by the
+tests, ``bench.py`` and the multi-GPU driver.  There is no CPU fallback: if the
+library is missing this import raises, and without a GPU every compute call
+returns an error status which is raised as :class:`SmcxError`.
+
+The directory name has a hyphen (it mirrors the reference's name), so import it
+through ``smcx_loader.load()`` at the repo root or with importlib.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsmcx.so")
+
+OK, ERR_PARAM, ERR_HIP, ERR_STATE, ERR_NOMEM, ERR_UNSUPPORTED, ERR_NODEVICE = range(7)
+FLAG_WALLS, FLAG_E0_RESTART, FLAG_SERIES = 1, 2, 4
+FLAGS_REFERENCE = FLAG_WALLS | FLAG_E0_RESTART
+OBS_RECORD_DOUBLES = 8
+
+
+class Params(C.Structure):
+    """mirror of smcx_params (include/smcx.h)"""
+    _fields_ = [("N", C.c_int32), ("M", C.c_int32), ("nrep", C.c_int32), ("device", C.c_int32),
+                ("L", C.c_double), ("Lz", C.c_double), ("T", C.c_double), ("A", C.c_double),
+                ("cutoff", C.c_double), ("a0", C.c_double), ("b0", C.c_double),
+                ("Ncx", C.c_int32), ("Ncz", C.c_int32), ("flags", C.c_uint32),
+                ("base_seed", C.c_uint32), ("first_replica", C.c_uint32),
+                ("tune_slots", C.c_int32), ("tune_waves", C.c_int32)]
+
+
+class SmcxError(RuntimeError):
+    def __init__(self, status, where, detail=""):
+        self.status = status
+        msg = "%s failed: status %d (%s)" % (where, status, _lib().smcx_strerror(status).decode())
+        if detail:
+            msg += " -- " + detail
+        super().__init__(msg)
+
+
+_LIB = None
+_dp = C.POINTER(C.c_double)
+_u64p = C.POINTER(C.c_uint64)
+_u32p = C.POINTER(C.c_uint32)
+_i32p = C.POINTER(C.c_int32)
+
+EXPORTS = [
+    "smcx_default_params", "smcx_device_count", "smcx_create", "smcx_destroy", "smcx_strerror",
+    "smcx_last_error_string", "smcx_upload", "smcx_run", "smcx_observables",
+    "smcx_therm_acceptance", "smcx_hist_info", "smcx_series", "smcx_download_positions",
+    "smcx_total_energy", "smcx_rng_export", "smcx_rng_import", "smcx_obs_device_bytes",
+    "smcx_export_observables_device", "smcx_last_kernel_ms", "smcx_geometry", "smcx_eval_moves",
+    "smcx_rng_seed", "smcx_one_particle_moves",
+]
+
+
+def _lib():
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError("libsmcx.so is not built (run __graft_entry__.build() or "
+                              "make -C montecarlo-surfacer_amd/csrc); there is no CPU fallback")
+        L = C.CDLL(LIB_PATH)
+        vp = C.c_void_p
+        L.smcx_default_params.argtypes = [C.POINTER(Params), C.c_int32, C.c_int32]
+        L.smcx_default_params.restype = None
+        L.smcx_device_count.argtypes = [C.POINTER(C.c_int)]
+        L.smcx_create.argtypes = [C.POINTER(Params), C.POINTER(vp)]
+        L.smcx_destroy.argtypes = [vp]
+        L.smcx_strerror.argtypes = [C.c_int]
+        L.smcx_strerror.restype = C.c_char_p
+        L.smcx_last_error_string.argtypes = [vp]
+        L.smcx_last_error_string.restype = C.c_char_p
+        L.smcx_upload.argtypes = [vp, _dp, C.c_int, _dp, _u32p]
+        L.smcx_run.argtypes = [vp, C.c_int, C.c_int, C.c_int]
+        L.smcx_observables.argtypes = [vp, _dp, _dp, _dp, _u64p, _u64p, _dp]
+        L.smcx_therm_acceptance.argtypes = [vp, _dp]
+        L.smcx_hist_info.argtypes = [vp, _u64p, _u64p]
+        L.smcx_series.argtypes = [vp, _dp, _i32p]
+        L.smcx_download_positions.argtypes = [vp, _dp]
+        L.smcx_total_energy.argtypes = [vp, _dp]
+        L.smcx_rng_export.argtypes = [vp, _u32p]
+        L.smcx_rng_import.argtypes = [vp, _u32p]
+        L.smcx_obs_device_bytes.argtypes = [vp]
+        L.smcx_obs_device_bytes.restype = C.c_size_t
+        L.smcx_export_observables_device.argtypes = [vp, vp, C.c_size_t]
+        L.smcx_last_kernel_ms.argtypes = [vp, _dp, C.POINTER(C.c_int)]
+        L.smcx_geometry.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.smcx_eval_moves.argtypes = [C.POINTER(Params), _dp, _dp, _i32p, _dp, _dp]
+        L.smcx_rng_seed.argtypes = [_u32p, C.c_uint32]
+        L.smcx_rng_seed.restype = None
+        L.smcx_one_particle_moves.argtypes = [C.POINTER(Params), _u32p, _dp, _dp, _dp, C.c_double,
+                                              C.c_double, C.POINTER(C.c_int), _dp]
+        _LIB = L
+    return _LIB
+
+
+def _p(a, t):
+    return a.ctypes.data_as(C.POINTER(t)) if a is not None else None
+
+
+def default_params(N, nrep, **kw):
+    p = Params()
+    _lib().smcx_default_params(C.byref(p), N, nrep)
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
+def device_count():
+    n = C.c_int(0)
+    _lib().smcx_device_count(C.byref(n))
+    return n.value
+
+
+def rng_seed(seed):
+    st = np.zeros(32, dtype=np.uint32)
+    _lib().smcx_rng_seed(_p(st, C.c_uint32), seed)
+    return st
+
+
+def eval_moves(params, R, W, n, prop):
+    """teacher-forced Um,Fm,Un,Fn (SMC.c:300-304, 319-321); returns [nrep][8]"""
+    R = np.ascontiguousarray(R, dtype=np.float64)
+    n = np.ascontiguousarray(n, dtype=np.int32)
+    prop = np.ascontiguousarray(prop, dtype=np.float64)
+    W = None if W is None else np.ascontiguousarray(W, dtype=np.float64)
+    out = np.zeros((params.nrep, 8))
+    rc = _lib().smcx_eval_moves(C.byref(params), _p(R, C.c_double), _p(W, C.c_double),
+                                _p(n, C.c_int32), _p(prop, C.c_double), _p(out, C.c_double))
+    if rc != OK:
+        raise SmcxError(rc, "smcx_eval_moves", _lib().smcx_last_error_string(None).decode())
+    return out
+
+
+def one_particle_moves(params, rng, R, Rn, W, A, T, j, U):
+    """oneParticleMoves (SMC.h:102) for one chain on the GPU; returns (j, U), arrays in place"""
+    jj = C.c_int(j)
+    UU = C.c_double(U)
+    W = None if W is None else np.ascontiguousarray(W, dtype=np.float64)
+    rc = _lib().smcx_one_particle_moves(C.byref(params), _p(rng, C.c_uint32), _p(R, C.c_double),
+                                        _p(Rn, C.c_double), _p(W, C.c_double), A, T, C.byref(jj),
+                                        C.byref(UU))
+    if rc != OK:
+        raise SmcxError(rc, "smcx_one_particle_moves", _lib().smcx_last_error_string(None).decode())
+    return jj.value, UU.value
+
+
+class Engine:
+    """One handle = the replica chains of one GPU (the batched form of sMC, SMC.c:21)."""
+
+    def __init__(self, params):
+        self.p = params
+        self._h = C.c_void_p()
+        self._chk(_lib().smcx_create(C.byref(params), C.byref(self._h)), "smcx_create")
+
+    def _chk(self, rc, where):
+        if rc != OK:
+            detail = _lib().smcx_last_error_string(self._h).decode() if self._h else \
+                _lib().smcx_last_error_string(None).decode()
+            raise SmcxError(rc, where, detail)
+
+    def close(self):
+        if self._h:
+            _lib().smcx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    @property
+    def geometry(self):
+        s, w, l = C.c_int(), C.c_int(), C.c_int()
+        self._chk(_lib().smcx_geometry(self._h, C.byref(s), C.byref(w), C.byref(l)), "smcx_geometry")
+        return s.value, w.value, l.value
+
+    def upload(self, R0, W, seeds=None):
+        R0 = np.ascontiguousarray(R0, dtype=np.float64)
+        per = 1 if R0.size == self.p.nrep * 3 * self.p.N and self.p.nrep > 1 else 0
+        if not per and R0.size != 3 * self.p.N:
+            raise ValueError("R0 must be [3N] or [nrep][3N]")
+        W = None if W is None else np.ascontiguousarray(W, dtype=np.float64)
+        seeds = None if seeds is None else np.ascontiguousarray(seeds, dtype=np.uint32)
+        self._chk(_lib().smcx_upload(self._h, _p(R0, C.c_double), per, _p(W, C.c_double),
+                                     _p(seeds, C.c_uint32)), "smcx_upload")
+
+    def run(self, eqsteps, maxsteps, gather_lapse):
+        self._chk(_lib().smcx_run(self._h, eqsteps, maxsteps, gather_lapse), "smcx_run")
+
+    def observables(self):
+        n, ncz = self.p.nrep, self.p.Ncz
+        acc, mE, dE, El = (np.zeros(n) for _ in range(4))
+        zh = np.zeros((n, ncz), dtype=np.uint64)
+        cnt = np.zeros(n, dtype=np.uint64)
+        self._chk(_lib().smcx_observables(self._h, _p(acc, C.c_double), _p(mE, C.c_double),
+                                          _p(dE, C.c_double), _p(zh, C.c_uint64),
+                                          _p(cnt, C.c_uint64), _p(El, C.c_double)), "smcx_observables")
+        return dict(acceptance_ratio=acc, meanE=mE, dE=dE, zhist=zh, accepted=cnt, E_last=El)
+
+    def therm_acceptance(self):
+        r = np.zeros(self.p.nrep)
+        self._chk(_lib().smcx_therm_acceptance(self._h, _p(r, C.c_double)), "smcx_therm_acceptance")
+        return r
+
+    def hist_info(self):
+        g = np.zeros(self.p.nrep, dtype=np.uint64)
+        o = np.zeros(self.p.nrep, dtype=np.uint64)
+        self._chk(_lib().smcx_hist_info(self._h, _p(g, C.c_uint64), _p(o, C.c_uint64)), "smcx_hist_info")
+        return g, o
+
+    def series(self, maxsteps):
+        E = np.zeros((self.p.nrep, maxsteps + 1))
+        jj = np.zeros((self.p.nrep, max(maxsteps, 1)), dtype=np.int32)
+        self._chk(_lib().smcx_series(self._h, _p(E, C.c_double), _p(jj, C.c_int32)), "smcx_series")
+        return E, jj[:, :maxsteps]
+
+    def positions(self):
+        R = np.zeros((self.p.nrep, 3 * self.p.N))
+        self._chk(_lib().smcx_download_positions(self._h, _p(R, C.c_double)), "smcx_download_positions")
+        return R
+
+    def total_energy(self):
+        E = np.zeros(self.p.nrep)
+        self._chk(_lib().smcx_total_energy(self._h, _p(E, C.c_double)), "smcx_total_energy")
+        return E
+
+    def rng_export(self):
+        st = np.zeros((self.p.nrep, 32), dtype=np.uint32)
+        self._chk(_lib().smcx_rng_export(self._h, _p(st, C.c_uint32)), "smcx_rng_export")
+        return st
+
+    def rng_import(self, st):
+        st = np.ascontiguousarray(st, dtype=np.uint32)
+        self._chk(_lib().smcx_rng_import(self._h, _p(st, C.c_uint32)), "smcx_rng_import")
+
+    def obs_device_bytes(self):
+        return _lib().smcx_obs_device_bytes(self._h)
+
+    def export_observables_device(self, dev_ptr, nbytes):
+        self._chk(_lib().smcx_export_observables_device(self._h, C.c_void_p(dev_ptr), nbytes),
+                  "smcx_export_observables_device")
+
+    def last_kernel_ms(self):
+        ms, n = C.c_double(), C.c_int()
+        self._chk(_lib().smcx_last_kernel_ms(self._h, C.byref(ms), C.byref(n)), "smcx_last_kernel_ms")
+        return ms.value, n.value

@@ -1,0 +1,620 @@
+// smcx_api.hip -- the C ABI of include/smcx.h on top of the gfx950 kernels.
+// Host-side orchestration only: no physics is computed on the CPU here, and
+// there is no CPU fallback -- without a HIP device every compute entry fails
+// with SMCX_ERR_NODEVICE / SMCX_ERR_HIP.
+#include "../../include/smcx.h"
+#include "smcx_kernels.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+using namespace smcx;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+struct Handle {
+    smcx_params p;
+    DevCtx c;
+    int S = 0, WPR = 0;
+    int chunk = 1;          // sweeps of random numbers per pre-pass launch
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    double *d_save = nullptr;   // [nrep] energy at smcx_run entry
+    double *d_tmp = nullptr;    // [nrep] scratch (energies)
+    bool uploaded = false;
+    int last_maxsteps = 0;
+    int last_eqsteps = 0;
+    double last_ms = 0.0;
+    int last_launches = 0;
+    std::string err;
+};
+
+} // namespace
+
+struct smcx_handle {
+    Handle h;
+};
+
+#define HIPCHK(hh, call)                                                                      \
+    do {                                                                                      \
+        hipError_t e_ = (call);                                                               \
+        if (e_ != hipSuccess) {                                                               \
+            std::string m_ = std::string(#call) + ": " + hipGetErrorString(e_);               \
+            g_last_error = m_;                                                                \
+            if (hh) (hh)->err = m_;                                                           \
+            return SMCX_ERR_HIP;                                                              \
+        }                                                                                     \
+    } while (0)
+
+// ---- glibc srand(): the state after seeding and its 310 discarded outputs ----------
+// (SURVEY.md 8a row R).  Output layout: 31 state words oldest first, then the
+// count of generated-but-unconsumed outputs (0 after seeding).
+static void seed_state(uint32_t seed, uint32_t out[32])
+{
+    uint32_t s[31];
+    if (seed == 0) seed = 1;
+    int64_t w = (int64_t)seed;
+    s[0] = seed;
+    for (int i = 1; i < 31; i++) {
+        const int64_t hi = w / 127773, lo = w % 127773;
+        w = 16807 * lo - 2836 * hi;
+        if (w < 0) w += 2147483647;
+        s[i] = (uint32_t)w;
+    }
+    int f = 3, r = 0;
+    for (int i = 0; i < 310; i++) {
+        s[f] += s[r];
+        f = (f + 1) % 31;
+        r = (r + 1) % 31;
+    }
+    // the word at f is the oldest (it is the next to be overwritten)
+    for (int j = 0; j < 31; j++) out[j] = s[(f + j) % 31];
+    out[31] = 0;
+}
+
+extern "C" void smcx_rng_seed(uint32_t *rng, uint32_t seed) { seed_state(seed, rng); }
+
+extern "C" void smcx_default_params(smcx_params *p, int32_t N, int32_t nrep)
+{
+    std::memset(p, 0, sizeof(*p));
+    p->N = N;
+    p->M = 3;                        // SMC.h:26
+    p->nrep = nrep;
+    p->device = 0;
+    p->L = 33.0;                     // main.c:41-44
+    p->Lz = 240.0;
+    p->T = 1.1;                      // main.c:18
+    p->A = 1.1;                      // main.c:48-51, gamma = 1
+    p->cutoff = 3.0;                 // SMC.h:38
+    p->a0 = 5.960464477539063e-9;    // SMC.h:32
+    p->b0 = 2.44140625e-5;           // SMC.h:33
+    p->Ncx = 33;                     // SMC.h:53
+    p->Ncz = 33;                     // SMC.h:55
+    p->flags = SMCX_FLAGS_REFERENCE;
+    p->base_seed = 12345;
+    p->first_replica = 0;
+}
+
+extern "C" const char *smcx_strerror(int status)
+{
+    switch (status) {
+    case SMCX_OK: return "ok";
+    case SMCX_ERR_PARAM: return "invalid parameter";
+    case SMCX_ERR_HIP: return "HIP runtime error";
+    case SMCX_ERR_STATE: return "call order violated";
+    case SMCX_ERR_NOMEM: return "out of memory";
+    case SMCX_ERR_UNSUPPORTED: return "unsupported configuration";
+    case SMCX_ERR_NODEVICE: return "no HIP device";
+    default: return "unknown status";
+    }
+}
+
+extern "C" const char *smcx_last_error_string(const smcx_handle *h)
+{
+    if (h && !h->h.err.empty()) return h->h.err.c_str();
+    return g_last_error.c_str();
+}
+
+extern "C" int smcx_device_count(int *count)
+{
+    if (!count) return SMCX_ERR_PARAM;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        *count = 0;
+        g_last_error = std::string("hipGetDeviceCount: ") + hipGetErrorString(e);
+        return SMCX_ERR_NODEVICE;
+    }
+    *count = n;
+    return n > 0 ? SMCX_OK : SMCX_ERR_NODEVICE;
+}
+
+static int validate(const smcx_params *p)
+{
+    if (!p) return SMCX_ERR_PARAM;
+    if (p->N < 2 || (p->N & 1)) return SMCX_ERR_PARAM; // odd 3N: vecBoxMuller leaves displ[3N-1] unset
+    if (p->nrep < 1) return SMCX_ERR_PARAM;
+    if (!(p->L > 0) || !(p->Lz > 0) || !(p->T > 0) || !(p->A > 0) || !(p->cutoff > 0))
+        return SMCX_ERR_PARAM;
+    if (p->Ncx < 1 || p->Ncz < 1 || p->Ncx > 255 || p->Ncz > 255) return SMCX_ERR_PARAM;
+    if (p->flags & SMCX_FLAG_WALLS) {
+        if (p->M < 1) return SMCX_ERR_PARAM;
+        if (p->M * p->M + 1 > 30) return SMCX_ERR_UNSUPPORTED;
+    }
+    return SMCX_OK;
+}
+
+// particles per lane (S) and wavefronts per replica (WPR): smallest geometry whose
+// capacity 64*WPR*S holds N; one wavefront per replica up to N = 2048
+static int choose_geometry(const smcx_params *p, int *S, int *WPR)
+{
+    if (p->tune_slots > 0 || p->tune_waves > 0) {
+        int s = p->tune_slots > 0 ? p->tune_slots : 16;
+        int w = p->tune_waves > 0 ? p->tune_waves : 1;
+        if (!geometry_supported(s, w) || (long)s * w * 64 < p->N) return SMCX_ERR_UNSUPPORTED;
+        *S = s; *WPR = w;
+        return SMCX_OK;
+    }
+    static const int cand[][2] = {{1, 1}, {2, 1}, {4, 1}, {8, 1}, {16, 1}, {32, 1},
+                                  {32, 2}, {32, 4}, {32, 8}, {32, 16}};
+    for (auto &g : cand) {
+        if ((long)g[0] * g[1] * 64 >= p->N && geometry_supported(g[0], g[1])) {
+            *S = g[0]; *WPR = g[1];
+            return SMCX_OK;
+        }
+    }
+    return SMCX_ERR_UNSUPPORTED;
+}
+
+static void fill_ctx(Handle &h)
+{
+    const smcx_params &p = h.p;
+    DevCtx &c = h.c;
+    c.N = p.N; c.M = p.M; c.M2 = p.M * p.M; c.nrep = p.nrep;
+    c.Ncx = p.Ncx; c.Ncz = p.Ncz;
+    c.flags = p.flags;
+    c.L = p.L; c.invL = 1.0 / p.L; c.Lz = p.Lz; c.invLz = 1.0 / p.Lz; c.halfLz = p.Lz / 2;
+    c.T = p.T; c.invT = 1.0 / p.T;
+    c.cutoff2 = p.cutoff * p.cutoff;
+    c.a0 = p.a0; c.b0 = p.b0;
+    c.c3NT2 = 3 * p.N * p.T / 2; // SMC.c:211
+    c.chunk = h.chunk;
+    c.rawStride = 4L * p.N + 1 + 31 + 3; // one sweep of outputs + a partial block, padded
+}
+
+extern "C" int smcx_destroy(smcx_handle *hh)
+{
+    if (!hh) return SMCX_OK;
+    Handle &h = hh->h;
+    hipSetDevice(h.p.device);
+    DevCtx &c = h.c;
+    hipFree(c.R); hipFree((void *)c.W); hipFree(c.rng); hipFree(c.raw); hipFree(c.displ);
+    hipFree(c.uni); hipFree(c.offs); hipFree(c.obs); hipFree(c.zhist); hipFree(c.Eseries);
+    hipFree(c.jjseries); hipFree(h.d_save); hipFree(h.d_tmp);
+    if (h.ev0) hipEventDestroy(h.ev0);
+    if (h.ev1) hipEventDestroy(h.ev1);
+    if (h.stream) hipStreamDestroy(h.stream);
+    delete hh;
+    return SMCX_OK;
+}
+
+extern "C" int smcx_create(const smcx_params *p, smcx_handle **out)
+{
+    if (!out) return SMCX_ERR_PARAM;
+    *out = nullptr;
+    int rc = validate(p);
+    if (rc != SMCX_OK) return rc;
+    int ndev = 0;
+    rc = smcx_device_count(&ndev);
+    if (rc != SMCX_OK) return rc;
+    if (p->device < 0 || p->device >= ndev) return SMCX_ERR_PARAM;
+
+    smcx_handle *hh = new (std::nothrow) smcx_handle();
+    if (!hh) return SMCX_ERR_NOMEM;
+    Handle &h = hh->h;
+    h.p = *p;
+    std::memset(&h.c, 0, sizeof(h.c));
+    rc = choose_geometry(p, &h.S, &h.WPR);
+    if (rc != SMCX_OK) { delete hh; return rc; }
+
+    // sweeps of random numbers kept on the device at once: bounded by ~6 GB
+    const double per_sweep = (double)p->nrep * (32.0 * p->N + 8);
+    h.chunk = (int)std::fmax(1.0, std::fmin(16.0, std::floor(6.0e9 / per_sweep)));
+    fill_ctx(h);
+
+#define CRT(call)                                                                             \
+    do {                                                                                      \
+        hipError_t e_ = (call);                                                               \
+        if (e_ != hipSuccess) {                                                               \
+            g_last_error = std::string(#call) + ": " + hipGetErrorString(e_);                 \
+            smcx_destroy(hh);                                                                 \
+            return e_ == hipErrorOutOfMemory ? SMCX_ERR_NOMEM : SMCX_ERR_HIP;                 \
+        }                                                                                     \
+    } while (0)
+
+    DevCtx &c = h.c;
+    const size_t nrep = p->nrep, N = p->N;
+    CRT(hipSetDevice(p->device));
+    CRT(hipStreamCreate(&h.stream));
+    CRT(hipEventCreate(&h.ev0));
+    CRT(hipEventCreate(&h.ev1));
+    CRT(hipMalloc(&c.R, nrep * 3 * N * sizeof(double)));
+    CRT(hipMalloc((void **)&c.W, (size_t)(2 * c.M2 > 2 ? 2 * c.M2 : 2) * sizeof(double)));
+    CRT(hipMalloc(&c.rng, nrep * 32 * sizeof(uint32_t)));
+    CRT(hipMalloc(&c.raw, nrep * (size_t)c.rawStride * sizeof(uint32_t)));
+    CRT(hipMalloc(&c.displ, nrep * h.chunk * 3 * N * sizeof(double)));
+    CRT(hipMalloc(&c.uni, nrep * h.chunk * N * sizeof(double)));
+    CRT(hipMalloc(&c.offs, nrep * h.chunk * sizeof(int)));
+    CRT(hipMalloc(&c.obs, nrep * sizeof(ObsRec)));
+    CRT(hipMalloc(&c.zhist, nrep * p->Ncz * sizeof(unsigned long long)));
+    CRT(hipMalloc(&h.d_save, nrep * sizeof(double)));
+    CRT(hipMalloc(&h.d_tmp, nrep * sizeof(double)));
+    CRT(hipMemset(c.obs, 0, nrep * sizeof(ObsRec)));
+    CRT(hipMemset(c.zhist, 0, nrep * p->Ncz * sizeof(unsigned long long)));
+    CRT(hipMemset((void *)c.W, 0, (size_t)(2 * c.M2 > 2 ? 2 * c.M2 : 2) * sizeof(double)));
+#undef CRT
+    *out = hh;
+    return SMCX_OK;
+}
+
+extern "C" int smcx_geometry(const smcx_handle *hh, int *slots, int *waves, int *lds_bytes)
+{
+    if (!hh) return SMCX_ERR_PARAM;
+    if (slots) *slots = hh->h.S;
+    if (waves) *waves = hh->h.WPR;
+    if (lds_bytes) *lds_bytes = (int)(sizeof(RoleTable) + 2 * hh->h.WPR * 8 * 8 + 2 * 2 * 4 * 8 + 257 * 4);
+    return SMCX_OK;
+}
+
+extern "C" int smcx_upload(smcx_handle *hh, const double *R0, int r0_per_replica, const double *W,
+                           const uint32_t *seeds)
+{
+    if (!hh || !R0) return SMCX_ERR_PARAM;
+    Handle &h = hh->h;
+    const smcx_params &p = h.p;
+    DevCtx &c = h.c;
+    if ((p.flags & SMCX_FLAG_WALLS) && !W) return SMCX_ERR_PARAM;
+    HIPCHK(&h, hipSetDevice(p.device));
+    const size_t nrep = p.nrep, row = 3 * (size_t)p.N;
+    if (r0_per_replica) {
+        HIPCHK(&h, hipMemcpy(c.R, R0, nrep * row * sizeof(double), hipMemcpyHostToDevice));
+    } else {
+        // all replicas start from the common R0 (SMC.c:43)
+        HIPCHK(&h, hipMemcpy(c.R, R0, row * sizeof(double), hipMemcpyHostToDevice));
+        size_t have = 1;
+        while (have < nrep) {
+            const size_t n = (have < nrep - have) ? have : nrep - have;
+            HIPCHK(&h, hipMemcpy(c.R + have * row, c.R, n * row * sizeof(double),
+                                 hipMemcpyDeviceToDevice));
+            have += n;
+        }
+    }
+    if (W)
+        HIPCHK(&h, hipMemcpy((void *)c.W, W, 2 * (size_t)c.M2 * sizeof(double), hipMemcpyHostToDevice));
+    std::vector<uint32_t> st(nrep * 32);
+    for (size_t r = 0; r < nrep; r++) {
+        const uint32_t seed = seeds ? seeds[r] : (uint32_t)(p.base_seed + p.first_replica + r);
+        seed_state(seed, &st[r * 32]);
+    }
+    HIPCHK(&h, hipMemcpy(c.rng, st.data(), st.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    HIPCHK(&h, hipMemset(c.obs, 0, nrep * sizeof(ObsRec)));
+    HIPCHK(&h, hipMemset(c.zhist, 0, nrep * p.Ncz * sizeof(unsigned long long)));
+    // E[0] = energy + wallsEnergy (SMC.c:48)
+    HIPCHK(&h, launch_total_energy(c, h.d_tmp, h.stream));
+    HIPCHK(&h, launch_obs_op(c, h.d_tmp, 1, h.stream));
+    HIPCHK(&h, hipStreamSynchronize(h.stream));
+    h.uploaded = true;
+    h.last_maxsteps = 0;
+    return SMCX_OK;
+}
+
+static int ensure_series(Handle &h, int maxsteps)
+{
+    DevCtx &c = h.c;
+    if (!(h.p.flags & SMCX_FLAG_SERIES)) {
+        c.series_stride = 0;
+        return SMCX_OK;
+    }
+    if (c.series_stride < maxsteps + 1) {
+        hipFree(c.Eseries); hipFree(c.jjseries);
+        c.Eseries = nullptr; c.jjseries = nullptr;
+        c.series_stride = maxsteps + 1;
+        HIPCHK(&h, hipMalloc(&c.Eseries, (size_t)h.p.nrep * c.series_stride * sizeof(double)));
+        HIPCHK(&h, hipMalloc(&c.jjseries, (size_t)h.p.nrep * c.series_stride * sizeof(int)));
+    }
+    HIPCHK(&h, hipMemsetAsync(c.Eseries, 0, (size_t)h.p.nrep * c.series_stride * sizeof(double), h.stream));
+    HIPCHK(&h, hipMemsetAsync(c.jjseries, 0, (size_t)h.p.nrep * c.series_stride * sizeof(int), h.stream));
+    return SMCX_OK;
+}
+
+// one phase of sMC: `steps` sweeps at step parameter A, in chunks of h.chunk
+static int run_phase(Handle &h, int steps, double A, int production, int gather_lapse)
+{
+    int done = 0;
+    bool first = true;
+    while (done < steps) {
+        const int k = (steps - done < h.chunk) ? steps - done : h.chunk;
+        HIPCHK(&h, launch_rng_prepass(h.c, k, A, h.stream));
+        HIPCHK(&h, launch_sweeps(h.c, h.S, h.WPR, k, A, production, gather_lapse, done,
+                                 (production && first) ? 1 : 0, h.stream));
+        h.last_launches++;
+        first = false;
+        done += k;
+    }
+    return SMCX_OK;
+}
+
+extern "C" int smcx_run(smcx_handle *hh, int eqsteps, int maxsteps, int gather_lapse)
+{
+    if (!hh) return SMCX_ERR_PARAM;
+    Handle &h = hh->h;
+    if (!h.uploaded) return SMCX_ERR_STATE;
+    if (eqsteps < 0 || maxsteps < 0 || gather_lapse < 1) return SMCX_ERR_PARAM;
+    HIPCHK(&h, hipSetDevice(h.p.device));
+    int rc = ensure_series(h, maxsteps);
+    if (rc != SMCX_OK) return rc;
+    h.last_launches = 0;
+    // zero the accumulators, remember E at entry (the reference's E[0])
+    HIPCHK(&h, launch_obs_op(h.c, h.d_save, 0, h.stream));
+    HIPCHK(&h, hipEventRecord(h.ev0, h.stream));
+    // thermalisation at 2A (SMC.c:110-118)
+    rc = run_phase(h, eqsteps, h.p.A * 2, 0, gather_lapse);
+    if (rc != SMCX_OK) return rc;
+    if (eqsteps > 0 && (h.p.flags & SMCX_FLAG_E0_RESTART)) // SMC.c:194 restarts from E[0]
+        HIPCHK(&h, launch_obs_op(h.c, h.d_save, 1, h.stream));
+    // production at A (SMC.c:134-196)
+    rc = run_phase(h, maxsteps, h.p.A, 1, gather_lapse);
+    if (rc != SMCX_OK) return rc;
+    HIPCHK(&h, hipEventRecord(h.ev1, h.stream));
+    HIPCHK(&h, hipStreamSynchronize(h.stream));
+    float ms = 0.f;
+    HIPCHK(&h, hipEventElapsedTime(&ms, h.ev0, h.ev1));
+    h.last_ms = ms;
+    h.last_maxsteps = maxsteps;
+    h.last_eqsteps = eqsteps;
+    return SMCX_OK;
+}
+
+extern "C" int smcx_last_kernel_ms(smcx_handle *hh, double *ms, int *launches)
+{
+    if (!hh) return SMCX_ERR_PARAM;
+    if (ms) *ms = hh->h.last_ms;
+    if (launches) *launches = hh->h.last_launches;
+    return SMCX_OK;
+}
+
+static int fetch_obs(Handle &h, std::vector<ObsRec> &obs)
+{
+    obs.resize(h.p.nrep);
+    HIPCHK(&h, hipSetDevice(h.p.device));
+    HIPCHK(&h, hipMemcpy(obs.data(), h.c.obs, obs.size() * sizeof(ObsRec), hipMemcpyDeviceToHost));
+    return SMCX_OK;
+}
+
+extern "C" int smcx_observables(smcx_handle *hh, double *acceptance_ratio, double *meanE, double *dE,
+                                uint64_t *zhist, uint64_t *accepted, double *E_last)
+{
+    if (!hh) return SMCX_ERR_PARAM;
+    Handle &h = hh->h;
+    if (!h.uploaded) return SMCX_ERR_STATE;
+    std::vector<ObsRec> obs;
+    int rc = fetch_obs(h, obs);
+    if (rc != SMCX_OK) return rc;
+    const int N = h.p.N, maxsteps = h.last_maxsteps;
+    for (int r = 0; r < h.p.nrep; r++) {
+        const ObsRec &o = obs[r];
+        if (acceptance_ratio) // intmean(jj, maxsteps)/N, SMC.c:248
+            acceptance_ratio[r] = maxsteps > 0 ? (o.accepted / maxsteps) / N : 0.0;
+        const double len = o.nsamp > 0 ? o.nsamp : 1.0;
+        const double mean = o.sumE / len;
+        if (meanE) meanE[r] = mean;                                       // SMC.c:244
+        if (dE) dE[r] = std::sqrt(o.sumE2 / len - mean * mean);           // SMC.c:245, matematicose.c:96-103
+        if (accepted) accepted[r] = (uint64_t)o.accepted;
+        if (E_last) E_last[r] = o.Ecur;
+    }
+    if (zhist)
+        HIPCHK(&h, hipMemcpy(zhist, h.c.zhist, (size_t)h.p.nrep * h.p.Ncz * sizeof(uint64_t),
+                             hipMemcpyDeviceToHost));
+    return SMCX_OK;
+}
+
+extern "C" int smcx_therm_acceptance(smcx_handle *hh, double *ratio)
+{
+    if (!hh || !ratio) return SMCX_ERR_PARAM;
+    Handle &h = hh->h;
+    std::vector<ObsRec> obs;
+    int rc = fetch_obs(h, obs);
+    if (rc != SMCX_OK) return rc;
+    for (int r = 0; r < h.p.nrep; r++) // intmean(jt, eqsteps)/N, SMC.c:124
+        ratio[r] = h.last_eqsteps > 0 ? (obs[r].therm_accepted / h.last_eqsteps) / h.p.N : 0.0;
+    return SMCX_OK;
+}
+
+extern "C" int smcx_hist_info(smcx_handle *hh, uint64_t *gathers, uint64_t *oob)
+{
+    if (!hh) return SMCX_ERR_PARAM;
+    Handle &h = hh->h;
+    std::vector<ObsRec> obs;
+    int rc = fetch_obs(h, obs);
+    if (rc != SMCX_OK) return rc;
+    for (int r = 0; r < h.p.nrep; r++) {
+        if (gathers) gathers[r] = (uint64_t)obs[r].gathers;
+        if (oob) oob[r] = (uint64_t)obs[r].oob;
+    }
+    return SMCX_OK;
+}
+
+extern "C" int smcx_series(smcx_handle *hh, double *E_series, int32_t *jj)
+{
+    if (!hh) return SMCX_ERR_PARAM;
+    Handle &h = hh->h;
+    if (!(h.p.flags & SMCX_FLAG_SERIES) || !h.c.Eseries) return SMCX_ERR_STATE;
+    HIPCHK(&h, hipSetDevice(h.p.device));
+    const int ms = h.last_maxsteps, stride = h.c.series_stride;
+    if (E_series)
+        HIPCHK(&h, hipMemcpy2D(E_series, (size_t)(ms + 1) * sizeof(double), h.c.Eseries,
+                               (size_t)stride * sizeof(double), (size_t)(ms + 1) * sizeof(double),
+                               h.p.nrep, hipMemcpyDeviceToHost));
+    if (jj && ms > 0)
+        HIPCHK(&h, hipMemcpy2D(jj, (size_t)ms * sizeof(int), h.c.jjseries, (size_t)stride * sizeof(int),
+                               (size_t)ms * sizeof(int), h.p.nrep, hipMemcpyDeviceToHost));
+    return SMCX_OK;
+}
+
+extern "C" int smcx_download_positions(smcx_handle *hh, double *R)
+{
+    if (!hh || !R) return SMCX_ERR_PARAM;
+    Handle &h = hh->h;
+    if (!h.uploaded) return SMCX_ERR_STATE;
+    HIPCHK(&h, hipSetDevice(h.p.device));
+    HIPCHK(&h, hipMemcpy(R, h.c.R, (size_t)h.p.nrep * 3 * h.p.N * sizeof(double), hipMemcpyDeviceToHost));
+    return SMCX_OK;
+}
+
+extern "C" int smcx_total_energy(smcx_handle *hh, double *E)
+{
+    if (!hh || !E) return SMCX_ERR_PARAM;
+    Handle &h = hh->h;
+    if (!h.uploaded) return SMCX_ERR_STATE;
+    HIPCHK(&h, hipSetDevice(h.p.device));
+    HIPCHK(&h, launch_total_energy(h.c, h.d_tmp, h.stream));
+    HIPCHK(&h, hipStreamSynchronize(h.stream));
+    HIPCHK(&h, hipMemcpy(E, h.d_tmp, (size_t)h.p.nrep * sizeof(double), hipMemcpyDeviceToHost));
+    return SMCX_OK;
+}
+
+extern "C" int smcx_rng_export(smcx_handle *hh, uint32_t *state)
+{
+    if (!hh || !state) return SMCX_ERR_PARAM;
+    Handle &h = hh->h;
+    if (!h.uploaded) return SMCX_ERR_STATE;
+    HIPCHK(&h, hipSetDevice(h.p.device));
+    HIPCHK(&h, hipMemcpy(state, h.c.rng, (size_t)h.p.nrep * 32 * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return SMCX_OK;
+}
+
+extern "C" int smcx_rng_import(smcx_handle *hh, const uint32_t *state)
+{
+    if (!hh || !state) return SMCX_ERR_PARAM;
+    Handle &h = hh->h;
+    for (int r = 0; r < h.p.nrep; r++)
+        if (state[r * 32 + 31] > 30) return SMCX_ERR_PARAM;
+    HIPCHK(&h, hipSetDevice(h.p.device));
+    HIPCHK(&h, hipMemcpy(h.c.rng, state, (size_t)h.p.nrep * 32 * sizeof(uint32_t), hipMemcpyHostToDevice));
+    return SMCX_OK;
+}
+
+extern "C" size_t smcx_obs_device_bytes(const smcx_handle *hh)
+{
+    if (!hh) return 0;
+    return ((size_t)hh->h.p.nrep * SMCX_OBS_RECORD_DOUBLES + (size_t)hh->h.p.nrep * hh->h.p.Ncz) * sizeof(double);
+}
+
+extern "C" int smcx_export_observables_device(smcx_handle *hh, void *dst, size_t bytes)
+{
+    if (!hh || !dst) return SMCX_ERR_PARAM;
+    Handle &h = hh->h;
+    if (bytes != smcx_obs_device_bytes(hh)) return SMCX_ERR_PARAM;
+    HIPCHK(&h, hipSetDevice(h.p.device));
+    HIPCHK(&h, launch_pack_obs(h.c, (double *)dst, h.stream));
+    HIPCHK(&h, hipStreamSynchronize(h.stream));
+    return SMCX_OK;
+}
+
+// ---- teacher-forced evaluator -------------------------------------------------------
+extern "C" int smcx_eval_moves(const smcx_params *p, const double *R, const double *W, const int32_t *n,
+                               const double *prop, double *out)
+{
+    int rc = validate(p);
+    if (rc != SMCX_OK) return rc;
+    if (!R || !n || !prop || !out) return SMCX_ERR_PARAM;
+    if ((p->flags & SMCX_FLAG_WALLS) && !W) return SMCX_ERR_PARAM;
+    for (int r = 0; r < p->nrep; r++)
+        if (n[r] < 0 || n[r] >= p->N) return SMCX_ERR_PARAM;
+    int ndev = 0;
+    rc = smcx_device_count(&ndev);
+    if (rc != SMCX_OK) return rc;
+    Handle h;
+    h.p = *p;
+    std::memset(&h.c, 0, sizeof(h.c));
+    h.chunk = 1;
+    fill_ctx(h);
+    DevCtx &c = h.c;
+    const size_t nrep = p->nrep, row = 3 * (size_t)p->N;
+    int *d_n = nullptr;
+    double *d_prop = nullptr, *d_out = nullptr;
+    int status = SMCX_OK;
+    auto fail = [&](hipError_t e, const char *what) {
+        if (e != hipSuccess && status == SMCX_OK) {
+            g_last_error = std::string(what) + ": " + hipGetErrorString(e);
+            status = SMCX_ERR_HIP;
+        }
+    };
+    fail(hipSetDevice(p->device), "hipSetDevice");
+    fail(hipMalloc(&c.R, nrep * row * sizeof(double)), "hipMalloc R");
+    fail(hipMalloc((void **)&c.W, (size_t)(2 * c.M2 > 2 ? 2 * c.M2 : 2) * sizeof(double)), "hipMalloc W");
+    fail(hipMalloc(&d_n, nrep * sizeof(int)), "hipMalloc n");
+    fail(hipMalloc(&d_prop, nrep * 3 * sizeof(double)), "hipMalloc prop");
+    fail(hipMalloc(&d_out, nrep * 8 * sizeof(double)), "hipMalloc out");
+    if (status == SMCX_OK) {
+        fail(hipMemcpy(c.R, R, nrep * row * sizeof(double), hipMemcpyHostToDevice), "copy R");
+        if (W) fail(hipMemcpy((void *)c.W, W, 2 * (size_t)c.M2 * sizeof(double), hipMemcpyHostToDevice), "copy W");
+        fail(hipMemcpy(d_n, n, nrep * sizeof(int), hipMemcpyHostToDevice), "copy n");
+        fail(hipMemcpy(d_prop, prop, nrep * 3 * sizeof(double), hipMemcpyHostToDevice), "copy prop");
+    }
+    if (status == SMCX_OK) {
+        fail(launch_eval_moves(c, d_n, d_prop, d_out, nullptr), "eval_moves_kernel");
+        fail(hipDeviceSynchronize(), "sync");
+        fail(hipMemcpy(out, d_out, nrep * 8 * sizeof(double), hipMemcpyDeviceToHost), "copy out");
+    }
+    hipFree(c.R); hipFree((void *)c.W); hipFree(d_n); hipFree(d_prop); hipFree(d_out);
+    return status;
+}
+
+// ---- single-chain shim with the oneParticleMoves contract (SMC.h:102) ---------------
+extern "C" int smcx_one_particle_moves(const smcx_params *p, uint32_t *rng, double *R, double *Rn,
+                                       const double *W, double A, double T, int *j, double *U)
+{
+    if (!p || !rng || !R || !j || !U) return SMCX_ERR_PARAM;
+    smcx_params q = *p;
+    q.nrep = 1;
+    q.A = A;
+    q.T = T;
+    q.flags &= ~SMCX_FLAG_SERIES;
+    smcx_handle *hh = nullptr;
+    int rc = smcx_create(&q, &hh);
+    if (rc != SMCX_OK) return rc;
+    Handle &h = hh->h;
+    do {
+        rc = smcx_upload(hh, R, 0, W, nullptr);
+        if (rc != SMCX_OK) break;
+        rc = smcx_rng_import(hh, rng);
+        if (rc != SMCX_OK) break;
+        // the caller's running energy goes in as the current energy (SMC.c:116-117)
+        hipError_t e = hipMemcpy(h.d_tmp, U, sizeof(double), hipMemcpyHostToDevice);
+        if (e != hipSuccess) { rc = SMCX_ERR_HIP; break; }
+        if (launch_obs_op(h.c, h.d_tmp, 1, h.stream) != hipSuccess) { rc = SMCX_ERR_HIP; break; }
+        rc = smcx_run(hh, 0, 1, 1 << 30);
+        if (rc != SMCX_OK) break;
+        uint64_t acc = 0;
+        double Elast = 0.0;
+        rc = smcx_observables(hh, nullptr, nullptr, nullptr, nullptr, &acc, &Elast);
+        if (rc != SMCX_OK) break;
+        rc = smcx_download_positions(hh, R);
+        if (rc != SMCX_OK) break;
+        if (Rn) std::memcpy(Rn, R, 3 * (size_t)q.N * sizeof(double)); // Rn == R on return, SMC.c:337-347
+        rc = smcx_rng_export(hh, rng);
+        if (rc != SMCX_OK) break;
+        *j += (int)acc;
+        *U = Elast;
+    } while (0);
+    smcx_destroy(hh);
+    return rc;
+}

@@ -1,0 +1,271 @@
+// smcx_device.hpp -- device-side building blocks of the SMC sweep for gfx950.
+//
+// Design (DESIGN.md has the long version):
+//  * one replica chain = one workgroup of WPR wavefronts (64 lanes each);
+//    every lane owns S particles IN REGISTERS (x[S],y[S],z[S], fp64), particle
+//    l lives in lane l % (64*WPR), register slot l / (64*WPR);
+//  * a trial move needs sum_{l != n} pair(R[l], probe) for two probes (the
+//    proposed position of particle n and the current position of the NEXT
+//    particle n+1): one fused pass over the S register slots does both, so
+//    positions are touched once per move and one 8-value wavefront reduction
+//    serves two of the reference's four O(N) loops each (SMC.c:300-304,319-321);
+//  * wall sites, the featureless plane and the (n, n+1) pair correction are
+//    extra pseudo-neighbours evaluated by otherwise idle lanes of wave 0;
+//  * the register file is rotated by one slot whenever the visiting order
+//    crosses a slot boundary, so the moving particle is always in slot 0 and
+//    no register is ever indexed at run time.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace smcx {
+
+constexpr double FAR_PAD = 1.0e150;    // z of padding particles (never inside any cutoff)
+constexpr double FAR_PROBE = -1.0e150; // z of a disabled probe
+
+struct ObsRec {                   // per-replica accumulators, 64 B
+    double accepted;              // production accepted moves (exact in fp64 up to 2^53)
+    double nsamp;                 // entries of the energy series seen so far
+    double sumE, sumE2;           // running sums of (E + 3NT/2) and its square
+    double Ecur;                  // current incremental energy (SMC.c:116-117,194-195)
+    double therm_accepted;
+    double gathers;
+    double oob;
+};
+
+struct DevCtx {
+    int N, M, M2, nrep;
+    int Ncx, Ncz;
+    unsigned flags;
+    int series_stride;            // entries per replica in Eseries (0 = off)
+    double L, invL, Lz, invLz, halfLz, T, invT, cutoff2, a0, b0;
+    double c3NT2;                 // 3*N*T/2 (SMC.c:211)
+    double *R;                    // [nrep][3N] AoS, the reference layout
+    const double *W;              // [2*M2]
+    uint32_t *rng;                // [nrep][32]
+    uint32_t *raw;                // [nrep][rawStride] raw rand() outputs of one sweep (pre-pass scratch)
+    double *displ;                // [nrep][chunk][3N] Gaussian displacements, one block per sweep
+    double *uni;                  // [nrep][chunk][N] acceptance uniforms
+    int *offs;                    // [nrep][chunk] first particle of each sweep (offset % N)
+    int chunk;                    // sweeps of random numbers held by the scratch buffers
+    ObsRec *obs;                  // [nrep]
+    unsigned long long *zhist;    // [nrep][Ncz]
+    double *Eseries;              // [nrep][series_stride] or null
+    int *jjseries;                // [nrep][series_stride] or null
+    long rawStride;
+};
+
+// ---- cross-lane helpers ------------------------------------------------------
+__device__ __forceinline__ double rdlane(double v, int lane)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_readlane(lo, lane);
+    hi = __builtin_amdgcn_readlane(hi, lane);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// move a wave-uniform double into scalar registers
+__device__ __forceinline__ double uniform_d(double v)
+{
+    int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
+    int hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ double xchg(double v, int mask) { return __shfl_xor(v, mask, 64); }
+
+// Reduce eight per-lane values over the 64 lanes of a wavefront.  Each step
+// halves the number of live values instead of reducing all eight through all
+// six levels: 4+2+1 exchanges for the top three levels, 3 for the rest.
+// On return every lane of lane-group g = lane>>3 holds the wave total of v[g].
+__device__ __forceinline__ double reduce8(const double (&v)[8], int lane)
+{
+    const bool b5 = lane & 32, b4 = lane & 16, b3 = lane & 8;
+    double w[4], u[2];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        double keep = b5 ? v[4 + i] : v[i];
+        double send = b5 ? v[i] : v[4 + i];
+        w[i] = keep + xchg(send, 32);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        double keep = b4 ? w[2 + i] : w[i];
+        double send = b4 ? w[i] : w[2 + i];
+        u[i] = keep + xchg(send, 16);
+    }
+    double keep = b3 ? u[1] : u[0];
+    double send = b3 ? u[0] : u[1];
+    double r = keep + xchg(send, 8);
+    r += xchg(r, 4);
+    r += xchg(r, 2);
+    r += xchg(r, 1);
+    return r;
+}
+
+// ---- Lennard-Jones term shared by pairs, wall sites and the plane -------------
+// e += ca/r^12 - cb/r^6 ; F += (48 ca/r^14 - 24 cb/r^8) d      (K1-K4, SMC.c:577-578,
+// 610-614, 741, 758, 788-789, 806-809; the common factor 4 of the energies is
+// applied once after the reduction)
+__device__ __forceinline__ void lj_acc(double dx, double dy, double dz, double dr2, double ca,
+                                       double cb, double &e, double &fx, double &fy, double &fz)
+{
+    const double ir2 = 1.0 / dr2;
+    const double ir6 = ir2 * ir2 * ir2;
+    const double t = ca * ir6 * ir6;
+    const double s = cb * ir6;
+    e += t - s;
+    const double f = (48.0 * t - 24.0 * s) * ir2;
+    fx += f * dx;
+    fy += f * dy;
+    fz += f * dz;
+}
+
+struct Geo {                      // wave-uniform constants of the pair loop
+    double L, invL, cutoff2;
+};
+
+// one pair evaluation: probe p against neighbour (x,y,z); d = probe - neighbour,
+// minimum image in x,y only (SMC.c:567-573, 601-607)
+__device__ __forceinline__ void pair_eval(const Geo &g, double px, double py, double pz, double x,
+                                          double y, double z, bool ok, double &e, double &fx,
+                                          double &fy, double &fz)
+{
+    double dx = px - x;
+    dx = dx - g.L * __builtin_rint(dx * g.invL);
+    double dy = py - y;
+    dy = dy - g.L * __builtin_rint(dy * g.invL);
+    const double dz = pz - z;
+    const double dr2 = dx * dx + dy * dy + dz * dz;
+    if (dr2 < g.cutoff2 && ok)
+        lj_acc(dx, dy, dz, dr2, 1.0, 1.0, e, fx, fy, fz);
+}
+
+// Fused pass over the register-resident neighbours: probe A (proposed position
+// of the moving particle n) accumulates into v[0..3], probe B (current position
+// of the next particle) into v[4..7].  exA0/exB0 mask this lane's slot-0
+// particle, exB1 its slot-1 particle (n and n+1 are always there, see kernel).
+template <int S>
+__device__ __forceinline__ void fused_pass(const Geo &g, const double (&x)[S], const double (&y)[S],
+                                           const double (&z)[S], double ax, double ay, double az,
+                                           double bx, double by, double bz, bool exA0, bool exB0,
+                                           bool exB1, double (&v)[8])
+{
+#pragma unroll
+    for (int k = 0; k < S; k++) {
+        const bool okA = (k == 0) ? !exA0 : true;
+        const bool okB = (k == 0) ? !exB0 : ((k == 1) ? !exB1 : true);
+        pair_eval(g, ax, ay, az, x[k], y[k], z[k], okA, v[0], v[1], v[2], v[3]);
+        pair_eval(g, bx, by, bz, x[k], y[k], z[k], okB, v[4], v[5], v[6], v[7]);
+    }
+}
+
+// ---- pseudo-neighbours handled by spare lanes of wave 0 ------------------------
+// role 0/1: wall site acting on probe A / B          -> v[0..3] / v[4..7]
+// role 4/5: featureless plane acting on probe A / B  (no x,y offset, no cutoff)
+// role 2  : pair (old position of n) -> B, kept aside   (lane 30)
+// role 3  : pair (new position of n) -> B, kept aside   (lane 31)
+// After the accept/reject decision the matching side term completes B's sums.
+// The per-lane constants live in LDS and are read once per move by wave 0.
+struct RoleTable {
+    double sx[64], sy[64]; // site position i*dw, j*dw (SMC.c:748-750)
+    double ca[64], cb[64]; // W[2m], W[2m+1] or a0, b0 or 1,1
+    int role[64];          // -1 = none
+};
+
+constexpr int SIDE_LANE_OLD = 30;
+constexpr int SIDE_LANE_NEW = 31;
+
+// filled by the 64 lanes of one wave
+__device__ __forceinline__ void fill_roles(const DevCtx &c, RoleTable &rt, int lane)
+{
+    int role = -1;
+    double sx = 0.0, sy = 0.0, ca = 1.0, cb = 1.0;
+    const bool walls = (c.flags & 0x1u) != 0;
+    const int half = lane & 31;
+    if (walls && half <= c.M2 && half < 30) {
+        role = lane >> 5;
+        if (half == c.M2) {
+            role |= 4; ca = c.a0; cb = c.b0;
+        } else {
+            const double dw = c.L / c.M;
+            sx = (half / c.M) * dw;
+            sy = (half % c.M) * dw;
+            ca = c.W[2 * half];
+            cb = c.W[2 * half + 1];
+        }
+    }
+    if (lane == SIDE_LANE_OLD) role = 2;
+    if (lane == SIDE_LANE_NEW) role = 3;
+    rt.sx[lane] = sx; rt.sy[lane] = sy; rt.ca[lane] = ca; rt.cb[lane] = cb;
+    rt.role[lane] = role;
+}
+
+// signed distance to the nearer wall with the reference's clamp (SMC.c:736-739)
+__device__ __forceinline__ double wall_dz(const DevCtx &c, double rz)
+{
+    double dz = rz + c.halfLz;
+    dz = dz - c.Lz * __builtin_rint(dz * c.invLz);
+    if (rz <= -c.halfLz) dz = 0.0001;
+    else if (rz >= c.halfLz) dz = -0.0001;
+    return dz;
+}
+
+// P: current position of n, A: its proposal, B: current position of the next particle.
+// Executed by wave 0 only; `role` is this lane's rt.role[lane].
+__device__ __forceinline__ void special_block(const DevCtx &c, const Geo &g, const RoleTable &rt,
+                                              int lane, int role, bool hasA, bool hasB, bool sides,
+                                              double Px, double Py, double Pz, double Ax, double Ay,
+                                              double Az, double Bx, double By, double Bz,
+                                              double (&v)[8], double (&side)[4])
+{
+    side[0] = side[1] = side[2] = side[3] = 0.0;
+    bool active = false;
+    const bool wallrole = (role >= 0) && ((role & 2) == 0);
+    const bool onA = wallrole && ((role & 1) == 0);
+    if (wallrole) active = onA ? hasA : hasB;
+    else if (role >= 2) active = hasA && hasB && sides;
+    if (active) {
+        const bool plane = wallrole && (role & 4);
+        const double tx = onA ? Ax : Bx, ty = onA ? Ay : By, tz = onA ? Az : Bz;
+        double dx, dy, dz;
+        if (wallrole) {
+            dx = tx - rt.sx[lane]; dy = ty - rt.sy[lane];
+            dz = wall_dz(c, tz);
+        } else {
+            const bool old = (role == 2);
+            dx = tx - (old ? Px : Ax); dy = ty - (old ? Py : Ay);
+            dz = tz - (old ? Pz : Az);
+        }
+        dx = dx - g.L * __builtin_rint(dx * g.invL);
+        dy = dy - g.L * __builtin_rint(dy * g.invL);
+        if (plane) { dx = 0.0; dy = 0.0; }
+        const double dr2 = dx * dx + dy * dy + dz * dz;
+        double e = 0.0, fx = 0.0, fy = 0.0, fz = 0.0;
+        if (plane || dr2 < g.cutoff2)
+            lj_acc(dx, dy, dz, dr2, rt.ca[lane], rt.cb[lane], e, fx, fy, fz);
+        if (wallrole && onA) { v[0] += e; v[1] += fx; v[2] += fy; v[3] += fz; }
+        else if (wallrole) { v[4] += e; v[5] += fx; v[6] += fy; v[7] += fz; }
+        else { side[0] = e; side[1] = fx; side[2] = fy; side[3] = fz; }
+    }
+}
+
+// ---- glibc rand(): 31 new outputs per step -------------------------------------
+// r[i] = r[i-31] + r[i-3] (mod 2^32), output r[i] >> 1.  Lane j < 31 holds
+// r[i-31+j].  new[j] = old[j] + (j < 3 ? old[j+28] : new[j-3]) is an inclusive
+// prefix sum over the three residue classes of j mod 3: four shifted adds.
+__device__ __forceinline__ uint32_t rand_block(uint32_t h, int lane)
+{
+    uint32_t t = __shfl_down(h, 28, 64);
+    uint32_t w = h + ((lane < 3) ? t : 0u);
+#pragma unroll
+    for (int d = 3; d <= 24; d *= 2) {
+        t = __shfl_up(w, d, 64);
+        if (lane >= d) w += t;
+    }
+    return w;
+}
+
+} // namespace smcx

@@ -1,0 +1,21 @@
+// smcx_kernels.h -- host-visible launchers of the gfx950 kernels (internal).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "smcx_device.hpp"
+
+namespace smcx {
+
+bool geometry_supported(int S, int WPR);
+
+hipError_t launch_rng_prepass(const DevCtx &c, int nsweeps, double A, hipStream_t st);
+hipError_t launch_sweeps(const DevCtx &c, int S, int WPR, int nsweeps, double A, int production,
+                         int gather_lapse, int sweep_base, int first_production, hipStream_t st);
+hipError_t launch_total_energy(const DevCtx &c, double *out, hipStream_t st);
+hipError_t launch_eval_moves(const DevCtx &c, const int *nsel, const double *prop, double *out,
+                             hipStream_t st);
+hipError_t launch_pack_obs(const DevCtx &c, double *dst, hipStream_t st);
+// op 0: zero the accumulators of every replica and remember Ecur in save[];
+// op 1: put save[] back into Ecur; op 2: Ecur <- save[] (set from host values)
+hipError_t launch_obs_op(const DevCtx &c, double *save, int op, hipStream_t st);
+
+} // namespace smcx
