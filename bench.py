@@ -1,0 +1,206 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the SMC hot path on MI355X.
+
+Metric (BASELINE.json): pair-evals/s = nrep * sweeps * 2N(N-1) / time at N=4096.
+One "step" = one Smart-Monte-Carlo sweep (N force-biased trial moves, SMC.c:278-351)
+of every replica chain on every GPU.  Workload at any GPU count: BASELINE config 3 per
+GPU (N=4096 + wall, 4096 replicas, fcc(8,16) start, T=A=1.1, M=3, W fixture, seeds
+12345 + global replica index) -- weak scaling, config 4 at 8 GPUs.  Replicas are
+independent (the reference's intended MPI fan-out), so ranks share nothing while
+sampling; the only collective is the final RCCL all-gather of the observables.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--replicas R] [--no-cpu]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+BYTES_PER_PAIR_EVAL = 24  # one neighbour position = 3 fp64 per pair-eval
+
+
+def cpu_baseline(N, Na, Nz, seconds_target=12.0):
+    """The oracle (CPU restatement, kind "port") timed on this box's host cores: one
+    independent chain per core, the reference's intended MPI fan-out."""
+    import ctypes as C
+    import subprocess
+    import tempfile
+    from concurrent.futures import ThreadPoolExecutor
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    # a -O3 -march=native build of the same source for the timing leg (the -O2
+    # -ffp-contract=off build stays the parity checker)
+    lib = None
+    try:
+        tmp = tempfile.mkdtemp(prefix="smcx_cpu_")
+        so = os.path.join(tmp, "liboracle_fast.so")
+        subprocess.check_call(["gcc", "-O3", "-march=native", "-fPIC", "-shared", "-o", so,
+                               os.path.join(O.ORACLE_DIR, "smc_oracle.c"), "-lm"],
+                              stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        lib = C.CDLL(so)
+        lib.orc_time_sweeps.argtypes = O.lib().orc_time_sweeps.argtypes
+        lib.orc_time_sweeps.restype = C.c_double
+        flags = "gcc -O3 -march=native"
+    except Exception:
+        lib = O.lib()
+        flags = "gcc -O2 -ffp-contract=off"
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 64))
+    R0 = O.fcc(Na, Nz)
+    s = O.make_sys(N)
+
+    def one(args):
+        seed, sweeps = args
+        R = R0.copy()
+        acc = C.c_uint64(0)
+        return lib.orc_time_sweeps(C.byref(s), seed, R.ctypes.data_as(C.POINTER(C.c_double)),
+                                   O.W_FIXTURE.ctypes.data_as(C.POINTER(C.c_double)), 1.1, 1.1, sweeps,
+                                   C.byref(acc))
+    t1 = one((12345, 1))                      # calibrate: one sweep on one core
+    sweeps = max(1, int(seconds_target / max(t1, 1e-3)))
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(cores) as ex:     # ctypes releases the GIL
+        list(ex.map(one, [(12345 + i, sweeps) for i in range(cores)]))
+    wall = time.perf_counter() - t0
+    pe = cores * sweeps * 2.0 * N * (N - 1.0)
+    return {"value": pe / wall, "unit": "pair-evals/s", "cores": cores, "kind": "port",
+            "per_core": pe / wall / cores,
+            "sample": "%d independent chains (one per core) x %d sweeps of N=%d, fcc(%d,%d) start, "
+                      "oracle/smc_oracle.c built %s, %.1f s wall" % (cores, sweeps, N, Na, Nz, flags, wall)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--replicas", type=int, default=4096, help="replica chains per GPU")
+    ap.add_argument("--N", type=int, default=4096, choices=[256, 1024, 4096, 16384])
+    ap.add_argument("--slots", type=int, default=0)
+    ap.add_argument("--waves", type=int, default=0)
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
+
+    import numpy as np
+    import torch
+    import smcx_loader
+    S = smcx_loader.load()   # raises if libsmcx.so is missing: no fallback
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("smcx_dist", os.path.join(ROOT, "montecarlo-surfacer_amd", "dist.py"))
+    D = importlib.util.module_from_spec(spec); spec.loader.exec_module(D)
+
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world)  # RCCL over xGMI
+    lattice = {256: (4, 4), 1024: (8, 4), 4096: (8, 16), 16384: (16, 16)}[a.N]
+    N, nrep = a.N, a.replicas
+    first, _ = D.shard(nrep * world, rank, world)
+    p = S.default_params(N, nrep, device=local_rank, first_replica=first,
+                         tune_slots=a.slots, tune_waves=a.waves)
+    eng = S.Engine(p)
+    eng.upload(S.fcc_init(*lattice), S.W_REFERENCE)   # inputs resident in HBM before timing
+    gather_lapse = 10                                  # SURVEY.md 8d throughput runs
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    if a.warmup > 0:
+        eng.run(0, a.warmup, gather_lapse)
+    barrier()
+    t0 = time.perf_counter()
+    eng.run(0, a.steps, gather_lapse)                  # exactly K steps; returns after stream sync
+    barrier()
+    dt = time.perf_counter() - t0
+    sweep_ms, launches = eng.last_kernel_ms()          # HIP events around the sweep launches
+    run_ms = eng.last_run_ms()
+
+    # the one exchange step: all-gather of the per-replica observables
+    nbytes = eng.obs_device_bytes()
+    buf = torch.zeros(nbytes // 8, dtype=torch.float64, device="cuda:%d" % local_rank)
+    eng.export_observables_device(buf.data_ptr(), nbytes)
+    tg = time.perf_counter()
+    obs = D.gather_observables(buf, nrep, p.Ncz)
+    torch.cuda.synchronize()
+    gather_ms = (time.perf_counter() - tg) * 1e3
+    summ = D.summarise(obs, N, a.steps)
+
+    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda:%d" % local_rank)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+
+    if rank == 0:
+        pe_per_gpu_launchset = nrep * a.steps * 2.0 * N * (N - 1.0)
+        value = world * pe_per_gpu_launchset / dt
+        S_, W_, _ = eng.geometry
+        algo_bytes_per_launch = pe_per_gpu_launchset * BYTES_PER_PAIR_EVAL / max(launches, 1)
+        launch_s = sweep_ms * 1e-3 / max(launches, 1)
+        achieved = algo_bytes_per_launch / launch_s / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                key = "N%d_R%d_S%d_W%d" % (N, nrep, S_, W_)
+                if key in tj:
+                    traffic = tj[key]["hbm_bytes_per_sweep"] * (a.steps / max(launches, 1))
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "pair-evals/s (MC sweeps/s x replicas x 2N(N-1)) at N=%d" % N,
+            "value": value, "unit": "pair-evals/s", "n_gpus": world, "steps": a.steps,
+            "warmup": a.warmup, "ms_per_step": dt * 1e3 / a.steps, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "BASELINE config 3 per GPU: N=%d LJ + wall (M=3), %d replica chains "
+                                   "per GPU, fcc(%d,%d) start, L=33 Lz=240 T=A=1.1, seeds 12345+replica"
+                                   % (N, nrep, lattice[0], lattice[1]),
+                       "N": N, "replicas_per_gpu": nrep, "replicas_total": nrep * world,
+                       "gather_lapse": gather_lapse,
+                       "geometry": "S=%d particles/lane, %d wavefront(s)/replica" % (S_, W_),
+                       "parallelism": "replica-sharded x%d, no data-path collective; RCCL all-gather of "
+                                      "observables at the end (%.2f ms)" % (world, gather_ms)},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "smcx::sweep_kernel<S=%d,WPR=%d>" % (S_, W_),
+                         "launches": launches, "avg_launch_ms": sweep_ms / max(launches, 1),
+                         "algorithmic_bytes_per_launch": algo_bytes_per_launch,
+                         "note": "algorithmic bytes = 24 B x pair-evals (streaming model, SURVEY 8d); "
+                                 "positions are register-resident, so frac > 1 is legitimate and the "
+                                 "binding resource is fp64 VALU issue, not HBM"},
+            "device_ms": {"sweep_kernels": sweep_ms, "whole_run": run_ms},
+            "observables": {"mean_acceptance": summ["mean_acceptance"], "mean_energy": summ["mean_of_meanE"],
+                            "replicas_gathered": int(len(obs["accepted"]))},
+        }
+        if world == 1 and not a.no_cpu:
+            try:
+                out["cpu_baseline"] = cpu_baseline(N, *lattice)
+            except Exception as e:  # the baseline leg must never take the GPU number down
+                out["cpu_baseline"] = {"value": None, "unit": "pair-evals/s", "cores": 0, "kind": "port",
+                                       "sample": "failed: %r" % (e,)}
+        print(json.dumps(out), flush=True)
+    eng.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -138,9 +138,11 @@ int smcx_rng_import(smcx_handle *h, const uint32_t *state);
 size_t smcx_obs_device_bytes(const smcx_handle *h);
 int smcx_export_observables_device(smcx_handle *h, void *dst_device, size_t bytes);
 
-/* timing of the sweep kernel(s) of the last smcx_run, HIP events on the
- * launch stream: total milliseconds and number of launches */
+/* timing of the sweep kernel launches of the last smcx_run (HIP events around each
+ * launch, on the launch stream): their summed milliseconds and their number */
 int smcx_last_kernel_ms(smcx_handle *h, double *ms, int *launches);
+/* device time of the whole last smcx_run (RNG pre-pass and bookkeeping kernels included) */
+int smcx_last_run_ms(smcx_handle *h, double *ms);
 /* the launch geometry chosen for this handle */
 int smcx_geometry(const smcx_handle *h, int *slots, int *waves_per_replica, int *lds_bytes);
 

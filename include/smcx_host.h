@@ -1,0 +1,70 @@
+/*
+ * smcx_host.h -- the C host side above the C ABI of smcx.h.
+ *
+ * Mirrors, for many replica chains at once, what the reference's host code
+ * does around the hot path: system preparation (initializeBox SMC.c:413-465,
+ * initializeWalls SMC.c:475-501), the simulation driver sMC (SMC.c:21-267) and
+ * the run set-up of main (main.c:35-51, 74-87, 98-122).  Built as
+ * libsmcx_host.so (plain C, links libsmcx.so) and as the `smcx_main` program.
+ */
+#ifndef SMCX_HOST_H
+#define SMCX_HOST_H
+
+#include "smcx.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* libc-compatible rand()/srand() with explicit state (glibc TYPE_3), used by
+ * the initialisers below exactly where the reference calls srand(42)/rand() */
+typedef struct smcx_host_rng {
+    uint32_t s[31];
+    int f, r;
+} smcx_host_rng;
+void smcx_host_srand(smcx_host_rng *g, unsigned int seed);
+int smcx_host_rand(smcx_host_rng *g);
+/* vecBoxMuller, matematicose.c:183-193 (x1/x2 swap and odd tail kept) */
+void smcx_host_vec_box_muller(smcx_host_rng *g, double sigma, size_t length, double *A);
+
+/* fcc(Na,Nz) slab start: N = 4*Na*Na*Nz particles, lattice constant L/Na, cell order
+ * i,j,k with k fastest, +a/4 on every coordinate, wrapped into the box with the z
+ * period 0.95*Lz (SMC.c:432-461).  Returns N or -1. */
+int smcx_host_fcc_init(int Na, int Nz, double L, double Lz, double *X);
+/* the reference's own choice of Na,Nz from N (SMC.c:416-431); returns the number of
+ * particles it places (< N means the reference leaves the rest at the origin) */
+int smcx_host_initialize_box(double L, double Lz, int N, double *X);
+/* W[2*M*M] from srand(42) and two vecBoxMuller draws (SMC.c:475-501).  For odd M*M
+ * the reference reads one uninitialised word; `uninit` supplies it (0.0 observed). */
+void smcx_host_initialize_walls(double x0m, double x0sigma, double ymm, double ymsigma, int M,
+                                double uninit, double *W);
+/* box table of main.c:35-44 */
+void smcx_host_box_for_N(int N, double *L, double *Lz);
+
+/* ensemble results of one smcx_host_sMC call (struct Sim, SMC.h:76-88, per replica
+ * and averaged over replicas; pressure, cluster analysis and ACF are not computed) */
+typedef struct smcx_sim {
+    int nrep, N, Ncz;
+    double E, dE;              /* ensemble mean of the replicas' mean energy / of their dE */
+    double acceptance_ratio;   /* ensemble mean */
+    double therm_acceptance;
+    double *rep_E;             /* [nrep] owned by the struct: smcx_host_sim_free */
+    double *rep_dE;            /* [nrep] */
+    double *rep_acceptance;    /* [nrep] */
+    double *zprofile;          /* [Ncz] particles per z cell per gather, ensemble mean */
+    double *Rfinal;            /* [nrep][3N] */
+    double kernel_ms;          /* device time of the sweep kernels */
+    double pair_evals_per_s;   /* nrep*maxsteps*2N(N-1) / kernel time */
+} smcx_sim;
+
+/* sMC (SMC.h:92) for nrep replica chains sharing R0 and W, seeds base_seed+r:
+ * thermalisation (eqsteps at 2A), production (maxsteps), results.  p supplies N, M,
+ * box, T, A, flags, seeds; returns an smcx status. */
+int smcx_host_sMC(const smcx_params *p, const double *W, const double *R0, int maxsteps,
+                  int gather_lapse, int eqsteps, smcx_sim *out);
+void smcx_host_sim_free(smcx_sim *s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

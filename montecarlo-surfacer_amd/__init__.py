@@ -53,7 +53,7 @@ EXPORTS = [
     "smcx_last_error_string", "smcx_upload", "smcx_run", "smcx_observables",
     "smcx_therm_acceptance", "smcx_hist_info", "smcx_series", "smcx_download_positions",
     "smcx_total_energy", "smcx_rng_export", "smcx_rng_import", "smcx_obs_device_bytes",
-    "smcx_export_observables_device", "smcx_last_kernel_ms", "smcx_geometry", "smcx_eval_moves",
+    "smcx_export_observables_device", "smcx_last_kernel_ms", "smcx_last_run_ms", "smcx_geometry", "smcx_eval_moves",
     "smcx_rng_seed", "smcx_one_particle_moves",
 ]
 
@@ -89,6 +89,7 @@ def _lib():
         L.smcx_obs_device_bytes.restype = C.c_size_t
         L.smcx_export_observables_device.argtypes = [vp, vp, C.c_size_t]
         L.smcx_last_kernel_ms.argtypes = [vp, _dp, C.POINTER(C.c_int)]
+        L.smcx_last_run_ms.argtypes = [vp, _dp]
         L.smcx_geometry.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.smcx_eval_moves.argtypes = [C.POINTER(Params), _dp, _dp, _i32p, _dp, _dp]
         L.smcx_rng_seed.argtypes = [_u32p, C.c_uint32]
@@ -253,7 +254,62 @@ class Engine:
         self._chk(_lib().smcx_export_observables_device(self._h, C.c_void_p(dev_ptr), nbytes),
                   "smcx_export_observables_device")
 
+    def last_run_ms(self):
+        ms = C.c_double()
+        self._chk(_lib().smcx_last_run_ms(self._h, C.byref(ms)), "smcx_last_run_ms")
+        return ms.value
+
     def last_kernel_ms(self):
         ms, n = C.c_double(), C.c_int()
         self._chk(_lib().smcx_last_kernel_ms(self._h, C.byref(ms), C.byref(n)), "smcx_last_kernel_ms")
         return ms.value, n.value
+
+
+# ---- C host side (libsmcx_host.so): system preparation, include/smcx_host.h -------
+HOST_LIB_PATH = os.path.join(_HERE, "libsmcx_host.so")
+_HOST = None
+
+# wall strengths the reference's initializeWalls(1.6, 0.0, 3.0, 0.5) produces on glibc
+# (SMC.c:475-501, main.c:74-87); equal to host_initialize_walls(M=3, uninit=0.0)
+W_REFERENCE = np.array([
+    962.2264072645321, 57.35316319850277, 874.39446992695275, 52.11797177356199,
+    857.36680597299653, 51.103043912231705, 1024.1964124687327, 61.046863345428257,
+    925.40789594507817, 55.158608910148025, 913.63518965684239, 54.456900933792724,
+    848.90539177252572, 50.598704324515197, 992.35137245273086, 59.148751047416368,
+    844.42493013196849, 50.331648000000015])
+
+
+def _host():
+    global _HOST
+    if _HOST is None:
+        _lib()
+        H = C.CDLL(HOST_LIB_PATH)
+        H.smcx_host_fcc_init.argtypes = [C.c_int, C.c_int, C.c_double, C.c_double, _dp]
+        H.smcx_host_initialize_box.argtypes = [C.c_double, C.c_double, C.c_int, _dp]
+        H.smcx_host_initialize_walls.argtypes = [C.c_double] * 4 + [C.c_int, C.c_double, _dp]
+        H.smcx_host_initialize_walls.restype = None
+        H.smcx_host_box_for_N.argtypes = [C.c_int, _dp, _dp]
+        H.smcx_host_box_for_N.restype = None
+        _HOST = H
+    return _HOST
+
+
+def fcc_init(Na, Nz, L=33.0, Lz=240.0):
+    """fcc(Na,Nz) slab start of SURVEY.md 8d (lattice code of SMC.c:432-461)"""
+    X = np.zeros(12 * Na * Na * Nz)
+    n = _host().smcx_host_fcc_init(Na, Nz, L, Lz, _p(X, C.c_double))
+    if n != 4 * Na * Na * Nz:
+        raise ValueError("bad lattice")
+    return X
+
+
+def initialize_box(N, L, Lz):
+    """the reference's initializeBox (SMC.c:413-465); returns (X, particles placed)"""
+    X = np.zeros(3 * N)
+    return X, _host().smcx_host_initialize_box(L, Lz, N, _p(X, C.c_double))
+
+
+def initialize_walls(M=3, x0m=1.6, x0sigma=0.0, ymm=3.0, ymsigma=0.5, uninit=0.0):
+    W = np.zeros(2 * M * M)
+    _host().smcx_host_initialize_walls(x0m, x0sigma, ymm, ymsigma, M, uninit, _p(W, C.c_double))
+    return W

@@ -31,8 +31,10 @@ struct Handle {
     bool uploaded = false;
     int last_maxsteps = 0;
     int last_eqsteps = 0;
-    double last_ms = 0.0;
+    double last_ms = 0.0;       // whole run
+    double last_sweep_ms = 0.0; // sweep kernels only
     int last_launches = 0;
+    std::vector<hipEvent_t> evs; // start/stop pairs around the sweep launches
     std::string err;
 };
 
@@ -60,11 +62,11 @@ static void seed_state(uint32_t seed, uint32_t out[32])
 {
     uint32_t s[31];
     if (seed == 0) seed = 1;
-    int64_t w = (int64_t)seed;
+    int32_t w = (int32_t)seed; // glibc keeps the running word in int32_t
     s[0] = seed;
     for (int i = 1; i < 31; i++) {
         const int64_t hi = w / 127773, lo = w % 127773;
-        w = 16807 * lo - 2836 * hi;
+        w = (int32_t)(16807 * lo - 2836 * hi);
         if (w < 0) w += 2147483647;
         s[i] = (uint32_t)w;
     }
@@ -198,6 +200,7 @@ extern "C" int smcx_destroy(smcx_handle *hh)
     hipFree(c.R); hipFree((void *)c.W); hipFree(c.rng); hipFree(c.raw); hipFree(c.displ);
     hipFree(c.uni); hipFree(c.offs); hipFree(c.obs); hipFree(c.zhist); hipFree(c.Eseries);
     hipFree(c.jjseries); hipFree(h.d_save); hipFree(h.d_tmp);
+    for (hipEvent_t e : h.evs) hipEventDestroy(e);
     if (h.ev0) hipEventDestroy(h.ev0);
     if (h.ev1) hipEventDestroy(h.ev1);
     if (h.stream) hipStreamDestroy(h.stream);
@@ -342,8 +345,15 @@ static int run_phase(Handle &h, int steps, double A, int production, int gather_
     while (done < steps) {
         const int k = (steps - done < h.chunk) ? steps - done : h.chunk;
         HIPCHK(&h, launch_rng_prepass(h.c, k, A, h.stream));
+        while ((int)h.evs.size() < 2 * (h.last_launches + 1)) {
+            hipEvent_t e;
+            HIPCHK(&h, hipEventCreate(&e));
+            h.evs.push_back(e);
+        }
+        HIPCHK(&h, hipEventRecord(h.evs[2 * h.last_launches], h.stream));
         HIPCHK(&h, launch_sweeps(h.c, h.S, h.WPR, k, A, production, gather_lapse, done,
                                  (production && first) ? 1 : 0, h.stream));
+        HIPCHK(&h, hipEventRecord(h.evs[2 * h.last_launches + 1], h.stream));
         h.last_launches++;
         first = false;
         done += k;
@@ -377,6 +387,12 @@ extern "C" int smcx_run(smcx_handle *hh, int eqsteps, int maxsteps, int gather_l
     float ms = 0.f;
     HIPCHK(&h, hipEventElapsedTime(&ms, h.ev0, h.ev1));
     h.last_ms = ms;
+    h.last_sweep_ms = 0.0;
+    for (int i = 0; i < h.last_launches; i++) {
+        float t = 0.f;
+        HIPCHK(&h, hipEventElapsedTime(&t, h.evs[2 * i], h.evs[2 * i + 1]));
+        h.last_sweep_ms += t;
+    }
     h.last_maxsteps = maxsteps;
     h.last_eqsteps = eqsteps;
     return SMCX_OK;
@@ -385,8 +401,15 @@ extern "C" int smcx_run(smcx_handle *hh, int eqsteps, int maxsteps, int gather_l
 extern "C" int smcx_last_kernel_ms(smcx_handle *hh, double *ms, int *launches)
 {
     if (!hh) return SMCX_ERR_PARAM;
-    if (ms) *ms = hh->h.last_ms;
+    if (ms) *ms = hh->h.last_sweep_ms;
     if (launches) *launches = hh->h.last_launches;
+    return SMCX_OK;
+}
+
+extern "C" int smcx_last_run_ms(smcx_handle *hh, double *ms)
+{
+    if (!hh || !ms) return SMCX_ERR_PARAM;
+    *ms = hh->h.last_ms;
     return SMCX_OK;
 }
 

@@ -1,0 +1,194 @@
+/*
+ * smcx_host.c -- C host side of the engine: system preparation and the sMC
+ * driver, calling the C ABI of libsmcx.so (HIP kernels).  No physics of the hot
+ * path is evaluated here; without a GPU smcx_host_sMC returns the ABI's error.
+ */
+#include "../../include/smcx_host.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ---- libc-compatible generator (what srand/rand are on glibc) ------------------ */
+void smcx_host_srand(smcx_host_rng *g, unsigned int seed)
+{
+    int32_t word;
+    if (seed == 0) seed = 1;
+    g->s[0] = seed;
+    word = (int32_t)seed;
+    for (int i = 1; i < 31; i++) {
+        long hi = word / 127773, lo = word % 127773;
+        word = (int32_t)(16807 * lo - 2836 * hi);
+        if (word < 0) word += 2147483647;
+        g->s[i] = (uint32_t)word;
+    }
+    g->f = 3;
+    g->r = 0;
+    for (int i = 0; i < 310; i++) (void)smcx_host_rand(g);
+}
+
+int smcx_host_rand(smcx_host_rng *g)
+{
+    uint32_t v = (g->s[g->f] += g->s[g->r]);
+    if (++g->f == 31) g->f = 0;
+    if (++g->r == 31) g->r = 0;
+    return (int)(v >> 1);
+}
+
+void smcx_host_vec_box_muller(smcx_host_rng *g, double sigma, size_t length, double *A)
+{
+    const double scale = 1.0 / 2147483648.0; /* rand()/(RAND_MAX+1.0), exact */
+    for (size_t k = 0; k + 1 < length; k += 2) {
+        const double x1 = smcx_host_rand(g) * scale;
+        const double x2 = smcx_host_rand(g) * scale;
+        A[k] = sigma * sqrt(-2 * log(1 - x1)) * cos(2 * M_PI * x2);
+        A[k + 1] = sigma * sqrt(-2 * log(1 - x2)) * sin(2 * M_PI * x1); /* x1,x2 swapped: as the reference */
+    }
+}
+
+/* ---- lattices ------------------------------------------------------------------- */
+static void place_fcc(int Na, int Nz, double a, int limit, double *X)
+{
+    const double h = a / 2;
+    for (int i = 0; i < Na; i++)
+        for (int j = 0; j < Na; j++)
+            for (int k = 0; k < Nz; k++) {
+                const int c = (i * Na + j) * Nz + k; /* k fastest */
+                const double x = a * i, y = a * j, z = a * k;
+                const double site[4][3] = {{x, y, z}, {x + h, y + h, z}, {x + h, y, z + h}, {x, y + h, z + h}};
+                for (int b = 0; b < 4; b++) {
+                    const int p = 4 * c + b;
+                    if (p < limit) memcpy(X + 3 * p, site[b], 3 * sizeof(double));
+                }
+            }
+}
+
+static void finish_lattice(double *X, int N, double a, double L, double Lz)
+{
+    const double Lzs = Lz - Lz / 20.0; /* SMC.c:461 */
+    for (int p = 0; p < N; p++) {
+        double *q = X + 3 * p;
+        for (int c = 0; c < 3; c++) q[c] += a / 4; /* off the cell edges, SMC.c:455-459 */
+        q[0] -= L * rint(q[0] / L);
+        q[1] -= L * rint(q[1] / L);
+        q[2] -= Lzs * rint(q[2] / Lzs);
+    }
+}
+
+int smcx_host_fcc_init(int Na, int Nz, double L, double Lz, double *X)
+{
+    if (Na < 1 || Nz < 1 || !X) return -1;
+    const int N = 4 * Na * Na * Nz;
+    const double a = L / Na;
+    place_fcc(Na, Nz, a, N, X);
+    finish_lattice(X, N, a, L, Lz);
+    return N;
+}
+
+int smcx_host_initialize_box(double L, double Lz, int N, double *X)
+{
+    if (N < 4 || !X) return -1;
+    const int cells = N / 4;
+    int Na = 1;
+    while ((Na + 1) * (Na + 1) * (Na + 1) <= cells) Na++; /* largest cube not above N/4 */
+    const int Nz = cells / (Na * Na);
+    const double a = L / Na;
+    memset(X, 0, 3 * (size_t)N * sizeof(double));
+    place_fcc(Na, Nz, a, N, X);
+    finish_lattice(X, N, a, L, Lz);
+    const int placed = 4 * Na * Na * Nz;
+    return placed < N ? placed : N;
+}
+
+void smcx_host_initialize_walls(double x0m, double x0sigma, double ymm, double ymsigma, int M,
+                                double uninit, double *W)
+{
+    const size_t n = (size_t)M * M;
+    double *X0 = (double *)malloc(2 * n * sizeof(double));
+    double *YM = X0 + n;
+    smcx_host_rng g;
+    smcx_host_srand(&g, 42); /* SMC.c:477 */
+    for (size_t m = 0; m < 2 * n; m++) X0[m] = uninit;
+    smcx_host_vec_box_muller(&g, x0sigma, n, X0);
+    smcx_host_vec_box_muller(&g, ymsigma, n, YM);
+    for (size_t m = 0; m < n; m++) {
+        const double x0 = X0[m] + x0m, depth = YM[m] + ymm;
+        W[2 * m] = pow(x0, 12.0) * depth;
+        W[2 * m + 1] = pow(x0, 6.) * depth;
+    }
+    free(X0);
+}
+
+void smcx_host_box_for_N(int N, double *L, double *Lz)
+{
+    if (N == 32) { *L = 20; *Lz = 120; }
+    else if (N < 150) { *L = 33; *Lz = 200; }
+    else { *L = 33; *Lz = 240; }
+}
+
+/* ---- sMC ---------------------------------------------------------------------- */
+void smcx_host_sim_free(smcx_sim *s)
+{
+    if (!s) return;
+    free(s->rep_E); free(s->rep_dE); free(s->rep_acceptance); free(s->zprofile); free(s->Rfinal);
+    memset(s, 0, sizeof(*s));
+}
+
+int smcx_host_sMC(const smcx_params *p, const double *W, const double *R0, int maxsteps,
+                  int gather_lapse, int eqsteps, smcx_sim *out)
+{
+    if (!p || !R0 || !out) return SMCX_ERR_PARAM;
+    memset(out, 0, sizeof(*out));
+    smcx_handle *h = NULL;
+    int rc = smcx_create(p, &h);
+    if (rc != SMCX_OK) return rc;
+    const int nrep = p->nrep, N = p->N, Ncz = p->Ncz;
+    uint64_t *zh = NULL, *gath = NULL;
+    double *therm = NULL;
+    do {
+        rc = smcx_upload(h, R0, 0, W, NULL);
+        if (rc != SMCX_OK) break;
+        rc = smcx_run(h, eqsteps, maxsteps, gather_lapse);
+        if (rc != SMCX_OK) break;
+        out->nrep = nrep; out->N = N; out->Ncz = Ncz;
+        out->rep_E = (double *)calloc(nrep, sizeof(double));
+        out->rep_dE = (double *)calloc(nrep, sizeof(double));
+        out->rep_acceptance = (double *)calloc(nrep, sizeof(double));
+        out->zprofile = (double *)calloc(Ncz, sizeof(double));
+        out->Rfinal = (double *)malloc((size_t)nrep * 3 * N * sizeof(double));
+        zh = (uint64_t *)calloc((size_t)nrep * Ncz, sizeof(uint64_t));
+        gath = (uint64_t *)calloc(nrep, sizeof(uint64_t));
+        therm = (double *)calloc(nrep, sizeof(double));
+        if (!out->rep_E || !out->rep_dE || !out->rep_acceptance || !out->zprofile || !out->Rfinal ||
+            !zh || !gath || !therm) { rc = SMCX_ERR_NOMEM; break; }
+        rc = smcx_observables(h, out->rep_acceptance, out->rep_E, out->rep_dE, zh, NULL, NULL);
+        if (rc != SMCX_OK) break;
+        rc = smcx_hist_info(h, gath, NULL);
+        if (rc != SMCX_OK) break;
+        rc = smcx_therm_acceptance(h, therm);
+        if (rc != SMCX_OK) break;
+        rc = smcx_download_positions(h, out->Rfinal);
+        if (rc != SMCX_OK) break;
+        double gsum = 0;
+        for (int r = 0; r < nrep; r++) {
+            out->E += out->rep_E[r] / nrep;
+            out->dE += out->rep_dE[r] / nrep;
+            out->acceptance_ratio += out->rep_acceptance[r] / nrep;
+            out->therm_acceptance += therm[r] / nrep;
+            gsum += (double)gath[r];
+            for (int k = 0; k < Ncz; k++) out->zprofile[k] += (double)zh[(size_t)r * Ncz + k];
+        }
+        if (gsum > 0)
+            for (int k = 0; k < Ncz; k++) out->zprofile[k] /= gsum;
+        int launches = 0;
+        smcx_last_kernel_ms(h, &out->kernel_ms, &launches);
+        if (out->kernel_ms > 0)
+            out->pair_evals_per_s = (double)nrep * (eqsteps + maxsteps) * 2.0 * N * (N - 1.0) /
+                                    (out->kernel_ms * 1e-3);
+    } while (0);
+    free(zh); free(gath); free(therm);
+    smcx_destroy(h);
+    if (rc != SMCX_OK) smcx_host_sim_free(out);
+    return rc;
+}

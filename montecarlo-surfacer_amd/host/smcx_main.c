@@ -1,0 +1,74 @@
+/*
+ * smcx_main.c -- command-line driver in the spirit of the reference's main.c:
+ *   smcx_main eqsteps maxsteps numdata T [N [nrep [Na Nz]]]
+ * (main.c:13-19 takes the first four; N is a macro there, SMC.h:29).  Prepares
+ * the walls and the lattice (main.c:74-113), runs nrep replica chains on GPU 0
+ * and prints the ensemble results (main.c:126-131).
+ */
+#include "../../include/smcx_host.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+int main(int argc, char **argv)
+{
+    if (argc < 5) {
+        fprintf(stderr, "usage: %s eqsteps maxsteps numdata T [N [nrep [Na Nz]]]\n", argv[0]);
+        return 2;
+    }
+    const int eqsteps = (int)strtol(argv[1], NULL, 10);
+    const int maxsteps = (int)strtol(argv[2], NULL, 10);
+    const int numdata = (int)strtol(argv[3], NULL, 10);
+    const double T = strtod(argv[4], NULL);
+    const int N = argc > 5 ? (int)strtol(argv[5], NULL, 10) : 108;
+    const int nrep = argc > 6 ? (int)strtol(argv[6], NULL, 10) : 1;
+    if (numdata < 1 || maxsteps < numdata) {
+        fprintf(stderr, "need 1 <= numdata <= maxsteps\n");
+        return 2;
+    }
+    const int gather_lapse = maxsteps / numdata; /* main.c:32 */
+
+    smcx_params p;
+    smcx_default_params(&p, N, nrep);
+    smcx_host_box_for_N(N, &p.L, &p.Lz);
+    p.T = T;
+    p.A = 1.0 * T; /* gamma = 1, main.c:48-51 */
+
+    double W[2 * 3 * 3];
+    smcx_host_initialize_walls(1.6, 0.0, 3.0, 0.5, p.M, 0.0, W); /* main.c:74-87 */
+
+    double *R0 = (double *)calloc(3 * (size_t)N, sizeof(double));
+    int placed;
+    if (argc > 8) {
+        placed = smcx_host_fcc_init((int)strtol(argv[7], NULL, 10), (int)strtol(argv[8], NULL, 10), p.L, p.Lz, R0);
+        if (placed != N) { fprintf(stderr, "4*Na*Na*Nz must equal N\n"); return 2; }
+    } else {
+        placed = smcx_host_initialize_box(p.L, p.Lz, N, R0);
+        if (placed != N) {
+            fprintf(stderr, "Can't make the reference's crystal with N=%d (%d particles placed); "
+                            "give Na Nz explicitly\n", N, placed);
+            return 2;
+        }
+    }
+    printf("Starting %d replica(s) of %d particles in %0.1fx%0.1fx%0.1f box, T=%0.2f, A=%0.3f, "
+           "%d+%d sweeps...\n", nrep, N, p.L, p.L, p.Lz, T, p.A, eqsteps, maxsteps);
+
+    smcx_sim sim;
+    int rc = smcx_host_sMC(&p, W, R0, maxsteps, gather_lapse, eqsteps, &sim);
+    if (rc != SMCX_OK) {
+        fprintf(stderr, "smcx_host_sMC: %s (%s)\n", smcx_strerror(rc), smcx_last_error_string(NULL));
+        free(R0);
+        return 1;
+    }
+    printf("\n###  Final results  ###");
+    printf("\nMean energy: %f +- %f", sim.E, sim.dE);
+    printf("\nAverage acceptance ratio: %f (thermalisation %f)", sim.acceptance_ratio, sim.therm_acceptance);
+    printf("\nDevice time %0.1f ms, %0.3e pair-evals/s", sim.kernel_ms, sim.pair_evals_per_s);
+    printf("\nz profile (particles per cell per gather):");
+    for (int k = 0; k < sim.Ncz; k++) printf(" %0.3f", sim.zprofile[k]);
+    printf("\n");
+    smcx_host_sim_free(&sim);
+    free(R0);
+    return 0;
+}

@@ -24,12 +24,12 @@ void orc_srand(orc_rng *g, unsigned int seed)
 {
     if (seed == 0)
         seed = 1;
-    int64_t w = (int64_t)seed;
+    int32_t w = (int32_t)seed; /* glibc keeps the running word in int32_t: seeds >= 2^31 go negative */
     g->s[0] = (uint32_t)seed;
     for (int i = 1; i < 31; i++) {
         /* 16807 * w mod (2^31 - 1) by Schrage's split, signed */
         int64_t hi = w / 127773, lo = w % 127773;
-        w = 16807 * lo - 2836 * hi;
+        w = (int32_t)(16807 * lo - 2836 * hi);
         if (w < 0)
             w += 2147483647;
         g->s[i] = (uint32_t)w;

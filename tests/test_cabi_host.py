@@ -1,0 +1,167 @@
+"""CPU tests of the product's host side: the C-ABI library loads, exports every
+symbol include/smcx.h declares, validates its arguments, fails loudly without a
+GPU (no CPU fallback), and its srand() state agrees with the oracle's rand().
+No compute entry is exercised here (there is no GPU in this container)."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    hdr = open(os.path.join(ROOT, "include", "smcx.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return sorted(set(re.findall(r"\b(smcx_[a-z_0-9]+)\s*\(", hdr)))
+
+
+def test_library_exports_every_declared_symbol(S):
+    lib = C.CDLL(S.LIB_PATH)
+    names = declared_symbols()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(lib, n), "libsmcx.so does not export %s" % n
+    assert sorted(S.EXPORTS) == names  # the Python binding covers the whole ABI
+
+
+def test_no_oracle_in_product():
+    """the product never links or imports the oracle"""
+    pkg = os.path.join(ROOT, "montecarlo-surfacer_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h", ".c", ".cpp")) or f == "Makefile":
+                txt = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "oracle" not in txt.lower().replace("oracle/ is", ""), os.path.join(dirpath, f)
+    out = subprocess.run(["ldd", os.path.join(pkg, "libsmcx.so")], capture_output=True, text=True).stdout
+    assert "oracle" not in out and "amdhip64" in out
+
+
+def test_default_params_are_the_reference_macros(S):
+    p = S.default_params(108, 2)
+    assert (p.N, p.M, p.nrep) == (108, 3, 2)
+    assert (p.L, p.Lz, p.T, p.A, p.cutoff) == (33.0, 240.0, 1.1, 1.1, 3.0)   # main.c:41-51, SMC.h:38
+    assert (p.a0, p.b0) == (5.960464477539063e-9, 2.44140625e-5)            # SMC.h:32-33
+    assert (p.Ncx, p.Ncz) == (33, 33)                                       # SMC.h:53-55
+    assert p.flags == S.FLAGS_REFERENCE and p.base_seed == 12345
+
+
+def test_parameter_validation_and_loud_failure_without_gpu(S):
+    lib = S._lib()
+    h = C.c_void_p()
+    for kw, want in ((dict(N=107), S.ERR_PARAM), (dict(N=0), S.ERR_PARAM), (dict(nrep=0), S.ERR_PARAM),
+                     (dict(L=-1.0), S.ERR_PARAM), (dict(T=0.0), S.ERR_PARAM), (dict(Ncz=300), S.ERR_PARAM),
+                     (dict(M=6), S.ERR_UNSUPPORTED), (dict(M=0), S.ERR_PARAM)):
+        p = S.default_params(108, 2)
+        for k, v in kw.items():
+            setattr(p, k, v)
+        assert lib.smcx_create(C.byref(p), C.byref(h)) == want, kw
+        assert not h.value
+    if S.device_count() == 0:
+        p = S.default_params(108, 2)
+        assert lib.smcx_create(C.byref(p), C.byref(h)) == S.ERR_NODEVICE
+        with pytest.raises(S.SmcxError) as e:
+            S.Engine(p)
+        assert e.value.status == S.ERR_NODEVICE
+        with pytest.raises(S.SmcxError):
+            S.eval_moves(p, np.zeros((2, 324)), np.zeros(18), np.zeros(2, dtype=np.int32), np.zeros((2, 3)))
+    assert lib.smcx_strerror(S.ERR_NODEVICE) == b"no HIP device"
+    assert lib.smcx_destroy(None) == S.OK
+
+
+def test_srand_state_agrees_with_oracle_rand(S, O):
+    """smcx_rng_seed = srand(): continuing r[i] = r[i-31] + r[i-3] from the exported
+    state must give rand()'s outputs."""
+    for seed in (0, 1, 42, 12345, 12345 + 4095, 2 ** 31 + 5, 2 ** 32 - 1):
+        st = S.rng_seed(seed)
+        assert st[31] == 0
+        h = [int(v) for v in st[:31]]
+        got = []
+        for _ in range(200):
+            nxt = (h[-31] + h[-3]) & 0xFFFFFFFF
+            h.append(nxt)
+            got.append(nxt >> 1)
+        assert got == list(O.Rng(seed).draws(200)), seed
+
+
+def test_block_generator_algebra(O):
+    """the kernel's 31-at-a-time rand() step (three stride-3 prefix sums, smcx_device.hpp
+    rand_block) restated in numpy against the oracle's one-at-a-time generator"""
+    def block(h):
+        w = h.copy()
+        w[:3] = (w[:3] + h[28:31]) & 0xFFFFFFFF
+        d = 3
+        while d <= 24:
+            sh = np.concatenate([np.zeros(d, dtype=np.uint64), w[:-d]])
+            w = (w + sh) & 0xFFFFFFFF
+            d *= 2
+        return w
+    import smcx_loader
+    S = smcx_loader.load()
+    h = S.rng_seed(777)[:31].astype(np.uint64)
+    r = O.Rng(777)
+    for _ in range(40):
+        h = block(h)
+        assert list(h >> 1) == list(r.draws(31))
+
+
+def test_shard_rule():
+    sys.path.insert(0, os.path.join(ROOT, "montecarlo-surfacer_amd"))
+    import importlib
+    dist = importlib.import_module("dist")
+    for total, world in ((32768, 8), (10, 4), (3, 8), (4096, 1)):
+        got = [dist.shard(total, r, world) for r in range(world)]
+        assert sum(c for _, c in got) == total
+        pos = 0
+        for first, count in got:
+            assert first == pos
+            pos += count
+    assert dist.shard(32768, 3, 8) == (3 * 4096, 4096)
+    with pytest.raises(ValueError):
+        dist.shard(8, 8, 8)
+
+
+_GLOO_WORKER = r'''
+import os, sys
+import numpy as np
+import torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+import dist as D
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", rank=rank, world_size=world)
+total, Ncz = 7, 5
+first, count = D.shard(total, rank, world)
+rec = np.zeros((count, 8)); zh = np.zeros((count, Ncz))
+for r in range(count):
+    g = first + r
+    rec[r] = [100 + g, 11, -5.0 * g, 25.0 * g * g, -g, 0, 10, 0]
+    zh[r] = np.arange(Ncz) + g
+packed = torch.from_numpy(np.concatenate([rec.ravel(), zh.ravel()]))
+obs = D.gather_observables(packed, count, Ncz)
+assert obs["accepted"].tolist() == [100 + g for g in range(total)], obs["accepted"]
+assert obs["zhist"].shape == (total, Ncz) and obs["zhist"][5, 2] == 7
+s = D.summarise(obs, N=10, maxsteps=10)
+assert abs(s["mean_of_meanE"] - np.mean([-5.0 * g / 11 for g in range(total)])) < 1e-12
+assert np.allclose(s["zprofile"], (np.arange(Ncz) * total + sum(range(total))) / (10 * total))
+dist.barrier()
+dist.destroy_process_group()
+print("rank", rank, "ok")
+'''
+
+
+def test_two_rank_gloo_gather(tmp_path):
+    """the N>1 path on CPU: replica sharding + the final observable gather, world_size 2"""
+    w = tmp_path / "worker.py"
+    w.write_text(_GLOO_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(w), os.path.join(ROOT, "montecarlo-surfacer_amd")],
+                              env=dict(env, RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                              text=True) for r in range(2)]
+    for p in procs:
+        out, err = p.communicate(timeout=240)
+        assert p.returncode == 0, err[-2000:]
+        assert "ok" in out

@@ -1,0 +1,367 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through
+the C ABI (libsmcx.so), against the CPU oracle on identical seeded inputs.
+
+Tolerances.  All arithmetic is fp64.  The GPU sums the neighbour loop in a
+different order (64-lane tree instead of l = 0..N-1), contracts a*b+c into FMA,
+multiplies by 1/L and 1/T where the reference divides, and uses the device libm;
+every such difference is a relative perturbation of ~1e-16 per operation.
+ * single evaluations (K1-K5):   |gpu - oracle| <= 1e-12 * (|value| + scale)
+ * one sweep, teacher-forced:    accept decisions identical; E, positions 1e-10
+ * free-running chains <= 20 sweeps: north-star tolerance 1e-6 relative on
+   acceptance ratio, mean energy and the z-profile.  Chains are chaotic
+   (1e-13 grows to 1e-6 in 30-60 sweeps), so longer chains are
+   compared through invariants, not value by value.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+T = A = 1.1
+
+
+def rel(a, b, scale=0.0):
+    return np.abs(np.asarray(a) - np.asarray(b)) / (np.abs(np.asarray(b)) + scale + 1e-300)
+
+
+def make_engine(S, O, R0, nrep, **kw):
+    N = len(R0) // 3 if np.ndim(R0) == 1 else np.shape(R0)[1] // 3
+    p = S.default_params(N, nrep, **kw)
+    eng = S.Engine(p)
+    eng.upload(R0, O.W_FIXTURE)
+    return eng, p
+
+
+def sys_of(O, p):
+    return O.make_sys(p.N, M=p.M, L=p.L, Lz=p.Lz, cutoff=p.cutoff, a0=p.a0, b0=p.b0, Ncx=p.Ncx, Ncz=p.Ncz)
+
+
+def dense_state(O, N=1024, seed=5):
+    """a state with neighbours inside the cutoff, particles at, near and beyond the walls"""
+    rs = np.random.RandomState(seed)
+    R = O.fcc(8, 4).reshape(-1, 3)[:N].copy()
+    R += 0.25 * rs.standard_normal(R.shape)
+    R[:, 2] *= 0.5
+    R[:40, 2] = 120.0 - np.abs(rs.standard_normal(40)) * 1.5      # close to the upper wall
+    R[40:80, 2] = -120.0 + np.abs(rs.standard_normal(40)) * 1.5   # close to the lower wall
+    R[80, 2] = 120.0 - 1e-3
+    R[81, 2] = -120.0 + 1e-3
+    R[82, 2] = 121.5   # beyond the wall: clamp branch SMC.c:738-739
+    R[83, 2] = -120.0  # exactly on it
+    R[:, 0] -= 33.0 * np.rint(R[:, 0] / 33.0)
+    R[:, 1] -= 33.0 * np.rint(R[:, 1] / 33.0)
+    return R.ravel()
+
+
+# ------------------------------------------------------------------ K1-K4
+@pytest.mark.parametrize("N", [256, 1024])
+def test_eval_moves_matches_oracle(S, O, N):
+    R = dense_state(O, 1024)[:3 * N] if N == 1024 else O.fcc(4, 4)
+    if N == 256:
+        R = R + 0.0
+        R[2::3] = R[2::3] * 0 + np.linspace(-119.9, 119.9, 256)  # spread to both walls
+        R[0::3] *= 0.2; R[1::3] *= 0.2                            # compress: pairs inside the cutoff
+    nrep = 48
+    rs = np.random.RandomState(N)
+    n = rs.randint(0, N, nrep).astype(np.int32)
+    if N == 1024:
+        n[:6] = [80, 81, 82, 83, 0, 41]
+    Rb = np.tile(R, (nrep, 1))
+    prop = np.stack([Rb[r, 3 * n[r]:3 * n[r] + 3] + 0.3 * rs.standard_normal(3) for r in range(nrep)])
+    prop[:, 0] -= 33.0 * np.rint(prop[:, 0] / 33.0)
+    prop[:, 1] -= 33.0 * np.rint(prop[:, 1] / 33.0)
+    prop[1] = [1.0, 2.0, 125.0]   # proposal beyond the wall
+    p = S.default_params(N, nrep)
+    out = S.eval_moves(p, Rb, O.W_FIXTURE, n, prop)
+    s = sys_of(O, p)
+    nz = 0
+    for r in range(nrep):
+        Um, Fm, Un, Fn = O.eval_move(s, Rb[r], O.W_FIXTURE, int(n[r]), prop[r])
+        ref = np.array([Um, *Fm, Un, *Fn])
+        sc = np.abs(ref).max()
+        assert np.all(np.abs(out[r] - ref) <= 1e-12 * (np.abs(ref) + sc)), (r, n[r], out[r], ref)
+        nz += np.count_nonzero(ref)
+    assert nz > 6 * nrep  # the in-cutoff and wall branches really ran
+
+
+def test_eval_moves_without_walls(S, O):
+    R = dense_state(O, 1024)
+    p = S.default_params(1024, 4, flags=S.FLAG_E0_RESTART)
+    n = np.array([1, 500, 82, 1023], dtype=np.int32)
+    prop = np.stack([R[3 * i:3 * i + 3] + 0.1 for i in n])
+    out = S.eval_moves(p, np.tile(R, (4, 1)), None, n, prop)
+    s = sys_of(O, p)
+    for r in range(4):
+        Rr = R.copy()
+        Um = O.energy_single(s, Rr, int(n[r])); Fm = O.force_single(s, Rr, int(n[r]))
+        Rr[3 * n[r]:3 * n[r] + 3] = prop[r]
+        Un = O.energy_single(s, Rr, int(n[r])); Fn = O.force_single(s, Rr, int(n[r]))
+        ref = np.array([Um, *Fm, Un, *Fn])
+        assert np.all(np.abs(out[r] - ref) <= 1e-12 * (np.abs(ref) + np.abs(ref).max()))
+
+
+# ------------------------------------------------------------------ K5
+@pytest.mark.parametrize("Na,Nz", [(4, 4), (8, 4), (8, 16), (16, 4)])
+def test_total_energy_matches_oracle(S, O, Na, Nz):
+    R0 = O.fcc(Na, Nz)
+    eng, p = make_engine(S, O, R0, 3)
+    E = eng.total_energy()
+    ref = O.total_energy(sys_of(O, p), R0, O.W_FIXTURE)
+    assert np.all(rel(E, ref) < 1e-12)
+    eng.close()
+
+
+def test_total_energy_dense_state(S, O):
+    R = dense_state(O)
+    eng, p = make_engine(S, O, R, 2)
+    ref = O.total_energy(sys_of(O, p), R, O.W_FIXTURE)
+    assert np.all(rel(eng.total_energy(), ref) < 1e-12) and abs(ref) > 1e30  # clamp term dominates
+    eng.close()
+
+
+# ------------------------------------------------------------------ S1: one sweep
+@pytest.mark.parametrize("case", ["N256", "N1024", "N108_padded", "N1024_dense_x2waves", "N4096"])
+def test_single_sweep_matches_oracle(S, O, case):
+    kw = {}
+    if case == "N256":
+        R0 = O.fcc(4, 4)
+    elif case == "N1024":
+        R0 = O.fcc(8, 4)
+    elif case == "N108_padded":
+        R0, _ = O.box_ref(108, 33.0, 200.0); kw = dict(Lz=200.0)
+    elif case == "N1024_dense_x2waves":
+        R0 = dense_state(O); R0[3 * 82 + 2] = 119.0; kw = dict(tune_slots=16, tune_waves=2)
+    else:
+        R0 = O.fcc(8, 16)
+    nrep = 3
+    eng, p = make_engine(S, O, R0, nrep, **kw)
+    eng.run(0, 1, 1)
+    ob = eng.observables()
+    Rg = eng.positions()
+    s = sys_of(O, p)
+    for r in range(nrep):
+        R = np.array(R0, copy=True)
+        E0 = O.total_energy(s, R, O.W_FIXTURE)
+        acc, E1, _ = O.sweep(s, O.Rng(12345 + r), R, O.W_FIXTURE, A, T, E=E0)
+        assert int(ob["accepted"][r]) == acc
+        assert rel(ob["E_last"][r], E1) < 1e-10
+        assert np.abs(Rg[r] - R).max() < 1e-9
+        assert ob["zhist"][r].sum() == p.N  # gather_lapse 1: one histogram of the initial state
+    eng.close()
+
+
+def test_compat_shim_one_particle_moves(S, O):
+    """smcx_one_particle_moves keeps the contract of SMC.h:102 (in-place R/Rn, += j, += U)"""
+    R0 = O.fcc(4, 4)
+    p = S.default_params(256, 1)
+    s = sys_of(O, p)
+    rng_gpu = S.rng_seed(777)
+    rng_cpu = O.Rng(777)
+    Rg, Rc = R0.copy(), R0.copy()
+    Rn = np.zeros_like(Rg)
+    j, U = 5, 1.25
+    jc, Uc = 5, 1.25
+    for _ in range(3):
+        j, U = S.one_particle_moves(p, rng_gpu, Rg, Rn, O.W_FIXTURE, 2.2, T, j, U)
+        a, Uc, _ = O.sweep(s, rng_cpu, Rc, O.W_FIXTURE, 2.2, T, E=Uc)
+        jc += a
+        assert j == jc and abs(U - Uc) < 1e-10 * max(1.0, abs(Uc))
+        assert np.abs(Rg - Rc).max() < 1e-9 and np.array_equal(Rn, Rg)
+    # the explicit RNG handle advanced by exactly 3*(4N+1) draws
+    h = [int(v) for v in rng_gpu[:31]]
+    left = int(rng_gpu[31])
+    nxt_gpu = (h[31 - left] >> 1) if left else (((h[0] + h[28]) & 0xFFFFFFFF) >> 1)
+    assert nxt_gpu == rng_cpu.rand()
+
+
+# ------------------------------------------------------------------ C: chains
+@pytest.mark.parametrize("Na,Nz,kw", [(4, 4, {}), (8, 4, {}), (8, 4, dict(tune_slots=16, tune_waves=4)),
+                                      (4, 4, dict(tune_slots=16, tune_waves=1))])
+def test_20_sweep_chain_observables(S, O, Na, Nz, kw):
+    R0 = O.fcc(Na, Nz)
+    nrep = 4
+    eng, p = make_engine(S, O, R0, nrep, flags=S.FLAGS_REFERENCE | S.FLAG_SERIES, **kw)
+    eng.run(0, 20, 1)
+    ob = eng.observables()
+    Es, jj = eng.series(20)
+    g, oob = eng.hist_info()
+    s = sys_of(O, p)
+    for r in range(nrep):
+        ref = O.chain(s, 12345 + r, R0, O.W_FIXTURE, T, A, 0, 20, 1)
+        assert rel(ob["acceptance_ratio"][r], ref["acceptance_ratio"]) < 1e-6
+        assert rel(ob["meanE"][r], ref["meanE"]) < 1e-6
+        assert rel(ob["dE"][r], ref["dE"]) < 1e-5
+        prof_g = ob["zhist"][r] / float(g[r]); prof_c = ref["zhist"] / float(ref["gathers"])
+        assert np.abs(prof_g - prof_c).sum() <= 1e-6 * prof_c.sum() + 2.0 / ref["gathers"]
+        assert int(g[r]) == 20 and int(oob[r]) == 0 and ob["zhist"][r].sum() == 20 * p.N
+        assert np.all(rel(Es[r], ref["E"], scale=1.0) < 1e-6)
+        assert np.count_nonzero(jj[r] != ref["jj"]) <= 1
+    eng.close()
+
+
+def test_thermalisation_and_E0_restart(S, O):
+    """SMC.c:110-125 (2A thermalisation) and the E[0] restart of the production series (:194)"""
+    R0 = O.fcc(4, 4)
+    s = O.make_sys(256)
+    for flags, restart in ((S.FLAGS_REFERENCE, True), (S.FLAG_WALLS, False)):
+        eng, p = make_engine(S, O, R0, 2, flags=flags | S.FLAG_SERIES)
+        eng.run(4, 6, 2)
+        ob = eng.observables()
+        Es, jj = eng.series(6)
+        ta = eng.therm_acceptance()
+        for r in range(2):
+            ref = O.chain(s, 12345 + r, R0, O.W_FIXTURE, T, A, 4, 6, 2, e0_restart=restart)
+            assert rel(Es[r][0], ref["E"][0], 1.0) < 1e-12
+            assert np.all(rel(Es[r], ref["E"], 1.0) < 1e-8)
+            assert rel(ob["meanE"][r], ref["meanE"]) < 1e-8
+            assert abs(ta[r] - ref["therm_acceptance"]) < 1e-12
+            assert np.array_equal(jj[r], ref["jj"])
+            assert np.array_equal(ob["zhist"][r], ref["zhist"]) and ref["gathers"] == 3
+        eng.close()
+
+
+def test_explicit_seeds_and_per_replica_positions(S, O):
+    rs = np.random.RandomState(2)
+    base = O.fcc(4, 4)
+    R0 = np.stack([base, base + 0.0, base])
+    R0[1] = np.roll(base.reshape(-1, 3), 7, axis=0).ravel()
+    seeds = np.array([99, 12345, 2 ** 31 + 17], dtype=np.uint32)
+    p = S.default_params(256, 3)
+    eng = S.Engine(p)
+    eng.upload(R0, O.W_FIXTURE, seeds)
+    eng.run(0, 3, 1)
+    ob = eng.observables()
+    s = sys_of(O, p)
+    for r in range(3):
+        ref = O.chain(s, int(seeds[r]), R0[r], O.W_FIXTURE, T, A, 0, 3, 1)
+        assert int(ob["accepted"][r]) == ref["accepted"]
+        assert rel(ob["E_last"][r], ref["Efinal"]) < 1e-10
+    eng.close()
+
+
+# ------------------------------------------------------------------ invariants at any size
+def test_determinism_sharding_and_resume(S, O):
+    """bit-identical results for: a repeated run; a replica computed inside a different
+    shard (seeds follow the global replica index); 2+3 sweeps vs 5 sweeps with the RNG
+    state exported and re-imported in between (checkpoint/resume of main.c:98-108, 162-170)."""
+    R0 = O.fcc(8, 4)
+    eng, p = make_engine(S, O, R0, 8)
+    eng.run(0, 5, 1)
+    a = eng.observables(); Ra = eng.positions()
+    eng.close()
+    eng, _ = make_engine(S, O, R0, 8)
+    eng.run(0, 5, 1)
+    b = eng.observables()
+    assert np.array_equal(a["E_last"], b["E_last"]) and np.array_equal(Ra, eng.positions())
+    eng.close()
+    # shard [5, 8) of the same ensemble, different geometry of the launch
+    eng, _ = make_engine(S, O, R0, 3, first_replica=5)
+    eng.run(0, 5, 1)
+    c = eng.observables()
+    assert np.array_equal(c["E_last"], a["E_last"][5:]) and np.array_equal(c["accepted"], a["accepted"][5:])
+    eng.close()
+    # resume
+    eng, _ = make_engine(S, O, R0, 8)
+    eng.run(0, 2, 1)
+    st, R2 = eng.rng_export(), eng.positions()
+    eng.close()
+    eng2 = S.Engine(S.default_params(1024, 8))
+    eng2.upload(R2, O.W_FIXTURE)
+    eng2.rng_import(st)
+    eng2.run(0, 3, 1)
+    assert np.array_equal(eng2.positions(), Ra)
+    eng2.close()
+
+
+def test_all_geometries_agree(S, O):
+    """every (slots, waves) instantiation that fits N=1024 gives the same chain to rounding"""
+    R0 = O.fcc(8, 4)
+    ref = O.chain(O.make_sys(1024), 12345, R0, O.W_FIXTURE, T, A, 0, 3, 1)
+    for slots, waves in ((16, 1), (32, 1), (64, 1), (16, 2), (32, 2), (16, 4), (32, 4), (16, 8), (32, 8),
+                         (16, 16), (32, 16)):
+        eng, p = make_engine(S, O, R0, 2, tune_slots=slots, tune_waves=waves)
+        assert eng.geometry[:2] == (slots, waves)
+        eng.run(0, 3, 1)
+        ob = eng.observables()
+        assert int(ob["accepted"][0]) == ref["accepted"], (slots, waves)
+        assert rel(ob["E_last"][0], ref["Efinal"]) < 1e-9, (slots, waves)
+        assert np.abs(eng.positions()[0] - ref["R"]).max() < 1e-8, (slots, waves)
+        eng.close()
+
+
+def test_full_size_invariants_N4096(S, O):
+    """BASELINE config 3 shape (N=4096; replicas reduced to keep the test short): the
+    incremental energy equals a from-scratch recomputation, histograms conserve particles,
+    the first replicas match the oracle."""
+    R0 = O.fcc(8, 16)
+    nrep = 256
+    eng, p = make_engine(S, O, R0, nrep)
+    eng.run(1, 3, 2)
+    ob = eng.observables()
+    g, oob = eng.hist_info()
+    Erec = eng.total_energy()
+    # thermalisation changed the energy but the series restarted from E[0] (SMC.c:194):
+    # compare energy differences instead
+    eng2, _ = make_engine(S, O, R0, nrep, flags=S.FLAG_WALLS)
+    eng2.run(1, 3, 2)
+    ob2 = eng2.observables()
+    assert np.all(rel(ob2["E_last"], eng2.total_energy()) < 1e-9)
+    assert np.array_equal(ob2["accepted"], ob["accepted"])
+    assert np.all(g == 1) and np.all(oob == 0) and np.all(ob["zhist"].sum(axis=1) == 4096)
+    assert np.all(np.isfinite(Erec))
+    s = sys_of(O, p)
+    ref = O.chain(s, 12345, R0, O.W_FIXTURE, T, A, 1, 3, 2)
+    assert int(ob["accepted"][0]) == ref["accepted"] and rel(ob["meanE"][0], ref["meanE"]) < 1e-9
+    # distinct seeds really give distinct chains
+    assert len(np.unique(ob["E_last"])) > nrep // 2
+    eng.close(); eng2.close()
+
+
+def test_edge_cases(S, O):
+    # the smallest system: two particles, no neighbours inside the cutoff
+    R0 = np.array([0.0, 0.0, -10.0, 5.0, 5.0, 10.0])
+    p = S.default_params(2, 1)
+    eng = S.Engine(p)
+    eng.upload(R0, O.W_FIXTURE)
+    eng.run(0, 4, 2)
+    ob = eng.observables()
+    ref = O.chain(sys_of(O, p), 12345, R0, O.W_FIXTURE, T, A, 0, 4, 2)
+    assert int(ob["accepted"][0]) == ref["accepted"] and rel(ob["E_last"][0], ref["Efinal"], 1e-12) < 1e-9
+    assert np.array_equal(ob["zhist"][0], ref["zhist"])
+    eng.close()
+    # zero sweeps: observables are those of the initial state
+    eng, p = make_engine(S, O, O.fcc(4, 4), 2)
+    eng.run(0, 0, 1)
+    ob = eng.observables()
+    assert np.all(ob["accepted"] == 0) and np.all(ob["zhist"] == 0)
+    with pytest.raises(S.SmcxError):
+        eng.run(0, 1, 0)  # gather_lapse < 1
+    eng.close()
+    # run before upload
+    eng = S.Engine(S.default_params(256, 1))
+    with pytest.raises(S.SmcxError) as e:
+        eng.run(0, 1, 1)
+    assert e.value.status == S.ERR_STATE
+    eng.close()
+
+
+def test_observable_export_to_device_memory(S, O):
+    """the packed block the RCCL gather moves (smcx_export_observables_device)"""
+    import sys, os
+    import torch
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                    "montecarlo-surfacer_amd"))
+    import dist as D
+    eng, p = make_engine(S, O, O.fcc(4, 4), 5)
+    eng.run(0, 4, 2)
+    ob = eng.observables()
+    nbytes = eng.obs_device_bytes()
+    buf = torch.zeros(nbytes // 8, dtype=torch.float64, device="cuda")
+    eng.export_observables_device(buf.data_ptr(), nbytes)
+    torch.cuda.synchronize()
+    got = D.gather_observables(buf, 5, p.Ncz)
+    assert np.array_equal(got["accepted"], ob["accepted"].astype(np.float64))
+    assert np.array_equal(got["zhist"], ob["zhist"].astype(np.float64))
+    sm = D.summarise(got, p.N, 4)
+    assert np.allclose(sm["meanE"], ob["meanE"], rtol=1e-15) and np.allclose(sm["acceptance_ratio"], ob["acceptance_ratio"])
+    eng.close()
