@@ -35,6 +35,7 @@ struct Handle {
     double last_sweep_ms = 0.0; // sweep kernels only
     int last_launches = 0;
     std::vector<hipEvent_t> evs; // start/stop pairs around the sweep launches
+    std::vector<int> last_sweeps; // sweeps in each launch of the last run
     std::string err;
 };
 
@@ -199,7 +200,7 @@ extern "C" int smcx_destroy(smcx_handle *hh)
     DevCtx &c = h.c;
     hipFree(c.R); hipFree((void *)c.W); hipFree(c.rng); hipFree(c.raw); hipFree(c.displ);
     hipFree(c.uni); hipFree(c.offs); hipFree(c.obs); hipFree(c.zhist); hipFree(c.Eseries);
-    hipFree(c.jjseries); hipFree(h.d_save); hipFree(h.d_tmp);
+    hipFree(c.jjseries); hipFree(c.rec); hipFree(h.d_save); hipFree(h.d_tmp);
     for (hipEvent_t e : h.evs) hipEventDestroy(e);
     if (h.ev0) hipEventDestroy(h.ev0);
     if (h.ev1) hipEventDestroy(h.ev1);
@@ -256,6 +257,7 @@ extern "C" int smcx_create(const smcx_params *p, smcx_handle **out)
     CRT(hipMalloc(&c.uni, nrep * h.chunk * N * sizeof(double)));
     CRT(hipMalloc(&c.offs, nrep * h.chunk * sizeof(int)));
     CRT(hipMalloc(&c.obs, nrep * sizeof(ObsRec)));
+    CRT(hipMalloc(&c.rec, nrep * h.chunk * sizeof(SweepRec)));
     CRT(hipMalloc(&c.zhist, nrep * p->Ncz * sizeof(unsigned long long)));
     CRT(hipMalloc(&h.d_save, nrep * sizeof(double)));
     CRT(hipMalloc(&h.d_tmp, nrep * sizeof(double)));
@@ -337,13 +339,22 @@ static int ensure_series(Handle &h, int maxsteps)
     return SMCX_OK;
 }
 
-// one phase of sMC: `steps` sweeps at step parameter A, in chunks of h.chunk
+// one phase of sMC: `steps` sweeps at step parameter A.  A launch group holds at most
+// h.chunk sweeps (the random numbers kept on the device) and ends where the next density
+// histogram is due, which is taken from the positions in memory before that sweep's moves.
 static int run_phase(Handle &h, int steps, double A, int production, int gather_lapse)
 {
     int done = 0;
     bool first = true;
     while (done < steps) {
-        const int k = (steps - done < h.chunk) ? steps - done : h.chunk;
+        int k = (steps - done < h.chunk) ? steps - done : h.chunk;
+        if (production) {
+            if ((done + 1) % gather_lapse == 0) // SMC.c:137-141
+                HIPCHK(&h, launch_hist(h.c, h.stream));
+            // next sweep index n > done with (n+1) % gather_lapse == 0
+            const int next = ((done + 1) / gather_lapse + 1) * gather_lapse - 1;
+            if (next - done < k) k = next - done;
+        }
         HIPCHK(&h, launch_rng_prepass(h.c, k, A, h.stream));
         while ((int)h.evs.size() < 2 * (h.last_launches + 1)) {
             hipEvent_t e;
@@ -351,10 +362,11 @@ static int run_phase(Handle &h, int steps, double A, int production, int gather_
             h.evs.push_back(e);
         }
         HIPCHK(&h, hipEventRecord(h.evs[2 * h.last_launches], h.stream));
-        HIPCHK(&h, launch_sweeps(h.c, h.S, h.WPR, k, A, production, gather_lapse, done,
-                                 (production && first) ? 1 : 0, h.stream));
+        HIPCHK(&h, launch_sweeps(h.c, h.S, h.WPR, k, A, h.stream));
         HIPCHK(&h, hipEventRecord(h.evs[2 * h.last_launches + 1], h.stream));
+        HIPCHK(&h, launch_finalize(h.c, k, production, done, (production && first) ? 1 : 0, h.stream));
         h.last_launches++;
+        h.last_sweeps.push_back(k);
         first = false;
         done += k;
     }
@@ -371,6 +383,7 @@ extern "C" int smcx_run(smcx_handle *hh, int eqsteps, int maxsteps, int gather_l
     int rc = ensure_series(h, maxsteps);
     if (rc != SMCX_OK) return rc;
     h.last_launches = 0;
+    h.last_sweeps.clear();
     // zero the accumulators, remember E at entry (the reference's E[0])
     HIPCHK(&h, launch_obs_op(h.c, h.d_save, 0, h.stream));
     HIPCHK(&h, hipEventRecord(h.ev0, h.stream));

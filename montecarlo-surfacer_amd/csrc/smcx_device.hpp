@@ -33,6 +33,14 @@ struct ObsRec {                   // per-replica accumulators, 64 B
     double oob;
 };
 
+// what one sweep hands to the bookkeeping kernel: the chain's running energy after
+// the sweep and its number of accepted moves (E[n+1] and jj[n] of SMC.c:194-195)
+struct SweepRec {
+    double E;
+    int accepted;
+    int pad;
+};
+
 struct DevCtx {
     int N, M, M2, nrep;
     int Ncx, Ncz;
@@ -53,6 +61,19 @@ struct DevCtx {
     double *Eseries;              // [nrep][series_stride] or null
     int *jjseries;                // [nrep][series_stride] or null
     long rawStride;
+    SweepRec *rec;                // [nrep][chunk] per-sweep records of the last sweep launch
+};
+
+// the (few) things the hot kernel needs; everything cold stays in DevCtx
+struct SweepArgs {
+    int N, chunk;
+    double L, invL, cutoff2, invT;
+    double *R;               // [nrep][3N]
+    const double *displ;     // [nrep][chunk][3N]
+    const double *uni;       // [nrep][chunk][N]
+    const int *offs;         // [nrep][chunk]
+    const ObsRec *obs;       // [nrep] (Ecur at entry)
+    SweepRec *rec;           // [nrep][chunk]
 };
 
 // ---- cross-lane helpers ------------------------------------------------------
@@ -76,34 +97,63 @@ __device__ __forceinline__ double uniform_d(double v)
 
 __device__ __forceinline__ double xchg(double v, int mask) { return __shfl_xor(v, mask, 64); }
 
-// Reduce eight per-lane values over the 64 lanes of a wavefront.  Each step
-// halves the number of live values instead of reducing all eight through all
-// six levels: 4+2+1 exchanges for the top three levels, 3 for the rest.
-// On return every lane of lane-group g = lane>>3 holds the wave total of v[g].
+// ---- cross-lane sums without LDS ------------------------------------------------
+// gfx950 has v_permlane32_swap / v_permlane16_swap (swap the upper half / the odd
+// 16-lane rows of one register with the lower half / even rows of another) and the
+// DPP row controls; together they give every xor-butterfly level in the VALU.
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+// lanes 0-31: a(lane) + a(lane+32)      lanes 32-63: b(lane-32) + b(lane)
+__device__ __forceinline__ double sum_swap32(double a, double b)
+{
+    const u32x2 l = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+    const u32x2 h = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+    return __hiloint2double((int)h[0], (int)l[0]) + __hiloint2double((int)h[1], (int)l[1]);
+}
+// rows 0,2: a(row) + a(row+1)           rows 1,3: b(row-1) + b(row)
+__device__ __forceinline__ double sum_swap16(double a, double b)
+{
+    const u32x2 l = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+    const u32x2 h = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+    return __hiloint2double((int)h[0], (int)l[0]) + __hiloint2double((int)h[1], (int)l[1]);
+}
+template <int CTRL> __device__ __forceinline__ double dpp_mov(double v)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+constexpr int DPP_ROR8 = 0x128;        // row_ror:8        lane ^ 8 within a row of 16
+constexpr int DPP_HALF_MIRROR = 0x141; // row_half_mirror  lane i <-> 7-i within 8 lanes
+constexpr int DPP_QUAD_X2 = 0x4E;      // quad_perm:[2,3,0,1]  lane ^ 2
+constexpr int DPP_QUAD_X1 = 0xB1;      // quad_perm:[1,0,3,2]  lane ^ 1
+
+// Reduce eight per-lane values over the 64 lanes of a wavefront.  Each level halves
+// the number of live values instead of carrying all eight through all six levels:
+// 4 + 2 + 1 exchanges for the top three levels, 3 for the rest, 34 VALU instructions
+// in all and no LDS.  On return every lane of lane-group g = lane>>3 holds the wave
+// total of v[g].
 __device__ __forceinline__ double reduce8(const double (&v)[8], int lane)
 {
-    const bool b5 = lane & 32, b4 = lane & 16, b3 = lane & 8;
     double w[4], u[2];
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-        double keep = b5 ? v[4 + i] : v[i];
-        double send = b5 ? v[i] : v[4 + i];
-        w[i] = keep + xchg(send, 32);
-    }
+    for (int i = 0; i < 4; i++) w[i] = sum_swap32(v[i], v[4 + i]); // low half: v[i], high: v[4+i]
 #pragma unroll
-    for (int i = 0; i < 2; i++) {
-        double keep = b4 ? w[2 + i] : w[i];
-        double send = b4 ? w[i] : w[2 + i];
-        u[i] = keep + xchg(send, 16);
-    }
-    double keep = b3 ? u[1] : u[0];
-    double send = b3 ? u[0] : u[1];
-    double r = keep + xchg(send, 8);
-    r += xchg(r, 4);
-    r += xchg(r, 2);
-    r += xchg(r, 1);
+    for (int i = 0; i < 2; i++) u[i] = sum_swap16(w[i], w[2 + i]); // rows: v[i], v[2+i], v[4+i], v[6+i]
+    const bool b3 = lane & 8;
+    const double keep = b3 ? u[1] : u[0];
+    const double send = b3 ? u[0] : u[1];
+    double r = keep + dpp_mov<DPP_ROR8>(send);                     // 8-lane groups: v[lane>>3]
+    r += dpp_mov<DPP_HALF_MIRROR>(r);
+    r += dpp_mov<DPP_QUAD_X2>(r);
+    r += dpp_mov<DPP_QUAD_X1>(r);
     return r;
 }
+
+// sum of t over lanes differing in bit 5 / 4 / 3, result in every lane
+__device__ __forceinline__ double sum_x32(double t) { return sum_swap32(t, t); }
+__device__ __forceinline__ double sum_x16(double t) { return sum_swap16(t, t); }
+__device__ __forceinline__ double sum_x8(double t) { return t + dpp_mov<DPP_ROR8>(t); }
 
 // ---- Lennard-Jones term shared by pairs, wall sites and the plane -------------
 // e += ca/r^12 - cb/r^6 ; F += (48 ca/r^14 - 24 cb/r^8) d      (K1-K4, SMC.c:577-578,
@@ -173,6 +223,7 @@ struct RoleTable {
     double sx[64], sy[64]; // site position i*dw, j*dw (SMC.c:748-750)
     double ca[64], cb[64]; // W[2m], W[2m+1] or a0, b0 or 1,1
     int role[64];          // -1 = none
+    double Lz, invLz, halfLz; // wall geometry, read by the few wall lanes only
 };
 
 constexpr int SIDE_LANE_OLD = 30;
@@ -201,10 +252,12 @@ __device__ __forceinline__ void fill_roles(const DevCtx &c, RoleTable &rt, int l
     if (lane == SIDE_LANE_NEW) role = 3;
     rt.sx[lane] = sx; rt.sy[lane] = sy; rt.ca[lane] = ca; rt.cb[lane] = cb;
     rt.role[lane] = role;
+    if (lane == 0) { rt.Lz = c.Lz; rt.invLz = c.invLz; rt.halfLz = c.halfLz; }
 }
 
 // signed distance to the nearer wall with the reference's clamp (SMC.c:736-739)
-__device__ __forceinline__ double wall_dz(const DevCtx &c, double rz)
+template <class Ctx>
+__device__ __forceinline__ double wall_dz(const Ctx &c, double rz)
 {
     double dz = rz + c.halfLz;
     dz = dz - c.Lz * __builtin_rint(dz * c.invLz);
@@ -215,7 +268,7 @@ __device__ __forceinline__ double wall_dz(const DevCtx &c, double rz)
 
 // P: current position of n, A: its proposal, B: current position of the next particle.
 // Executed by wave 0 only; `role` is this lane's rt.role[lane].
-__device__ __forceinline__ void special_block(const DevCtx &c, const Geo &g, const RoleTable &rt,
+__device__ __forceinline__ void special_block(const Geo &g, const RoleTable &rt,
                                               int lane, int role, bool hasA, bool hasB, bool sides,
                                               double Px, double Py, double Pz, double Ax, double Ay,
                                               double Az, double Bx, double By, double Bz,
@@ -233,7 +286,7 @@ __device__ __forceinline__ void special_block(const DevCtx &c, const Geo &g, con
         double dx, dy, dz;
         if (wallrole) {
             dx = tx - rt.sx[lane]; dy = ty - rt.sy[lane];
-            dz = wall_dz(c, tz);
+            dz = wall_dz(rt, tz);
         } else {
             const bool old = (role == 2);
             dx = tx - (old ? Px : Ax); dy = ty - (old ? Py : Ay);

@@ -95,8 +95,6 @@ template <int WPR> struct SweepShared {
     RoleTable roles;
     double red[2][WPR][8];
     double side[2][2][4];
-    unsigned zh[256];
-    unsigned oob;
 };
 
 // combine the eight wave totals (and, with several waves, the waves) into
@@ -126,21 +124,28 @@ __device__ __forceinline__ void combine(SweepShared<WPR> &sh, int &par, int lane
         double t = 0.0;
         if (lane < 8 * WPR) t = sh.red[par][lane >> 3][lane & 7];
         if constexpr (WPR > 8) t += sh.red[par][(lane >> 3) + 8][lane & 7];
-        if constexpr (WPR >= 8) t += xchg(t, 32);
-        if constexpr (WPR >= 4) t += xchg(t, 16);
-        t += xchg(t, 8);
+        if constexpr (WPR >= 8) t = sum_x32(t);
+        if constexpr (WPR >= 4) t = sum_x16(t);
+        t = sum_x8(t);
 #pragma unroll
         for (int j = 0; j < 8; j++) tot[j] = rdlane(t, j);
 #pragma unroll
-        for (int j = 0; j < 4; j++) { sOld[j] = sh.side[par][0][j]; sNew[j] = sh.side[par][1][j]; }
+        for (int j = 0; j < 4; j++) {
+            sOld[j] = uniform_d(sh.side[par][0][j]);
+            sNew[j] = uniform_d(sh.side[par][1][j]);
+        }
         par ^= 1;
     }
 }
 
+// The hot kernel.  One workgroup = one replica chain; it keeps the chain's positions in
+// registers across the `nsweeps` sweeps of the launch.  Per trial move: ONE pass over
+// the register-resident neighbours evaluates the proposal of particle n (probe A) and
+// the current position of particle n+1 (probe B); one 8-value reduction; the Metropolis
+// decision in scalar registers.  Wave-uniform values live in SGPRs (uniform_d).
 template <int S, int WPR, int MINW>
 __global__ void __launch_bounds__(64 * WPR, MINW)
-sweep_kernel(DevCtx c, int nsweeps, double A, int production, int gather_lapse, int sweep_base,
-             int first_production)
+sweep_kernel(SweepArgs a, DevCtx c, int nsweeps, double A)
 {
     constexpr int T = 64 * WPR;
     __shared__ SweepShared<WPR> sh;
@@ -149,9 +154,9 @@ sweep_kernel(DevCtx c, int nsweeps, double A, int production, int gather_lapse, 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = uniform(tid >> 6);
-    const int N = c.N;
+    const int N = a.N;
 
-    double *Rg = c.R + (size_t)rep * 3 * N;
+    double *Rg = a.R + (size_t)rep * 3 * N;
 
     // ---- register-resident positions: particle l in lane l % T, slot l / T ------
     double x[S], y[S], z[S];
@@ -163,83 +168,54 @@ sweep_kernel(DevCtx c, int nsweeps, double A, int production, int gather_lapse, 
     }
     int rot = 0; // register slot j holds logical slot (j + rot) % S
 
-    for (int i = tid; i < 256; i += T) sh.zh[i] = 0u;
-    if (tid == 0) sh.oob = 0u;
-    if (wave == 0) fill_roles(c, sh.roles, lane);
+    if (wave == 0) fill_roles(c, sh.roles, lane); // the only use of the cold context
     __syncthreads();
     const int role = (wave == 0) ? sh.roles.role[lane] : -1;
 
-    Geo g; g.L = c.L; g.invL = c.invL; g.cutoff2 = c.cutoff2;
+    Geo g; g.L = a.L; g.invL = a.invL; g.cutoff2 = a.cutoff2;
 
-    double E = c.obs[rep].Ecur; // identical in every lane
-    if (production && first_production && tid == 0) { // entry 0 of the energy series, SMC.c:48/194
-        const double e0 = E + c.c3NT2;
-        c.obs[rep].sumE = e0; c.obs[rep].sumE2 = e0 * e0; c.obs[rep].nsamp = 1.0;
-        if (c.Eseries) c.Eseries[(size_t)rep * c.series_stride] = E;
-    }
-    int gathers = 0;
+    double E = uniform_d(a.obs[rep].Ecur);
     int par = 0;
+    const double AoT = A * a.invT;         // SMC.c:307-309 (A/T)
+    const double Ao4T = A * 0.25 * a.invT; // SMC.c:327 (A/(4T))
 
-    const double AoT = A * c.invT;         // SMC.c:307-309 (A/T)
-    const double Ao4T = A * 0.25 * c.invT; // SMC.c:327 (A/(4T))
-
+#pragma unroll 1
     for (int sw = 0; sw < nsweeps; sw++) {
-        // ---- H: density histogram before this sweep's moves (SMC.c:137-141) --------
-        if (production && ((sweep_base + sw + 1) % gather_lapse == 0)) {
-#pragma unroll
-            for (int k = 0; k < S; k++) {
-                int ls = k + rot; if (ls >= S) ls -= S;
-                if (ls * T + tid < N) {
-                    const int ci = (int)floor((x[k] / c.L + .5) * c.Ncx) & 0xff;
-                    const int cj = (int)floor((y[k] / c.L + .5) * c.Ncx) & 0xff;
-                    const int ck = (int)floor((z[k] / c.Lz + .5) * c.Ncz) & 0xff;
-                    const int cell = ci * c.Ncx * c.Ncz + cj * c.Ncz + ck;
-                    if (cell < c.Ncx * c.Ncx * c.Ncz) atomicAdd(&sh.zh[cell % c.Ncz], 1u);
-                    else atomicAdd(&sh.oob, 1u);
-                }
-            }
-            gathers++;
-        }
-
-        const double *displ = c.displ + ((size_t)rep * c.chunk + sw) * 3 * N;
-        const double *uni = c.uni + ((size_t)rep * c.chunk + sw) * N;
-        const int n0 = uniform(c.offs[(size_t)rep * c.chunk + sw]);
+        // positions written through by the owner wave in the last moves of the previous
+        // sweep must have reached L2 before any wave fetches them again
+        if constexpr (WPR > 1) __syncthreads();
+        const double *displ = a.displ + ((size_t)rep * a.chunk + sw) * 3 * N;
+        const double *uni = a.uni + ((size_t)rep * a.chunk + sw) * N;
+        const int n0 = uniform(a.offs[(size_t)rep * a.chunk + sw]);
 
         int jacc = 0;
         // the visiting order n0..N-1, 0..n0-1 (SMC.c:292-294) is two ascending runs
+#pragma unroll 1
         for (int run = 0; run < 2; run++) {
             const int first = run == 0 ? n0 : 0;
             const int len = run == 0 ? N - n0 : n0;
             if (len == 0) continue;
             const int vbase = run == 0 ? 0 : N - n0;
-            int ks = first / T;
+            const int ks = first / T;
             while (rot != ks) { rotate1<S>(x, y, z); rot = (rot + 1 == S) ? 0 : rot + 1; }
-            int tl = first - ks * T; // owner thread of the current particle (always slot 0)
+            // iteration i = -1 is the run's prologue: no particle moves, probe B alone
+            // gives Um,Fm of the first particle.  tl = owner thread of particle n (slot 0).
+            int tl = first - ks * T - 1;
 
-            // prologue: Um,Fm of the run's first particle (B sums only)
-            double Px, Py, Pz;
-            if constexpr (WPR == 1) {
-                Px = rdlane(x[0], tl); Py = rdlane(y[0], tl); Pz = rdlane(z[0], tl);
-            } else {
-                Px = ld_coherent(Rg + 3 * first); Py = ld_coherent(Rg + 3 * first + 1);
-                Pz = ld_coherent(Rg + 3 * first + 2);
+            double Px = 0.0, Py = 0.0, Pz = FAR_PROBE;   // current position of particle n
+            double Um = 0.0, Fmx = 0.0, Fmy = 0.0, Fmz = 0.0;
+            double nBx = 0.0, nBy = 0.0, nBz = FAR_PROBE; // WPR > 1: next particle, fetched one
+                                                          // move ahead of its use
+            if constexpr (WPR > 1) {
+                nBx = ld_coherent(Rg + 3 * first); nBy = ld_coherent(Rg + 3 * first + 1);
+                nBz = ld_coherent(Rg + 3 * first + 2);
             }
-            double Um, Fmx, Fmy, Fmz;
-            {
-                double v[8] = {0, 0, 0, 0, 0, 0, 0, 0}, side[4], tot[8], s0[4], s1[4];
-                fused_pass<S>(g, x, y, z, 0.0, 0.0, FAR_PROBE, Px, Py, Pz, true, tid == tl, false, v);
-                if (wave == 0)
-                    special_block(c, g, sh.roles, lane, role, false, true, false, Px, Py, Pz, 0.0, 0.0,
-                                  FAR_PROBE, Px, Py, Pz, v, side);
-                else side[0] = side[1] = side[2] = side[3] = 0.0;
-                combine<WPR>(sh, par, lane, wave, v, side, tot, s0, s1);
-                Um = 4.0 * tot[4]; Fmx = tot[5]; Fmy = tot[6]; Fmz = tot[7];
-            }
-
             double bdx = 0.0, bdy = 0.0, bdz = 0.0, bu = 2.0;
-            for (int i = 0; i < len; i++) {
+#pragma unroll 1
+            for (int i = -1; i < len; i++) {
                 const int n = first + i;
-                if ((i & 63) == 0) { // this wave's next 64 displacements / uniforms
+                const bool hasA = (i >= 0);
+                if (hasA && (i & 63) == 0) { // this wave's next 64 displacements / uniforms
                     if (i + lane < len) {
                         const int pn = n + lane;
                         bdx = displ[3 * pn]; bdy = displ[3 * pn + 1]; bdz = displ[3 * pn + 2];
@@ -248,13 +224,15 @@ sweep_kernel(DevCtx c, int nsweeps, double A, int production, int gather_lapse, 
                 }
                 const int j = i & 63;
                 // proposal, SMC.c:307-316
-                const double dX = Fmx * AoT + rdlane(bdx, j);
-                const double dY = Fmy * AoT + rdlane(bdy, j);
-                const double dZ = Fmz * AoT + rdlane(bdz, j);
-                double Qx = Px + dX, Qy = Py + dY, Qz = Pz + dZ;
-                Qx = Qx - c.L * __builtin_rint(Qx * c.invL);
-                Qy = Qy - c.L * __builtin_rint(Qy * c.invL);
-                Qx = uniform_d(Qx); Qy = uniform_d(Qy); Qz = uniform_d(Qz);
+                double Qx = 0.0, Qy = 0.0, Qz = FAR_PROBE;
+                if (hasA) {
+                    Qx = Px + (Fmx * AoT + rdlane(bdx, j));
+                    Qy = Py + (Fmy * AoT + rdlane(bdy, j));
+                    Qz = Pz + (Fmz * AoT + rdlane(bdz, j));
+                    Qx = Qx - a.L * __builtin_rint(Qx * a.invL);
+                    Qy = Qy - a.L * __builtin_rint(Qy * a.invL);
+                    Qx = uniform_d(Qx); Qy = uniform_d(Qy); Qz = uniform_d(Qz);
+                }
 
                 const bool hasB = (i + 1 < len);
                 const bool cross = hasB && (tl == T - 1);
@@ -268,76 +246,77 @@ sweep_kernel(DevCtx c, int nsweeps, double A, int production, int gather_lapse, 
                             Bx = rdlane(x[0], tl + 1); By = rdlane(y[0], tl + 1); Bz = rdlane(z[0], tl + 1);
                         }
                     } else {
-                        Bx = uniform_d(ld_coherent(Rg + 3 * (n + 1)));
-                        By = uniform_d(ld_coherent(Rg + 3 * (n + 1) + 1));
-                        Bz = uniform_d(ld_coherent(Rg + 3 * (n + 1) + 2));
+                        Bx = uniform_d(nBx); By = uniform_d(nBy); Bz = uniform_d(nBz);
+                    }
+                }
+                if constexpr (WPR > 1) {
+                    // particle n+2 cannot change before its own move: fetch it now, use it next move
+                    if (i + 2 < len) {
+                        nBx = ld_coherent(Rg + 3 * (n + 2)); nBy = ld_coherent(Rg + 3 * (n + 2) + 1);
+                        nBz = ld_coherent(Rg + 3 * (n + 2) + 2);
                     }
                 }
 
                 double v[8] = {0, 0, 0, 0, 0, 0, 0, 0}, side[4], tot[8], sOld[4], sNew[4];
                 const bool exA0 = (tid == tl);
-                const bool exB0 = (tid == tl) || (hasB && !cross && tid == tl + 1);
+                const bool exB0 = (hasA && tid == tl) || (hasB && !cross && tid == tl + 1);
                 const bool exB1 = cross && (tid == 0);
                 fused_pass<S>(g, x, y, z, Qx, Qy, Qz, Bx, By, Bz, exA0, exB0, exB1, v);
                 if (wave == 0)
-                    special_block(c, g, sh.roles, lane, role, true, hasB, true, Px, Py, Pz, Qx, Qy, Qz,
+                    special_block(g, sh.roles, lane, role, hasA, hasB, hasA, Px, Py, Pz, Qx, Qy, Qz,
                                   Bx, By, Bz, v, side);
                 else side[0] = side[1] = side[2] = side[3] = 0.0;
                 combine<WPR>(sh, par, lane, wave, v, side, tot, sOld, sNew);
 
-                const double Un = 4.0 * tot[0], Fnx = tot[1], Fny = tot[2], Fnz = tot[3];
-                // SMC acceptance, SMC.c:326-335
-                const double gx = Fnx - Fmx, gy = Fny - Fmy, gz = Fnz - Fmz;
-                const double deltaW = (gx * gx + gy * gy + gz * gz +
-                                       2.0 * (gx * Fmx + gy * Fmy + gz * Fmz)) * Ao4T;
-                const double arg = Un - Um +
-                                   (dX * (Fnx + Fmx) + dY * (Fny + Fmy) + dZ * (Fnz + Fmz)) * 0.5 + deltaW;
-                const double ap = exp(-arg * c.invT);
-                const double u = rdlane(bu, j);
-                const bool acc = (u < ap);
-                const bool upd = acc && (tid == tl);
-                x[0] = upd ? Qx : x[0]; y[0] = upd ? Qy : y[0]; z[0] = upd ? Qz : z[0];
-                if constexpr (WPR > 1) {
-                    if (upd) { Rg[3 * n] = Qx; Rg[3 * n + 1] = Qy; Rg[3 * n + 2] = Qz; }
+                bool acc = false;
+                if (hasA) {
+                    const double Un = 4.0 * tot[0], Fnx = tot[1], Fny = tot[2], Fnz = tot[3];
+                    // SMC acceptance, SMC.c:326-335
+                    const double dX = Fmx * AoT + rdlane(bdx, j);
+                    const double dY = Fmy * AoT + rdlane(bdy, j);
+                    const double dZ = Fmz * AoT + rdlane(bdz, j);
+                    const double gx = Fnx - Fmx, gy = Fny - Fmy, gz = Fnz - Fmz;
+                    const double deltaW = (gx * gx + gy * gy + gz * gz +
+                                           2.0 * (gx * Fmx + gy * Fmy + gz * Fmz)) * Ao4T;
+                    const double arg = Un - Um +
+                                       (dX * (Fnx + Fmx) + dY * (Fny + Fmy) + dZ * (Fnz + Fmz)) * 0.5 + deltaW;
+                    const double u = rdlane(bu, j);
+                    // u <= 1 < exp(-arg/T) whenever arg < 0: the exponential is only needed uphill
+                    acc = true;
+                    if (!(arg < 0.0)) acc = (u < exp(-arg * a.invT));
+                    acc = (uniform((int)acc) != 0);
+                    const bool upd = acc && (tid == tl);
+                    x[0] = upd ? Qx : x[0]; y[0] = upd ? Qy : y[0]; z[0] = upd ? Qz : z[0];
+                    if constexpr (WPR > 1) {
+                        if (upd) { Rg[3 * n] = Qx; Rg[3 * n + 1] = Qy; Rg[3 * n + 2] = Qz; }
+                    }
+                    if (acc) { E = uniform_d(E + (Un - Um)); jacc++; }
                 }
-                if (acc) { E += Un - Um; jacc++; }
 
                 if (hasB) { // next particle's Um,Fm = B sums + the (n, n+1) pair term
-                    Um = 4.0 * (tot[4] + (acc ? sNew[0] : sOld[0]));
-                    Fmx = tot[5] + (acc ? sNew[1] : sOld[1]);
-                    Fmy = tot[6] + (acc ? sNew[2] : sOld[2]);
-                    Fmz = tot[7] + (acc ? sNew[3] : sOld[3]);
+                    Um = uniform_d(4.0 * (tot[4] + (acc ? sNew[0] : sOld[0])));
+                    Fmx = uniform_d(tot[5] + (acc ? sNew[1] : sOld[1]));
+                    Fmy = uniform_d(tot[6] + (acc ? sNew[2] : sOld[2]));
+                    Fmz = uniform_d(tot[7] + (acc ? sNew[3] : sOld[3]));
                     Px = Bx; Py = By; Pz = Bz;
                     if (cross) {
                         rotate1<S>(x, y, z);
                         rot = (rot + 1 == S) ? 0 : rot + 1;
-                        ks++; tl = 0;
+                        tl = 0;
                     } else {
                         tl++;
                     }
                 }
             }
         }
-
-        // ---- C: chain bookkeeping, SMC.c:116-117 / 194-195 / 210-211 ---------------
+        // C: hand E[n+1] and jj[n] (SMC.c:194-195) to the bookkeeping kernel
         if (tid == 0) {
-            ObsRec &ob = c.obs[rep];
-            if (production) {
-                const double e = E + c.c3NT2;
-                ob.sumE += e; ob.sumE2 += e * e; ob.nsamp += 1.0;
-                ob.accepted += (double)jacc;
-                if (c.Eseries) {
-                    const size_t o = (size_t)rep * c.series_stride + sweep_base + sw;
-                    c.Eseries[o + 1] = E;
-                    c.jjseries[o] = jacc;
-                }
-            } else {
-                ob.therm_accepted += (double)jacc;
-            }
+            SweepRec r; r.E = E; r.accepted = jacc; r.pad = 0;
+            a.rec[(size_t)rep * a.chunk + sw] = r;
         }
     }
 
-    // ---- write state back ---------------------------------------------------------
+    // ---- positions back to memory (with several waves they were written through) ----
     if constexpr (WPR == 1) {
 #pragma unroll
         for (int k = 0; k < S; k++) {
@@ -346,14 +325,69 @@ sweep_kernel(DevCtx c, int nsweeps, double A, int production, int gather_lapse, 
             if (l < N) { Rg[3 * l] = x[k]; Rg[3 * l + 1] = y[k]; Rg[3 * l + 2] = z[k]; }
         }
     }
+}
+
+// ---------------------------------------------------------------------------------
+// C: chain bookkeeping of sMC for the sweeps of one launch, in sweep order
+// (SMC.c:116-117, 194-195, 210-211, 244-250); one thread per replica
+// ---------------------------------------------------------------------------------
+__global__ void finalize_kernel(DevCtx c, int nsweeps, int production, int sweep_base, int first_production)
+{
+    const int rep = blockIdx.x * blockDim.x + threadIdx.x;
+    if (rep >= c.nrep) return;
+    ObsRec ob = c.obs[rep];
+    if (production && first_production) { // entry 0 of the energy series, SMC.c:48 / 194
+        const double e0 = ob.Ecur + c.c3NT2;
+        ob.sumE = e0; ob.sumE2 = e0 * e0; ob.nsamp = 1.0;
+        if (c.Eseries) c.Eseries[(size_t)rep * c.series_stride] = ob.Ecur;
+    }
+    for (int sw = 0; sw < nsweeps; sw++) {
+        const SweepRec r = c.rec[(size_t)rep * c.chunk + sw];
+        ob.Ecur = r.E;
+        if (production) {
+            const double e = r.E + c.c3NT2;
+            ob.sumE += e; ob.sumE2 += e * e; ob.nsamp += 1.0;
+            ob.accepted += (double)r.accepted;
+            if (c.Eseries) {
+                const size_t o = (size_t)rep * c.series_stride + sweep_base + sw;
+                c.Eseries[o + 1] = r.E;
+                c.jjseries[o] = r.accepted;
+            }
+        } else {
+            ob.therm_accepted += (double)r.accepted;
+        }
+    }
+    c.obs[rep] = ob;
+}
+
+// ---------------------------------------------------------------------------------
+// H: localDensityAndMobility's cell counts, summed over x,y (SMC.c:912-927), taken from
+// the positions in memory between two sweep launches; 256 threads per replica
+// ---------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) hist_kernel(DevCtx c)
+{
+    __shared__ unsigned zh[256];
+    __shared__ unsigned oob;
+    const int rep = blockIdx.x, tid = threadIdx.x;
+    zh[tid] = 0u;
+    if (tid == 0) oob = 0u;
     __syncthreads();
-    for (int i = tid; i < c.Ncz; i += T)
-        if (sh.zh[i]) c.zhist[(size_t)rep * c.Ncz + i] += sh.zh[i];
+    const double *Rg = c.R + (size_t)rep * 3 * c.N;
+    const int Nc = c.Ncx * c.Ncx * c.Ncz;
+    for (int l = tid; l < c.N; l += 256) {
+        // floor() through uint8_t as the reference does (SMC.c:914-919)
+        const int ci = (int)floor((Rg[3 * l] / c.L + .5) * c.Ncx) & 0xff;
+        const int cj = (int)floor((Rg[3 * l + 1] / c.L + .5) * c.Ncx) & 0xff;
+        const int ck = (int)floor((Rg[3 * l + 2] / c.Lz + .5) * c.Ncz) & 0xff;
+        const int cell = ci * c.Ncx * c.Ncz + cj * c.Ncz + ck;
+        if (cell < Nc) atomicAdd(&zh[cell % c.Ncz], 1u);
+        else atomicAdd(&oob, 1u); // the reference writes out of bounds here
+    }
+    __syncthreads();
+    if (tid < c.Ncz && zh[tid]) c.zhist[(size_t)rep * c.Ncz + tid] += zh[tid];
     if (tid == 0) {
-        ObsRec &ob = c.obs[rep];
-        ob.Ecur = E;
-        ob.gathers += (double)gathers;
-        ob.oob += (double)sh.oob;
+        c.obs[rep].gathers += 1.0;
+        c.obs[rep].oob += (double)oob;
     }
 }
 
@@ -429,7 +463,7 @@ eval_moves_kernel(DevCtx c, const int *nsel, const double *prop, double *out)
         pair_eval(g, Qx, Qy, Qz, xl, yl, zl, l != n, v[0], v[1], v[2], v[3]);
         pair_eval(g, Px, Py, Pz, xl, yl, zl, l != n, v[4], v[5], v[6], v[7]);
     }
-    special_block(c, g, rt, lane, rt.role[lane], true, true, false, Px, Py, Pz, Qx, Qy, Qz, Px, Py, Pz,
+    special_block(g, rt, lane, rt.role[lane], true, true, false, Px, Py, Pz, Qx, Qy, Qz, Px, Py, Pz,
                   v, side);
     const double r = reduce8(v, lane);
     double tot[8];
@@ -468,7 +502,7 @@ __global__ void pack_obs_kernel(DevCtx c, double *dst)
 // ---------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------
-typedef void (*sweep_fn)(DevCtx, int, double, int, int, int, int);
+typedef void (*sweep_fn)(SweepArgs, DevCtx, int, double);
 
 // MINW (second __launch_bounds__ argument, waves per SIMD) caps the register
 // allocation: 96 VGPRs of positions at S=16 fit 3 waves/SIMD, S=32 fits 2, S=64 one.
@@ -477,9 +511,9 @@ static sweep_fn lookup(int S, int WPR)
 #define SMCX_CASE(s, w, m) if (S == s && WPR == w) return sweep_kernel<s, w, m>;
     SMCX_CASE(1, 1, 4) SMCX_CASE(2, 1, 4) SMCX_CASE(4, 1, 4) SMCX_CASE(8, 1, 4)
     SMCX_CASE(16, 1, 3) SMCX_CASE(32, 1, 2) SMCX_CASE(64, 1, 1)
-    SMCX_CASE(16, 2, 3) SMCX_CASE(32, 2, 2)
-    SMCX_CASE(16, 4, 3) SMCX_CASE(32, 4, 2)
-    SMCX_CASE(16, 8, 3) SMCX_CASE(32, 8, 2)
+    SMCX_CASE(8, 2, 4) SMCX_CASE(16, 2, 3) SMCX_CASE(32, 2, 2)
+    SMCX_CASE(4, 4, 4) SMCX_CASE(8, 4, 4) SMCX_CASE(16, 4, 3) SMCX_CASE(32, 4, 2)
+    SMCX_CASE(8, 8, 4) SMCX_CASE(16, 8, 3) SMCX_CASE(32, 8, 2)
     SMCX_CASE(16, 16, 4) SMCX_CASE(32, 16, 2)
 #undef SMCX_CASE
     return nullptr;
@@ -493,13 +527,29 @@ hipError_t launch_rng_prepass(const DevCtx &c, int nsweeps, double A, hipStream_
     return hipGetLastError();
 }
 
-hipError_t launch_sweeps(const DevCtx &c, int S, int WPR, int nsweeps, double A, int production,
-                         int gather_lapse, int sweep_base, int first_production, hipStream_t st)
+hipError_t launch_sweeps(const DevCtx &c, int S, int WPR, int nsweeps, double A, hipStream_t st)
 {
     sweep_fn f = lookup(S, WPR);
     if (!f) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(f, dim3(c.nrep), dim3(64 * WPR), 0, st, c, nsweeps, A, production,
-                       gather_lapse, sweep_base, first_production);
+    SweepArgs a;
+    a.N = c.N; a.chunk = c.chunk;
+    a.L = c.L; a.invL = c.invL; a.cutoff2 = c.cutoff2; a.invT = c.invT;
+    a.R = c.R; a.displ = c.displ; a.uni = c.uni; a.offs = c.offs; a.obs = c.obs; a.rec = c.rec;
+    hipLaunchKernelGGL(f, dim3(c.nrep), dim3(64 * WPR), 0, st, a, c, nsweeps, A);
+    return hipGetLastError();
+}
+
+hipError_t launch_finalize(const DevCtx &c, int nsweeps, int production, int sweep_base,
+                           int first_production, hipStream_t st)
+{
+    hipLaunchKernelGGL(finalize_kernel, dim3((c.nrep + 127) / 128), dim3(128), 0, st, c, nsweeps,
+                       production, sweep_base, first_production);
+    return hipGetLastError();
+}
+
+hipError_t launch_hist(const DevCtx &c, hipStream_t st)
+{
+    hipLaunchKernelGGL(hist_kernel, dim3(c.nrep), dim3(256), 0, st, c);
     return hipGetLastError();
 }
 
