@@ -178,19 +178,27 @@ struct Geo {                      // wave-uniform constants of the pair loop
 };
 
 // one pair evaluation: probe p against neighbour (x,y,z); d = probe - neighbour,
-// minimum image in x,y only (SMC.c:567-573, 601-607)
+// minimum image in x,y only (SMC.c:567-573, 601-607).
+// Both coordinates are kept wrapped into [-L/2, L/2] (SMC.c:315-316, 461), so
+// |d - L rint(d/L)| = min(|d|, L - |d|): two instructions per axis for the cutoff
+// test, which almost every pair fails; the signed minimum image is formed only
+// inside the cutoff.
 __device__ __forceinline__ void pair_eval(const Geo &g, double px, double py, double pz, double x,
                                           double y, double z, bool ok, double &e, double &fx,
                                           double &fy, double &fz)
 {
-    double dx = px - x;
-    dx = dx - g.L * __builtin_rint(dx * g.invL);
-    double dy = py - y;
-    dy = dy - g.L * __builtin_rint(dy * g.invL);
+    const double dx = px - x;
+    const double dy = py - y;
     const double dz = pz - z;
-    const double dr2 = dx * dx + dy * dy + dz * dz;
-    if (dr2 < g.cutoff2 && ok)
-        lj_acc(dx, dy, dz, dr2, 1.0, 1.0, e, fx, fy, fz);
+    const double mx = fmin(fabs(dx), g.L - fabs(dx));
+    const double my = fmin(fabs(dy), g.L - fabs(dy));
+    const double q = mx * mx + my * my + dz * dz;
+    if (q < g.cutoff2 && ok) {
+        const double sx = dx - g.L * __builtin_rint(dx * g.invL);
+        const double sy = dy - g.L * __builtin_rint(dy * g.invL);
+        const double dr2 = sx * sx + sy * sy + dz * dz;
+        lj_acc(sx, sy, dz, dr2, 1.0, 1.0, e, fx, fy, fz);
+    }
 }
 
 // Fused pass over the register-resident neighbours: probe A (proposed position

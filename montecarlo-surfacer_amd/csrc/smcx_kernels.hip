@@ -109,10 +109,7 @@ __device__ __forceinline__ void combine(SweepShared<WPR> &sh, int &par, int lane
 #pragma unroll
         for (int j = 0; j < 8; j++) tot[j] = rdlane(r, 8 * j);
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            sOld[j] = rdlane(side[j], SIDE_LANE_OLD);
-            sNew[j] = rdlane(side[j], SIDE_LANE_NEW);
-        }
+        for (int j = 0; j < 4; j++) { sOld[j] = side[j]; sNew[j] = side[j]; } // read by lane later
     } else {
         if ((lane & 7) == 0) sh.red[par][wave][lane >> 3] = r;
         if (wave == 0 && (lane == SIDE_LANE_OLD || lane == SIDE_LANE_NEW)) {
@@ -130,10 +127,7 @@ __device__ __forceinline__ void combine(SweepShared<WPR> &sh, int &par, int lane
 #pragma unroll
         for (int j = 0; j < 8; j++) tot[j] = rdlane(t, j);
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            sOld[j] = uniform_d(sh.side[par][0][j]);
-            sNew[j] = uniform_d(sh.side[par][1][j]);
-        }
+        for (int j = 0; j < 4; j++) { sOld[j] = sh.side[par][0][j]; sNew[j] = sh.side[par][1][j]; }
         par ^= 1;
     }
 }
@@ -294,10 +288,19 @@ sweep_kernel(SweepArgs a, DevCtx c, int nsweeps, double A)
                 }
 
                 if (hasB) { // next particle's Um,Fm = B sums + the (n, n+1) pair term
-                    Um = uniform_d(4.0 * (tot[4] + (acc ? sNew[0] : sOld[0])));
-                    Fmx = uniform_d(tot[5] + (acc ? sNew[1] : sOld[1]));
-                    Fmy = uniform_d(tot[6] + (acc ? sNew[2] : sOld[2]));
-                    Fmz = uniform_d(tot[7] + (acc ? sNew[3] : sOld[3]));
+                    double s0, s1, s2, s3;
+                    if constexpr (WPR == 1) { // the term sits in lane 30 (old) or 31 (new) of this wave
+                        const int src = acc ? SIDE_LANE_NEW : SIDE_LANE_OLD;
+                        s0 = rdlane(sOld[0], src); s1 = rdlane(sOld[1], src);
+                        s2 = rdlane(sOld[2], src); s3 = rdlane(sOld[3], src);
+                    } else {
+                        s0 = acc ? sNew[0] : sOld[0]; s1 = acc ? sNew[1] : sOld[1];
+                        s2 = acc ? sNew[2] : sOld[2]; s3 = acc ? sNew[3] : sOld[3];
+                    }
+                    Um = uniform_d(4.0 * (tot[4] + s0));
+                    Fmx = uniform_d(tot[5] + s1);
+                    Fmy = uniform_d(tot[6] + s2);
+                    Fmz = uniform_d(tot[7] + s3);
                     Px = Bx; Py = By; Pz = Bz;
                     if (cross) {
                         rotate1<S>(x, y, z);
