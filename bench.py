@@ -161,7 +161,7 @@ def main():
                 tj = json.load(open(tpath))
                 key = "N%d_R%d_S%d_W%d" % (N, nrep, S_, W_)
                 if key in tj:
-                    traffic = tj[key]["hbm_bytes_per_sweep"] * (a.steps / max(launches, 1))
+                    traffic = tj[key]["hbm_bytes_per_sweep"] * (a.steps / max(launches, 1))  # per launch
             except Exception:
                 traffic = None
         out = {

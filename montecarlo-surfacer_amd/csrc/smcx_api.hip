@@ -154,10 +154,8 @@ static int validate(const smcx_params *p)
     return SMCX_OK;
 }
 
-// particles per lane (S) and wavefronts per replica (WPR).  Up to N = 1024 one wavefront
-// holds a replica (S = N/64 rounded up to a power of two); beyond that S stays 16 -- 96
-// VGPRs of positions, three waves per SIMD -- and the replica is spread over N/1024
-// wavefronts (measured fastest at N = 4096 on MI355X: profiles/r01_geometry_N4096.log).
+// particles per lane (S) and wavefronts per replica (WPR): the smallest capacity 64*WPR*S
+// that holds N from a table of the geometries measured fastest on MI355X.
 static int choose_geometry(const smcx_params *p, int *S, int *WPR)
 {
     if (p->tune_slots > 0 || p->tune_waves > 0) {
@@ -167,8 +165,9 @@ static int choose_geometry(const smcx_params *p, int *S, int *WPR)
         *S = s; *WPR = w;
         return SMCX_OK;
     }
-    static const int cand[][2] = {{1, 1}, {2, 1}, {4, 1}, {8, 1}, {16, 1}, {16, 2}, {16, 4},
-                                  {16, 8}, {16, 16}, {32, 16}};
+    // measured on MI355X (profiles/r01_geometry_N*.log): N=1024 -> 8x2, 4096 -> 16x4, 16384 -> 32x8
+    static const int cand[][2] = {{1, 1}, {2, 1}, {4, 1}, {8, 1}, {8, 2}, {16, 2}, {16, 4},
+                                  {32, 4}, {32, 8}, {32, 16}};
     for (auto &g : cand) {
         if ((long)g[0] * g[1] * 64 >= p->N && geometry_supported(g[0], g[1])) {
             *S = g[0]; *WPR = g[1];
