@@ -53,7 +53,7 @@ struct DevCtx {
     uint32_t *rng;                // [nrep][32]
     uint32_t *raw;                // [nrep][rawStride] raw rand() outputs of one sweep (pre-pass scratch)
     double *displ;                // [nrep][chunk][3N] Gaussian displacements, one block per sweep
-    double *uni;                  // [nrep][chunk][N] acceptance uniforms
+    double *uni;                  // [nrep][chunk][N] log of the acceptance uniforms
     int *offs;                    // [nrep][chunk] first particle of each sweep (offset % N)
     int chunk;                    // sweeps of random numbers held by the scratch buffers
     ObsRec *obs;                  // [nrep]
@@ -162,7 +162,11 @@ __device__ __forceinline__ double sum_x8(double t) { return t + dpp_mov<DPP_ROR8
 __device__ __forceinline__ void lj_acc(double dx, double dy, double dz, double dr2, double ca,
                                        double cb, double &e, double &fx, double &fy, double &fz)
 {
-    const double ir2 = 1.0 / dr2;
+    // 1/dr2: hardware reciprocal seed + two Newton steps (<= 2 ulp; the IEEE division
+    // sequence costs three times as many instructions for the last half ulp)
+    double ir2 = __builtin_amdgcn_rcp(dr2);
+    ir2 = fma(fma(-dr2, ir2, 1.0), ir2, ir2);
+    ir2 = fma(fma(-dr2, ir2, 1.0), ir2, ir2);
     const double ir6 = ir2 * ir2 * ir2;
     const double t = ca * ir6 * ir6;
     const double s = cb * ir6;

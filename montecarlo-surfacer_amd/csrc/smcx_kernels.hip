@@ -55,8 +55,11 @@ rng_prepass_kernel(DevCtx c, int nsweeps, double A)
             displ[2 * p] = sigma * sqrt(-2.0 * log(1.0 - x1)) * cos(2.0 * M_PI * x2);
             displ[2 * p + 1] = sigma * sqrt(-2.0 * log(1.0 - x2)) * sin(2.0 * M_PI * x1);
         }
-        for (int i = tid; i < N; i += 256) // acceptance uniforms, SMC.c:335
-            uni[i] = (double)raw[3 * N + 1 + i] / 2147483647.0;
+        // acceptance uniforms u = rand()/RAND_MAX (SMC.c:335), stored as log(u): the test
+        // u < exp(-x/T) of SMC.c:329-335 is evaluated as log(u) < -x/T, which keeps the
+        // exponential out of the sequential part of every move (u = 0 -> -inf: always accepted)
+        for (int i = tid; i < N; i += 256)
+            uni[i] = log((double)raw[3 * N + 1 + i] / 2147483647.0);
         if (tid == 0) // SMC.c:290-294: the sweep starts at particle offset % N
             c.offs[(size_t)rep * c.chunk + s] = (int)(raw[3 * N] % (uint32_t)N);
         __syncthreads();
@@ -274,10 +277,8 @@ sweep_kernel(SweepArgs a, DevCtx c, int nsweeps, double A)
                                            2.0 * (gx * Fmx + gy * Fmy + gz * Fmz)) * Ao4T;
                     const double arg = Un - Um +
                                        (dX * (Fnx + Fmx) + dY * (Fny + Fmy) + dZ * (Fnz + Fmz)) * 0.5 + deltaW;
-                    const double u = rdlane(bu, j);
-                    // u <= 1 < exp(-arg/T) whenever arg < 0: the exponential is only needed uphill
-                    acc = true;
-                    if (!(arg < 0.0)) acc = (u < exp(-arg * a.invT));
+                    const double lu = rdlane(bu, j); // log(u), see rng_prepass_kernel
+                    acc = (lu < -arg * a.invT);      // u < exp(-arg/T); NaN rejects (SMC.c:335)
                     acc = (uniform((int)acc) != 0);
                     const bool upd = acc && (tid == tl);
                     x[0] = upd ? Qx : x[0]; y[0] = upd ? Qy : y[0]; z[0] = upd ? Qz : z[0];
