@@ -165,7 +165,20 @@ static int choose_geometry(const smcx_params *p, int *S, int *WPR)
         *S = s; *WPR = w;
         return SMCX_OK;
     }
-    // measured on MI355X (profiles/r01_geometry_N*.log): N=1024 -> 8x2, 4096 -> 16x4, 16384 -> 32x8
+    // Rule fitted to measurements on MI355X (profiles/r01_geometry_N*.log): 16 particles per
+    // lane (96 VGPRs of positions, 3 waves per SIMD) and N/1024 wavefronts per replica; 32 per
+    // lane once that would need more than 8 wavefronts (a 1024-thread workgroup is capped at
+    // 128 VGPRs); with few replicas, halve S and double the wavefronts until the chip has
+    // about two waves per SIMD to work on.
+    auto pow2_at_least = [](long v) { int r = 1; while (r < v) r *= 2; return r; };
+    int s, w;
+    if (p->N <= 1024) { s = pow2_at_least((p->N + 63) / 64); w = 1; }
+    else {
+        s = 16; w = pow2_at_least((p->N + 1023) / 1024);
+        if (w > 8) { s = 32; w = pow2_at_least((p->N + 2047) / 2048); }
+    }
+    while ((long)p->nrep * w < 2048 && s > 4 && w < 8 && geometry_supported(s / 2, w * 2)) { s /= 2; w *= 2; }
+    if (geometry_supported(s, w) && (long)s * w * 64 >= p->N) { *S = s; *WPR = w; return SMCX_OK; }
     static const int cand[][2] = {{1, 1}, {2, 1}, {4, 1}, {8, 1}, {8, 2}, {16, 2}, {16, 4},
                                   {32, 4}, {32, 8}, {32, 16}};
     for (auto &g : cand) {

@@ -133,16 +133,15 @@ constexpr int DPP_QUAD_X1 = 0xB1;      // quad_perm:[1,0,3,2]  lane ^ 1
 // 4 + 2 + 1 exchanges for the top three levels, 3 for the rest, 34 VALU instructions
 // in all and no LDS.  On return every lane of lane-group g = lane>>3 holds the wave
 // total of v[g].
-__device__ __forceinline__ double reduce8(const double (&v)[8], int lane)
+__device__ __forceinline__ double reduce8(double v0, double v1, double v2, double v3, double v4,
+                                          double v5, double v6, double v7, int lane)
 {
-    double w[4], u[2];
-#pragma unroll
-    for (int i = 0; i < 4; i++) w[i] = sum_swap32(v[i], v[4 + i]); // low half: v[i], high: v[4+i]
-#pragma unroll
-    for (int i = 0; i < 2; i++) u[i] = sum_swap16(w[i], w[2 + i]); // rows: v[i], v[2+i], v[4+i], v[6+i]
+    const double w0 = sum_swap32(v0, v4), w1 = sum_swap32(v1, v5); // low half: v[i], high: v[4+i]
+    const double w2 = sum_swap32(v2, v6), w3 = sum_swap32(v3, v7);
+    const double u0 = sum_swap16(w0, w2), u1 = sum_swap16(w1, w3); // rows: v[i], v[2+i], v[4+i], v[6+i]
     const bool b3 = lane & 8;
-    const double keep = b3 ? u[1] : u[0];
-    const double send = b3 ? u[0] : u[1];
+    const double keep = b3 ? u1 : u0;
+    const double send = b3 ? u0 : u1;
     double r = keep + dpp_mov<DPP_ROR8>(send);                     // 8-lane groups: v[lane>>3]
     r += dpp_mov<DPP_HALF_MIRROR>(r);
     r += dpp_mov<DPP_QUAD_X2>(r);
@@ -176,6 +175,13 @@ __device__ __forceinline__ void lj_acc(double dx, double dy, double dz, double d
     fy += f * dy;
     fz += f * dz;
 }
+
+// the eight per-lane partial sums of a move: probe A (e, fx, fy, fz) and probe B.
+// Named scalars, not an array: an array is kept as one 16-register tuple and copied
+// wholesale around every conditional update.
+struct Acc8 {
+    double a0, a1, a2, a3, b0, b1, b2, b3;
+};
 
 struct Geo {                      // wave-uniform constants of the pair loop
     double L, invL, cutoff2;
@@ -213,14 +219,14 @@ template <int S>
 __device__ __forceinline__ void fused_pass(const Geo &g, const double (&x)[S], const double (&y)[S],
                                            const double (&z)[S], double ax, double ay, double az,
                                            double bx, double by, double bz, bool exA0, bool exB0,
-                                           bool exB1, double (&v)[8])
+                                           bool exB1, Acc8 &v)
 {
 #pragma unroll
     for (int k = 0; k < S; k++) {
         const bool okA = (k == 0) ? !exA0 : true;
         const bool okB = (k == 0) ? !exB0 : ((k == 1) ? !exB1 : true);
-        pair_eval(g, ax, ay, az, x[k], y[k], z[k], okA, v[0], v[1], v[2], v[3]);
-        pair_eval(g, bx, by, bz, x[k], y[k], z[k], okB, v[4], v[5], v[6], v[7]);
+        pair_eval(g, ax, ay, az, x[k], y[k], z[k], okA, v.a0, v.a1, v.a2, v.a3);
+        pair_eval(g, bx, by, bz, x[k], y[k], z[k], okB, v.b0, v.b1, v.b2, v.b3);
     }
 }
 
@@ -284,7 +290,7 @@ __device__ __forceinline__ void special_block(const Geo &g, const RoleTable &rt,
                                               int lane, int role, bool hasA, bool hasB, bool sides,
                                               double Px, double Py, double Pz, double Ax, double Ay,
                                               double Az, double Bx, double By, double Bz,
-                                              double (&v)[8], double (&side)[4])
+                                              Acc8 &v, double (&side)[4])
 {
     side[0] = side[1] = side[2] = side[3] = 0.0;
     bool active = false;
@@ -311,8 +317,8 @@ __device__ __forceinline__ void special_block(const Geo &g, const RoleTable &rt,
         double e = 0.0, fx = 0.0, fy = 0.0, fz = 0.0;
         if (plane || dr2 < g.cutoff2)
             lj_acc(dx, dy, dz, dr2, rt.ca[lane], rt.cb[lane], e, fx, fy, fz);
-        if (wallrole && onA) { v[0] += e; v[1] += fx; v[2] += fy; v[3] += fz; }
-        else if (wallrole) { v[4] += e; v[5] += fx; v[6] += fy; v[7] += fz; }
+        if (wallrole && onA) { v.a0 += e; v.a1 += fx; v.a2 += fy; v.a3 += fz; }
+        else if (wallrole) { v.b0 += e; v.b1 += fx; v.b2 += fy; v.b3 += fz; }
         else { side[0] = e; side[1] = fx; side[2] = fy; side[3] = fz; }
     }
 }

@@ -104,10 +104,10 @@ template <int WPR> struct SweepShared {
 // tot[8], identical in every lane of the workgroup; also fetches the two side terms
 template <int WPR>
 __device__ __forceinline__ void combine(SweepShared<WPR> &sh, int &par, int lane, int wave,
-                                        const double (&v)[8], const double (&side)[4],
+                                        const Acc8 &v, const double (&side)[4],
                                         double (&tot)[8], double (&sOld)[4], double (&sNew)[4])
 {
-    const double r = reduce8(v, lane);
+    const double r = reduce8(v.a0, v.a1, v.a2, v.a3, v.b0, v.b1, v.b2, v.b3, lane);
     if constexpr (WPR == 1) {
 #pragma unroll
         for (int j = 0; j < 8; j++) tot[j] = rdlane(r, 8 * j);
@@ -254,7 +254,8 @@ sweep_kernel(SweepArgs a, DevCtx c, int nsweeps, double A)
                     }
                 }
 
-                double v[8] = {0, 0, 0, 0, 0, 0, 0, 0}, side[4], tot[8], sOld[4], sNew[4];
+                Acc8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+                double side[4], tot[8], sOld[4], sNew[4];
                 const bool exA0 = (tid == tl);
                 const bool exB0 = (hasA && tid == tl) || (hasB && !cross && tid == tl + 1);
                 const bool exB1 = cross && (tid == 0);
@@ -461,15 +462,16 @@ eval_moves_kernel(DevCtx c, const int *nsel, const double *prop, double *out)
     Geo g; g.L = c.L; g.invL = c.invL; g.cutoff2 = c.cutoff2;
     fill_roles(c, rt, lane);
     __syncthreads();
-    double v[8] = {0, 0, 0, 0, 0, 0, 0, 0}, side[4];
+    Acc8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+    double side[4];
     for (int l = lane; l < N; l += 64) {
         const double xl = Rg[3 * l], yl = Rg[3 * l + 1], zl = Rg[3 * l + 2];
-        pair_eval(g, Qx, Qy, Qz, xl, yl, zl, l != n, v[0], v[1], v[2], v[3]);
-        pair_eval(g, Px, Py, Pz, xl, yl, zl, l != n, v[4], v[5], v[6], v[7]);
+        pair_eval(g, Qx, Qy, Qz, xl, yl, zl, l != n, v.a0, v.a1, v.a2, v.a3);
+        pair_eval(g, Px, Py, Pz, xl, yl, zl, l != n, v.b0, v.b1, v.b2, v.b3);
     }
     special_block(g, rt, lane, rt.role[lane], true, true, false, Px, Py, Pz, Qx, Qy, Qz, Px, Py, Pz,
                   v, side);
-    const double r = reduce8(v, lane);
+    const double r = reduce8(v.a0, v.a1, v.a2, v.a3, v.b0, v.b1, v.b2, v.b3, lane);
     double tot[8];
 #pragma unroll
     for (int j = 0; j < 8; j++) tot[j] = rdlane(r, 8 * j);
