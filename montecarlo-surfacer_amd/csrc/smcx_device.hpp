@@ -211,22 +211,66 @@ __device__ __forceinline__ void pair_eval(const Geo &g, double px, double py, do
     }
 }
 
+// squared minimum-image distance for the cutoff test (see pair_eval)
+__device__ __forceinline__ double pair_q(const Geo &g, double px, double py, double pz, double x,
+                                         double y, double z)
+{
+    const double dx = px - x, dy = py - y, dz = pz - z;
+    const double mx = fmin(fabs(dx), g.L - fabs(dx));
+    const double my = fmin(fabs(dy), g.L - fabs(dy));
+    return mx * mx + my * my + dz * dz;
+}
+
+// the rare part of a pair evaluation: the pair is inside the cutoff
+__device__ __forceinline__ void pair_hit(const Geo &g, double px, double py, double pz, double x,
+                                         double y, double z, double &e, double &fx, double &fy,
+                                         double &fz)
+{
+    const double dx = px - x, dy = py - y, dz = pz - z;
+    const double sx = dx - g.L * __builtin_rint(dx * g.invL);
+    const double sy = dy - g.L * __builtin_rint(dy * g.invL);
+    const double dr2 = sx * sx + sy * sy + dz * dz;
+    lj_acc(sx, sy, dz, dr2, 1.0, 1.0, e, fx, fy, fz);
+}
+
 // Fused pass over the register-resident neighbours: probe A (proposed position
-// of the moving particle n) accumulates into v[0..3], probe B (current position
-// of the next particle) into v[4..7].  exA0/exB0 mask this lane's slot-0
+// of the moving particle n) accumulates into v.a*, probe B (current position
+// of the next particle) into v.b*.  exA0/exB0 mask this lane's slot-0
 // particle, exB1 its slot-1 particle (n and n+1 are always there, see kernel).
+// The cutoff test is done for G slots x 2 probes at a time and followed by ONE
+// branch: straight-line blocks of 22*G fp64 instructions with 2*G independent
+// dependency chains, instead of a branch after every 11 instructions.
 template <int S>
 __device__ __forceinline__ void fused_pass(const Geo &g, const double (&x)[S], const double (&y)[S],
                                            const double (&z)[S], double ax, double ay, double az,
                                            double bx, double by, double bz, bool exA0, bool exB0,
                                            bool exB1, Acc8 &v)
 {
+#ifndef SMCX_G
+#define SMCX_G 4
+#endif
+    constexpr int G = (S >= SMCX_G) ? SMCX_G : S;
 #pragma unroll
-    for (int k = 0; k < S; k++) {
-        const bool okA = (k == 0) ? !exA0 : true;
-        const bool okB = (k == 0) ? !exB0 : ((k == 1) ? !exB1 : true);
-        pair_eval(g, ax, ay, az, x[k], y[k], z[k], okA, v.a0, v.a1, v.a2, v.a3);
-        pair_eval(g, bx, by, bz, x[k], y[k], z[k], okB, v.b0, v.b1, v.b2, v.b3);
+    for (int k0 = 0; k0 < S; k0 += G) {
+        bool ha[G], hb[G];
+        bool any = false;
+#pragma unroll
+        for (int j = 0; j < G; j++) {
+            const int k = k0 + j;
+            const bool okA = (k == 0) ? !exA0 : true;
+            const bool okB = (k == 0) ? !exB0 : ((k == 1) ? !exB1 : true);
+            ha[j] = (pair_q(g, ax, ay, az, x[k], y[k], z[k]) < g.cutoff2) && okA;
+            hb[j] = (pair_q(g, bx, by, bz, x[k], y[k], z[k]) < g.cutoff2) && okB;
+            any = any || ha[j] || hb[j];
+        }
+        if (any) {
+#pragma unroll
+            for (int j = 0; j < G; j++) {
+                const int k = k0 + j;
+                if (ha[j]) pair_hit(g, ax, ay, az, x[k], y[k], z[k], v.a0, v.a1, v.a2, v.a3);
+                if (hb[j]) pair_hit(g, bx, by, bz, x[k], y[k], z[k], v.b0, v.b1, v.b2, v.b3);
+            }
+        }
     }
 }
 
