@@ -84,7 +84,9 @@ const char *smcx_strerror(int status);
 /* text of the last HIP error seen by this handle (h may be NULL: process-wide) */
 const char *smcx_last_error_string(const smcx_handle *h);
 
-/* Load initial state: R0 (shared [3N] if r0_per_replica==0, else [nrep][3N]),
+/* Load initial state: R0 (shared [3N] if r0_per_replica==0, else [nrep][3N]; x,y must lie
+ * in [-L/2, L/2] as initializeBox and the sweep itself leave them (SMC.c:315-316, 461), and
+ * |z| <= 4 Lz: SMCX_ERR_PARAM otherwise),
  * W[2*M*M] (may be NULL when walls are off), seeds[nrep] (NULL = base_seed
  * rule).  Seeds the RNG streams, zeroes observables and evaluates
  * E[0] = energy + wallsEnergy on the device (SMC.c:44-48). */

@@ -288,7 +288,7 @@ extern "C" int smcx_geometry(const smcx_handle *hh, int *slots, int *waves, int 
     if (!hh) return SMCX_ERR_PARAM;
     if (slots) *slots = hh->h.S;
     if (waves) *waves = hh->h.WPR;
-    if (lds_bytes) *lds_bytes = (int)(sizeof(RoleTable) + 2 * hh->h.WPR * 8 * 8 + 2 * 2 * 4 * 8 + 257 * 4);
+    if (lds_bytes) *lds_bytes = (int)(sizeof(RoleTable) + 2 * hh->h.WPR * 8 * 8 + 2 * 2 * 4 * 8);
     return SMCX_OK;
 }
 
@@ -302,6 +302,18 @@ extern "C" int smcx_upload(smcx_handle *hh, const double *R0, int r0_per_replica
     if ((p.flags & SMCX_FLAG_WALLS) && !W) return SMCX_ERR_PARAM;
     HIPCHK(&h, hipSetDevice(p.device));
     const size_t nrep = p.nrep, row = 3 * (size_t)p.N;
+    {   // the pair test relies on wrapped x,y (|d| <= L); z is only sanity-bounded
+        const size_t cnt = (r0_per_replica ? nrep : 1) * (size_t)p.N;
+        const double hx = p.L / 2 * (1 + 1e-12), hz = 4 * p.Lz;
+        for (size_t i = 0; i < cnt; i++) {
+            const double *q = R0 + 3 * i;
+            if (!(std::fabs(q[0]) <= hx) || !(std::fabs(q[1]) <= hx) || !(std::fabs(q[2]) <= hz)) {
+                h.err = "R0: x,y must be wrapped into [-L/2, L/2] and |z| <= 4 Lz";
+                g_last_error = h.err;
+                return SMCX_ERR_PARAM;
+            }
+        }
+    }
     if (r0_per_replica) {
         HIPCHK(&h, hipMemcpy(c.R, R0, nrep * row * sizeof(double), hipMemcpyHostToDevice));
     } else {

@@ -140,7 +140,7 @@ __device__ __forceinline__ void combine(SweepShared<WPR> &sh, int &par, int lane
 // the register-resident neighbours evaluates the proposal of particle n (probe A) and
 // the current position of particle n+1 (probe B); one 8-value reduction; the Metropolis
 // decision in scalar registers.  Wave-uniform values live in SGPRs (uniform_d).
-template <int S, int WPR, int MINW>
+template <int S, int WPR, int MINW, int G>
 __global__ void __launch_bounds__(64 * WPR, MINW)
 sweep_kernel(SweepArgs a, DevCtx c, int nsweeps, double A)
 {
@@ -259,7 +259,11 @@ sweep_kernel(SweepArgs a, DevCtx c, int nsweeps, double A)
                 const bool exA0 = (tid == tl);
                 const bool exB0 = (hasA && tid == tl) || (hasB && !cross && tid == tl + 1);
                 const bool exB1 = cross && (tid == 0);
-                fused_pass<S>(g, x, y, z, Qx, Qy, Qz, Bx, By, Bz, exA0, exB0, exB1, v);
+                // both probes at least one cutoff away from the periodic x,y edges?  (a disabled
+                // probe sits at x = y = 0)  Then no pair needs the minimum-image wrap.
+                const bool interior =
+                    uniform((int)(fmax(fmax(fabs(Qx), fabs(Qy)), fmax(fabs(Bx), fabs(By))) <= a.edge)) != 0;
+                fused_pass<S, G>(g, x, y, z, Qx, Qy, Qz, Bx, By, Bz, exA0, exB0, exB1, interior, v);
                 if (wave == 0)
                     special_block(g, sh.roles, lane, role, hasA, hasB, hasA, Px, Py, Pz, Qx, Qy, Qz,
                                   Bx, By, Bz, v, side);
@@ -512,15 +516,16 @@ typedef void (*sweep_fn)(SweepArgs, DevCtx, int, double);
 
 // MINW (second __launch_bounds__ argument, waves per SIMD) caps the register
 // allocation: 96 VGPRs of positions at S=16 fit 3 waves/SIMD, S=32 fits 2, S=64 one.
+// G = slots per cutoff-test group (more independent chains for the single-wave S=64).
 static sweep_fn lookup(int S, int WPR)
 {
-#define SMCX_CASE(s, w, m) if (S == s && WPR == w) return sweep_kernel<s, w, m>;
-    SMCX_CASE(1, 1, 4) SMCX_CASE(2, 1, 4) SMCX_CASE(4, 1, 4) SMCX_CASE(8, 1, 4)
-    SMCX_CASE(16, 1, 3) SMCX_CASE(32, 1, 2) SMCX_CASE(64, 1, 1)
-    SMCX_CASE(8, 2, 4) SMCX_CASE(16, 2, 3) SMCX_CASE(32, 2, 2)
-    SMCX_CASE(4, 4, 4) SMCX_CASE(8, 4, 4) SMCX_CASE(16, 4, 3) SMCX_CASE(32, 4, 2)
-    SMCX_CASE(8, 8, 4) SMCX_CASE(16, 8, 3) SMCX_CASE(32, 8, 2)
-    SMCX_CASE(16, 16, 4) SMCX_CASE(32, 16, 2)
+#define SMCX_CASE(s, w, m, gg) if (S == s && WPR == w) return sweep_kernel<s, w, m, gg>;
+    SMCX_CASE(1, 1, 4, 1) SMCX_CASE(2, 1, 4, 2) SMCX_CASE(4, 1, 4, 2) SMCX_CASE(8, 1, 4, 2)
+    SMCX_CASE(16, 1, 3, 2) SMCX_CASE(32, 1, 2, 2) SMCX_CASE(64, 1, 1, 2)
+    SMCX_CASE(8, 2, 4, 2) SMCX_CASE(16, 2, 3, 2) SMCX_CASE(32, 2, 2, 2)
+    SMCX_CASE(4, 4, 4, 2) SMCX_CASE(8, 4, 4, 2) SMCX_CASE(16, 4, 3, 2) SMCX_CASE(32, 4, 2, 2)
+    SMCX_CASE(8, 8, 4, 2) SMCX_CASE(16, 8, 3, 2) SMCX_CASE(32, 8, 2, 2)
+    SMCX_CASE(16, 16, 4, 2) SMCX_CASE(32, 16, 2, 2)
 #undef SMCX_CASE
     return nullptr;
 }
@@ -541,6 +546,7 @@ hipError_t launch_sweeps(const DevCtx &c, int S, int WPR, int nsweeps, double A,
     a.N = c.N; a.chunk = c.chunk;
     a.L = c.L; a.invL = c.invL; a.cutoff2 = c.cutoff2; a.invT = c.invT;
     a.R = c.R; a.displ = c.displ; a.uni = c.uni; a.offs = c.offs; a.obs = c.obs; a.rec = c.rec;
+    a.edge = c.L / 2 - sqrt(c.cutoff2); // |x|,|y| up to here: no pair needs the periodic image
     hipLaunchKernelGGL(f, dim3(c.nrep), dim3(64 * WPR), 0, st, a, c, nsweeps, A);
     return hipGetLastError();
 }
