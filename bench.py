@@ -104,10 +104,14 @@ def main():
     spec = importlib.util.spec_from_file_location("smcx_dist", os.path.join(ROOT, "montecarlo-surfacer_amd", "dist.py"))
     D = importlib.util.module_from_spec(spec); spec.loader.exec_module(D)
 
+    # rehearsal knobs (one-GPU box): SMCX_DIST_BACKEND=gloo, SMCX_FORCE_DEVICE=0
+    backend = os.environ.get("SMCX_DIST_BACKEND", "nccl")
+    if "SMCX_FORCE_DEVICE" in os.environ:
+        local_rank = int(os.environ["SMCX_FORCE_DEVICE"])
     if world > 1:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world)  # RCCL over xGMI
+        dist.init_process_group(backend, rank=rank, world_size=world)  # "nccl" = RCCL over xGMI
     lattice = {256: (4, 4), 1024: (8, 4), 4096: (8, 16), 16384: (16, 16)}[a.N]
     N, nrep = a.N, a.replicas
     first, _ = D.shard(nrep * world, rank, world)
@@ -137,12 +141,13 @@ def main():
     buf = torch.zeros(nbytes // 8, dtype=torch.float64, device="cuda:%d" % local_rank)
     eng.export_observables_device(buf.data_ptr(), nbytes)
     tg = time.perf_counter()
-    obs = D.gather_observables(buf, nrep, p.Ncz)
+    obs = D.gather_observables(buf if backend == "nccl" or world == 1 else buf.cpu(), nrep, p.Ncz)
     torch.cuda.synchronize()
     gather_ms = (time.perf_counter() - tg) * 1e3
     summ = D.summarise(obs, N, a.steps)
 
-    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda:%d" % local_rank)
+    tmax = torch.tensor([dt], dtype=torch.float64,
+                        device=("cuda:%d" % local_rank) if backend == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
@@ -175,8 +180,8 @@ def main():
                        "N": N, "replicas_per_gpu": nrep, "replicas_total": nrep * world,
                        "gather_lapse": gather_lapse,
                        "geometry": "S=%d particles/lane, %d wavefront(s)/replica" % (S_, W_),
-                       "parallelism": "replica-sharded x%d, no data-path collective; RCCL all-gather of "
-                                      "observables at the end (%.2f ms)" % (world, gather_ms)},
+                       "parallelism": "replica-sharded x%d, no data-path collective; %s all-gather of "
+                                      "observables at the end (%.2f ms)" % (world, "RCCL" if backend == "nccl" else backend, gather_ms)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "smcx::sweep_kernel<S=%d,WPR=%d>" % (S_, W_),

@@ -51,6 +51,9 @@ extern "C" {
                                      thermalisation energy, as SMC.c:116-117 vs 194 does */
 #define SMCX_FLAG_SERIES 0x4u     /* keep per-sweep E and accepted-count series (data_*.csv
                                      columns, SMC.c:214-215) for the last smcx_run */
+#define SMCX_FLAG_FULL_HIST 0x8u   /* keep the full Ncx x Ncx x Ncz density and mobility counters of
+                                     localDensityAndMobility (local_*.csv, SMC.c:218-225) */
+#define SMCX_FLAG_PRESSURE 0x10u   /* evaluate pressure + wallsPressure at every gather (SMC.c:140) */
 #define SMCX_FLAGS_REFERENCE (SMCX_FLAG_WALLS | SMCX_FLAG_E0_RESTART)
 
 typedef struct smcx_params {
@@ -118,6 +121,15 @@ int smcx_hist_info(smcx_handle *h, uint64_t *gathers, uint64_t *oob);
 /* per-sweep series of the last run (needs SMCX_FLAG_SERIES):
  * E_series[nrep][maxsteps+1] without 3NT/2, jj[nrep][maxsteps] */
 int smcx_series(smcx_handle *h, double *E_series, int32_t *jj);
+
+/* full cell counters of the last run (needs SMCX_FLAG_FULL_HIST): D and Mu of
+ * localDensityAndMobility (SMC.c:912-927), [nrep][Ncx*Ncx*Ncz] each, cell index
+ * i*Ncx*Ncz + j*Ncz + k; either may be NULL */
+int smcx_density(smcx_handle *h, uint64_t *D, uint64_t *Mu);
+/* pressure(R) + wallsPressure(R) of every gather of the last run, in gather order (needs
+ * SMCX_FLAG_PRESSURE): P[nrep][ngathers]; without the ideal-gas term rho*T the reference adds
+ * at SMC.c:207-208, and with wallsPressure's geometry as the reference has it (SMC.c:880) */
+int smcx_pressure_series(smcx_handle *h, double *P, int *ngathers);
 
 /* current positions, [nrep][3N] (struct Sim.Rfinal, SMC.h:84) */
 int smcx_download_positions(smcx_handle *h, double *R);

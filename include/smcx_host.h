@@ -64,6 +64,21 @@ int smcx_host_sMC(const smcx_params *p, const double *W, const double *R0, int m
                   int gather_lapse, int eqsteps, smcx_sim *out);
 void smcx_host_sim_free(smcx_sim *s);
 
+/* The reference's result files for the last smcx_run of `h`, one set per replica with
+ * the replica's global index as the `_rank` suffix (SMC.c:66-95 names them per MPI rank):
+ *   data_N%d_M%d_r%0.4f_T%0.2f_rank%d.csv    "E, P, jj"  one row per gather   (SMC.c:75-77, 214-215)
+ *   local_N..._rank%d.csv                     "nx, ny, nz, n, mu" all cells     (SMC.c:80-82, 218-225)
+ *   last_state_N%d_M%d_r%0.4f_T%0.2f[_rank%d].csv  3N positions, %0.12f,        (main.c:162-170)
+ * Rows follow the reference's indexing: E[k*gather_lapse] + 3NT/2, P[k] + rho*T with P[0] = 0
+ * and P[k] the k-th gather (SMC.c:138-140), jj[k] (sic).  The handle must have been created
+ * with SMCX_FLAG_SERIES | SMCX_FLAG_FULL_HIST (| SMCX_FLAG_PRESSURE, else the P column holds
+ * rho*T only).  Returns an smcx status; `dir` must exist. */
+int smcx_host_write_csv(smcx_handle *h, const smcx_params *p, int maxsteps, int gather_lapse,
+                        const char *dir);
+/* reads a last_state file written by the reference or by smcx_host_write_csv (main.c:98-108);
+ * returns the number of coordinates read */
+int smcx_host_read_last_state(const char *path, int N, double *R0);
+
 #ifdef __cplusplus
 }
 #endif

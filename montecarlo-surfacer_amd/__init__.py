@@ -18,7 +18,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsmcx.so")
 
 OK, ERR_PARAM, ERR_HIP, ERR_STATE, ERR_NOMEM, ERR_UNSUPPORTED, ERR_NODEVICE = range(7)
-FLAG_WALLS, FLAG_E0_RESTART, FLAG_SERIES = 1, 2, 4
+FLAG_WALLS, FLAG_E0_RESTART, FLAG_SERIES, FLAG_FULL_HIST, FLAG_PRESSURE = 1, 2, 4, 8, 16
 FLAGS_REFERENCE = FLAG_WALLS | FLAG_E0_RESTART
 OBS_RECORD_DOUBLES = 8
 
@@ -51,7 +51,8 @@ _i32p = C.POINTER(C.c_int32)
 EXPORTS = [
     "smcx_default_params", "smcx_device_count", "smcx_create", "smcx_destroy", "smcx_strerror",
     "smcx_last_error_string", "smcx_upload", "smcx_run", "smcx_observables",
-    "smcx_therm_acceptance", "smcx_hist_info", "smcx_series", "smcx_download_positions",
+    "smcx_therm_acceptance", "smcx_hist_info", "smcx_series", "smcx_density",
+    "smcx_pressure_series", "smcx_download_positions",
     "smcx_total_energy", "smcx_rng_export", "smcx_rng_import", "smcx_obs_device_bytes",
     "smcx_export_observables_device", "smcx_last_kernel_ms", "smcx_last_run_ms", "smcx_geometry", "smcx_eval_moves",
     "smcx_rng_seed", "smcx_one_particle_moves",
@@ -81,6 +82,8 @@ def _lib():
         L.smcx_therm_acceptance.argtypes = [vp, _dp]
         L.smcx_hist_info.argtypes = [vp, _u64p, _u64p]
         L.smcx_series.argtypes = [vp, _dp, _i32p]
+        L.smcx_density.argtypes = [vp, _u64p, _u64p]
+        L.smcx_pressure_series.argtypes = [vp, _dp, C.POINTER(C.c_int)]
         L.smcx_download_positions.argtypes = [vp, _dp]
         L.smcx_total_energy.argtypes = [vp, _dp]
         L.smcx_rng_export.argtypes = [vp, _u32p]
@@ -228,6 +231,20 @@ class Engine:
         self._chk(_lib().smcx_series(self._h, _p(E, C.c_double), _p(jj, C.c_int32)), "smcx_series")
         return E, jj[:, :maxsteps]
 
+    def density(self):
+        Nc = self.p.Ncx * self.p.Ncx * self.p.Ncz
+        D = np.zeros((self.p.nrep, Nc), dtype=np.uint64)
+        Mu = np.zeros((self.p.nrep, Nc), dtype=np.uint64)
+        self._chk(_lib().smcx_density(self._h, _p(D, C.c_uint64), _p(Mu, C.c_uint64)), "smcx_density")
+        return D, Mu
+
+    def pressure_series(self):
+        n = C.c_int(0)
+        self._chk(_lib().smcx_pressure_series(self._h, None, C.byref(n)), "smcx_pressure_series")
+        P = np.zeros((self.p.nrep, max(n.value, 1)))
+        self._chk(_lib().smcx_pressure_series(self._h, _p(P, C.c_double), C.byref(n)), "smcx_pressure_series")
+        return P[:, :n.value]
+
     def positions(self):
         R = np.zeros((self.p.nrep, 3 * self.p.N))
         self._chk(_lib().smcx_download_positions(self._h, _p(R, C.c_double)), "smcx_download_positions")
@@ -290,6 +307,8 @@ def _host():
         H.smcx_host_initialize_walls.restype = None
         H.smcx_host_box_for_N.argtypes = [C.c_int, _dp, _dp]
         H.smcx_host_box_for_N.restype = None
+        H.smcx_host_write_csv.argtypes = [C.c_void_p, C.POINTER(Params), C.c_int, C.c_int, C.c_char_p]
+        H.smcx_host_read_last_state.argtypes = [C.c_char_p, C.c_int, _dp]
         _HOST = H
     return _HOST
 
@@ -313,3 +332,19 @@ def initialize_walls(M=3, x0m=1.6, x0sigma=0.0, ymm=3.0, ymsigma=0.5, uninit=0.0
     W = np.zeros(2 * M * M)
     _host().smcx_host_initialize_walls(x0m, x0sigma, ymm, ymsigma, M, uninit, _p(W, C.c_double))
     return W
+
+
+def write_csv(engine, maxsteps, gather_lapse, directory):
+    """the reference's data_/local_/last_state_ files for the engine's last run (C host side)"""
+    rc = _host().smcx_host_write_csv(engine._h, C.byref(engine.p), maxsteps, gather_lapse,
+                                     directory.encode())
+    if rc != OK:
+        raise SmcxError(rc, "smcx_host_write_csv")
+
+
+def read_last_state(path, N):
+    R = np.zeros(3 * N)
+    n = _host().smcx_host_read_last_state(path.encode(), N, _p(R, C.c_double))
+    if n != 3 * N:
+        raise ValueError("last_state file holds %d of %d coordinates" % (n, 3 * N))
+    return R

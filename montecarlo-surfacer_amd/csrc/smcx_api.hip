@@ -36,6 +36,7 @@ struct Handle {
     int last_launches = 0;
     std::vector<hipEvent_t> evs; // start/stop pairs around the sweep launches
     std::vector<int> last_sweeps; // sweeps in each launch of the last run
+    int last_gathers = 0;
     std::string err;
 };
 
@@ -215,6 +216,7 @@ extern "C" int smcx_destroy(smcx_handle *hh)
     hipFree(c.R); hipFree((void *)c.W); hipFree(c.rng); hipFree(c.raw); hipFree(c.displ);
     hipFree(c.uni); hipFree(c.offs); hipFree(c.obs); hipFree(c.zhist); hipFree(c.Eseries);
     hipFree(c.jjseries); hipFree(c.rec); hipFree(h.d_save); hipFree(h.d_tmp);
+    hipFree(c.D); hipFree(c.Mu); hipFree(c.Rbin); hipFree(c.Pseries);
     for (hipEvent_t e : h.evs) hipEventDestroy(e);
     if (h.ev0) hipEventDestroy(h.ev0);
     if (h.ev1) hipEventDestroy(h.ev1);
@@ -275,6 +277,12 @@ extern "C" int smcx_create(const smcx_params *p, smcx_handle **out)
     CRT(hipMalloc(&c.zhist, nrep * p->Ncz * sizeof(unsigned long long)));
     CRT(hipMalloc(&h.d_save, nrep * sizeof(double)));
     CRT(hipMalloc(&h.d_tmp, nrep * sizeof(double)));
+    if (p->flags & SMCX_FLAG_FULL_HIST) {
+        const size_t Nc = (size_t)p->Ncx * p->Ncx * p->Ncz;
+        CRT(hipMalloc(&c.D, nrep * Nc * sizeof(unsigned long long)));
+        CRT(hipMalloc(&c.Mu, nrep * Nc * sizeof(unsigned long long)));
+        CRT(hipMalloc(&c.Rbin, nrep * N * sizeof(int)));
+    }
     CRT(hipMemset(c.obs, 0, nrep * sizeof(ObsRec)));
     CRT(hipMemset(c.zhist, 0, nrep * p->Ncz * sizeof(unsigned long long)));
     CRT(hipMemset((void *)c.W, 0, (size_t)(2 * c.M2 > 2 ? 2 * c.M2 : 2) * sizeof(double)));
@@ -375,8 +383,11 @@ static int run_phase(Handle &h, int steps, double A, int production, int gather_
     while (done < steps) {
         int k = (steps - done < h.chunk) ? steps - done : h.chunk;
         if (production) {
-            if ((done + 1) % gather_lapse == 0) // SMC.c:137-141
+            if ((done + 1) % gather_lapse == 0) { // SMC.c:137-141
+                if (h.c.Pseries) HIPCHK(&h, launch_pressure(h.c, h.last_gathers, h.stream));
                 HIPCHK(&h, launch_hist(h.c, h.stream));
+                h.last_gathers++;
+            }
             // next sweep index n > done with (n+1) % gather_lapse == 0
             const int next = ((done + 1) / gather_lapse + 1) * gather_lapse - 1;
             if (next - done < k) k = next - done;
@@ -410,6 +421,23 @@ extern "C" int smcx_run(smcx_handle *hh, int eqsteps, int maxsteps, int gather_l
     if (rc != SMCX_OK) return rc;
     h.last_launches = 0;
     h.last_sweeps.clear();
+    h.last_gathers = 0;
+    if (h.c.D) { // D, Mu and Rbin start from zero in every sMC call (SMC.c:52-55)
+        const size_t Nc = (size_t)h.p.Ncx * h.p.Ncx * h.p.Ncz;
+        HIPCHK(&h, hipMemsetAsync(h.c.D, 0, (size_t)h.p.nrep * Nc * sizeof(unsigned long long), h.stream));
+        HIPCHK(&h, hipMemsetAsync(h.c.Mu, 0, (size_t)h.p.nrep * Nc * sizeof(unsigned long long), h.stream));
+        HIPCHK(&h, hipMemsetAsync(h.c.Rbin, 0, (size_t)h.p.nrep * h.p.N * sizeof(int), h.stream));
+    }
+    if (h.p.flags & SMCX_FLAG_PRESSURE) {
+        const int need = maxsteps / gather_lapse + 1;
+        if (h.c.pstride < need) {
+            hipFree(h.c.Pseries);
+            h.c.Pseries = nullptr;
+            h.c.pstride = need;
+            HIPCHK(&h, hipMalloc(&h.c.Pseries, (size_t)h.p.nrep * need * sizeof(double)));
+        }
+        HIPCHK(&h, hipMemsetAsync(h.c.Pseries, 0, (size_t)h.p.nrep * h.c.pstride * sizeof(double), h.stream));
+    }
     // zero the accumulators, remember E at entry (the reference's E[0])
     HIPCHK(&h, launch_obs_op(h.c, h.d_save, 0, h.stream));
     HIPCHK(&h, hipEventRecord(h.ev0, h.stream));
@@ -527,6 +555,33 @@ extern "C" int smcx_series(smcx_handle *hh, double *E_series, int32_t *jj)
     if (jj && ms > 0)
         HIPCHK(&h, hipMemcpy2D(jj, (size_t)ms * sizeof(int), h.c.jjseries, (size_t)stride * sizeof(int),
                                (size_t)ms * sizeof(int), h.p.nrep, hipMemcpyDeviceToHost));
+    return SMCX_OK;
+}
+
+extern "C" int smcx_density(smcx_handle *hh, uint64_t *D, uint64_t *Mu)
+{
+    if (!hh) return SMCX_ERR_PARAM;
+    Handle &h = hh->h;
+    if (!h.c.D) return SMCX_ERR_STATE;
+    HIPCHK(&h, hipSetDevice(h.p.device));
+    const size_t bytes = (size_t)h.p.nrep * h.p.Ncx * h.p.Ncx * h.p.Ncz * sizeof(uint64_t);
+    if (D) HIPCHK(&h, hipMemcpy(D, h.c.D, bytes, hipMemcpyDeviceToHost));
+    if (Mu) HIPCHK(&h, hipMemcpy(Mu, h.c.Mu, bytes, hipMemcpyDeviceToHost));
+    return SMCX_OK;
+}
+
+extern "C" int smcx_pressure_series(smcx_handle *hh, double *P, int *ngathers)
+{
+    if (!hh) return SMCX_ERR_PARAM;
+    Handle &h = hh->h;
+    if (!h.c.Pseries) return SMCX_ERR_STATE;
+    if (ngathers) *ngathers = h.last_gathers;
+    if (P && h.last_gathers > 0) {
+        HIPCHK(&h, hipSetDevice(h.p.device));
+        HIPCHK(&h, hipMemcpy2D(P, (size_t)h.last_gathers * sizeof(double), h.c.Pseries,
+                               (size_t)h.c.pstride * sizeof(double), (size_t)h.last_gathers * sizeof(double),
+                               h.p.nrep, hipMemcpyDeviceToHost));
+    }
     return SMCX_OK;
 }
 

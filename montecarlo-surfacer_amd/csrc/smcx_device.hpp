@@ -62,6 +62,12 @@ struct DevCtx {
     int *jjseries;                // [nrep][series_stride] or null
     long rawStride;
     SweepRec *rec;                // [nrep][chunk] per-sweep records of the last sweep launch
+    // optional observables (SMCX_FLAG_FULL_HIST / SMCX_FLAG_PRESSURE), null when off
+    unsigned long long *D;        // [nrep][Ncx*Ncx*Ncz] cell occupancy   (SMC.c:921)
+    unsigned long long *Mu;       // [nrep][Ncx*Ncx*Ncz] cell changes     (SMC.c:922-925)
+    int *Rbin;                    // [nrep][N] cell of each particle at the previous gather
+    double *Pseries;              // [nrep][pstride] pressure + wallsPressure per gather (SMC.c:140)
+    int pstride;
 };
 
 // the (few) things the hot kernel needs; everything cold stays in DevCtx

@@ -12,6 +12,7 @@ hipError_t launch_sweeps(const DevCtx &c, int S, int WPR, int nsweeps, double A,
 hipError_t launch_finalize(const DevCtx &c, int nsweeps, int production, int sweep_base,
                            int first_production, hipStream_t st);
 hipError_t launch_hist(const DevCtx &c, hipStream_t st);
+hipError_t launch_pressure(const DevCtx &c, int gather, hipStream_t st);
 hipError_t launch_total_energy(const DevCtx &c, double *out, hipStream_t st);
 hipError_t launch_eval_moves(const DevCtx &c, const int *nsel, const double *prop, double *out,
                              hipStream_t st);

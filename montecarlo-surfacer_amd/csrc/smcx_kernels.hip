@@ -389,8 +389,16 @@ __global__ void __launch_bounds__(256) hist_kernel(DevCtx c)
         const int cj = (int)floor((Rg[3 * l + 1] / c.L + .5) * c.Ncx) & 0xff;
         const int ck = (int)floor((Rg[3 * l + 2] / c.Lz + .5) * c.Ncz) & 0xff;
         const int cell = ci * c.Ncx * c.Ncz + cj * c.Ncz + ck;
-        if (cell < Nc) atomicAdd(&zh[cell % c.Ncz], 1u);
-        else atomicAdd(&oob, 1u); // the reference writes out of bounds here
+        if (cell < Nc) {
+            atomicAdd(&zh[cell % c.Ncz], 1u);
+            if (c.D) { // the full Ncx x Ncx x Ncz occupancy and mobility counters
+                atomicAdd(&c.D[(size_t)rep * Nc + cell], 1ull);
+                int *rb = c.Rbin + (size_t)rep * c.N + l;
+                if (*rb != cell) { atomicAdd(&c.Mu[(size_t)rep * Nc + cell], 1ull); *rb = cell; }
+            }
+        } else {
+            atomicAdd(&oob, 1u); // the reference writes out of bounds here
+        }
     }
     __syncthreads();
     if (tid < c.Ncz && zh[tid]) c.zhist[(size_t)rep * c.Ncz + tid] += zh[tid];
@@ -398,6 +406,57 @@ __global__ void __launch_bounds__(256) hist_kernel(DevCtx c)
         c.obs[rep].gathers += 1.0;
         c.obs[rep].oob += (double)oob;
     }
+}
+
+// ---------------------------------------------------------------------------------
+// virial pressure of one gather: pressure() SMC.c:696-720 + wallsPressure() SMC.c:862-895,
+// the latter with the reference's own geometry (wall distance from z + L/2, no clamp,
+// plane term once per site inside that site's cutoff); 256 threads per replica
+// ---------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) pressure_kernel(DevCtx c, int gather)
+{
+    __shared__ double part[4];
+    const int rep = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int N = c.N;
+    const double *Rg = c.R + (size_t)rep * 3 * N;
+    const int half = N / 2;
+    double acc = 0.0;
+    for (int i = tid; i < N; i += 256) {
+        const double xi = Rg[3 * i], yi = Rg[3 * i + 1], zi = Rg[3 * i + 2];
+        for (int d = 1; d <= half; d++) {
+            if (2 * d == N && i >= half) break;
+            int l = i + d; if (l >= N) l -= N;
+            double dx = Rg[3 * l] - xi; dx = dx - c.L * __builtin_rint(dx * c.invL);
+            double dy = Rg[3 * l + 1] - yi; dy = dy - c.L * __builtin_rint(dy * c.invL);
+            const double dz = Rg[3 * l + 2] - zi;
+            const double dr2 = dx * dx + dy * dy + dz * dz;
+            if (dr2 < c.cutoff2) {
+                const double ir2 = 1.0 / dr2, ir6 = ir2 * ir2 * ir2;
+                acc += 24.0 * ir6 - 48.0 * ir6 * ir6;
+            }
+        }
+        if (c.flags & 0x1u) {
+            double dz = zi + c.L / 2; // sic, SMC.c:880
+            dz = dz - c.Lz * __builtin_rint(dz * c.invLz);
+            const double iz2 = 1.0 / (dz * dz), iz6 = iz2 * iz2 * iz2;
+            const double plane = 24.0 * c.b0 * iz6 - 48.0 * c.a0 * iz6 * iz6;
+            const double dw = c.L / c.M;
+            for (int m = 0; m < c.M2; m++) {
+                double dx = xi - (m / c.M) * dw; dx = dx - c.L * __builtin_rint(dx * c.invL);
+                double dy = yi - (m % c.M) * dw; dy = dy - c.L * __builtin_rint(dy * c.invL);
+                const double dr2 = dx * dx + dy * dy + dz * dz;
+                if (dr2 < c.cutoff2) {
+                    const double ir2 = 1.0 / dr2, ir6 = ir2 * ir2 * ir2;
+                    acc += 24.0 * c.W[2 * m + 1] * ir6 - 48.0 * c.W[2 * m] * ir6 * ir6 + plane;
+                }
+            }
+        }
+    }
+    for (int m = 32; m >= 1; m >>= 1) acc += xchg(acc, m);
+    if (lane == 0) part[wave] = acc;
+    __syncthreads();
+    if (tid == 0 && gather < c.pstride)
+        c.Pseries[(size_t)rep * c.pstride + gather] = -(part[0] + part[1] + part[2] + part[3]) / (3 * c.L * c.L * c.Lz);
 }
 
 // ---------------------------------------------------------------------------------
@@ -562,6 +621,12 @@ hipError_t launch_finalize(const DevCtx &c, int nsweeps, int production, int swe
 hipError_t launch_hist(const DevCtx &c, hipStream_t st)
 {
     hipLaunchKernelGGL(hist_kernel, dim3(c.nrep), dim3(256), 0, st, c);
+    return hipGetLastError();
+}
+
+hipError_t launch_pressure(const DevCtx &c, int gather, hipStream_t st)
+{
+    hipLaunchKernelGGL(pressure_kernel, dim3(c.nrep), dim3(256), 0, st, c, gather);
     return hipGetLastError();
 }
 

@@ -192,3 +192,80 @@ int smcx_host_sMC(const smcx_params *p, const double *W, const double *R0, int m
     if (rc != SMCX_OK) smcx_host_sim_free(out);
     return rc;
 }
+
+/* ---- the reference's CSV outputs ------------------------------------------------- */
+int smcx_host_write_csv(smcx_handle *h, const smcx_params *p, int maxsteps, int gather_lapse,
+                        const char *dir)
+{
+    if (!h || !p || !dir || maxsteps < 0 || gather_lapse < 1) return SMCX_ERR_PARAM;
+    const int nrep = p->nrep, N = p->N, Ncx = p->Ncx, Ncz = p->Ncz;
+    const size_t Nc = (size_t)Ncx * Ncx * Ncz;
+    const int gather_steps = maxsteps / gather_lapse;        /* SMC.c:27 */
+    const double rho = N / (p->L * p->L * p->Lz);             /* SMC.c:24 */
+    double *E = (double *)malloc((size_t)nrep * (maxsteps + 1) * sizeof(double));
+    int32_t *jj = (int32_t *)malloc((size_t)nrep * (maxsteps > 0 ? maxsteps : 1) * sizeof(int32_t));
+    uint64_t *D = (uint64_t *)malloc((size_t)nrep * Nc * sizeof(uint64_t));
+    uint64_t *Mu = (uint64_t *)malloc((size_t)nrep * Nc * sizeof(uint64_t));
+    double *R = (double *)malloc((size_t)nrep * 3 * N * sizeof(double));
+    double *P = NULL;
+    int ng = 0, rc = SMCX_OK;
+    char path[1024];
+    do {
+        if (!E || !jj || !D || !Mu || !R) { rc = SMCX_ERR_NOMEM; break; }
+        if ((rc = smcx_series(h, E, jj)) != SMCX_OK) break;
+        if ((rc = smcx_density(h, D, Mu)) != SMCX_OK) break;
+        if ((rc = smcx_download_positions(h, R)) != SMCX_OK) break;
+        if (p->flags & SMCX_FLAG_PRESSURE) {
+            if ((rc = smcx_pressure_series(h, NULL, &ng)) != SMCX_OK) break;
+            P = (double *)calloc((size_t)nrep * (ng > 0 ? ng : 1), sizeof(double));
+            if (!P) { rc = SMCX_ERR_NOMEM; break; }
+            if ((rc = smcx_pressure_series(h, P, &ng)) != SMCX_OK) break;
+        }
+        for (int r = 0; r < nrep && rc == SMCX_OK; r++) {
+            const int rank = (int)p->first_replica + r;
+            snprintf(path, sizeof path, "%s/data_N%d_M%d_r%0.4f_T%0.2f_rank%d.csv", dir, N, p->M, rho, p->T, rank);
+            FILE *f = fopen(path, "w");
+            if (!f) { rc = SMCX_ERR_STATE; break; }
+            fprintf(f, "E, P, jj\n");
+            for (int k = 0; k < gather_steps; k++) { /* SMC.c:207-215 */
+                const double e = E[(size_t)r * (maxsteps + 1) + (size_t)k * gather_lapse] + 3 * N * p->T / 2;
+                const double pk = ((k >= 1 && P && k - 1 < ng) ? P[(size_t)r * ng + (k - 1)] : 0.0) + rho * p->T;
+                fprintf(f, "%0.9lf, %0.9lf, %d\n", e, pk, jj[(size_t)r * maxsteps + k]);
+            }
+            fclose(f);
+            snprintf(path, sizeof path, "%s/local_N%d_M%d_r%0.4f_T%0.2f_rank%d.csv", dir, N, p->M, rho, p->T, rank);
+            f = fopen(path, "w");
+            if (!f) { rc = SMCX_ERR_STATE; break; }
+            fprintf(f, "nx, ny, nz, n, mu\n");
+            for (int i = 0; i < Ncx; i++)
+                for (int j = 0; j < Ncx; j++)
+                    for (int k = 0; k < Ncz; k++) { /* SMC.c:218-225 */
+                        const size_t v = (size_t)i * Ncx * Ncz + (size_t)j * Ncz + k;
+                        fprintf(f, "%d, %d, %d, %lu, %lu\n", i, j, k, (unsigned long)D[r * Nc + v],
+                                (unsigned long)Mu[r * Nc + v]);
+                    }
+            fclose(f);
+            if (nrep == 1 && p->first_replica == 0)
+                snprintf(path, sizeof path, "%s/last_state_N%d_M%d_r%0.4f_T%0.2f.csv", dir, N, p->M, rho, p->T);
+            else
+                snprintf(path, sizeof path, "%s/last_state_N%d_M%d_r%0.4f_T%0.2f_rank%d.csv", dir, N, p->M, rho,
+                         p->T, rank);
+            f = fopen(path, "w");
+            if (!f) { rc = SMCX_ERR_STATE; break; }
+            for (int i = 0; i < 3 * N; i++) fprintf(f, "%0.12f,", R[(size_t)r * 3 * N + i]); /* main.c:169-170 */
+            fclose(f);
+        }
+    } while (0);
+    free(E); free(jj); free(D); free(Mu); free(R); free(P);
+    return rc;
+}
+
+int smcx_host_read_last_state(const char *path, int N, double *R0)
+{
+    FILE *f = fopen(path, "r");
+    if (!f) return -1;
+    int n = 0;
+    while (n < 3 * N && fscanf(f, "%lf,", &R0[n]) == 1) n++; /* main.c:104-105 */
+    fclose(f);
+    return n;
+}

@@ -243,6 +243,56 @@ double orc_walls_energy(const orc_sys *s, const double *r, const double *W)
 }
 
 /* ------------------------------------------------------------------------ */
+/* pressure SMC.c:696-720, wallsPressure SMC.c:862-895                      */
+/* ------------------------------------------------------------------------ */
+double orc_pressure(const orc_sys *s, const double *r)
+{
+    const int N = s->N;
+    const double L = s->L, c2 = s->cutoff * s->cutoff;
+    double P = 0.0;
+    for (int l = 1; l < N; l++) {
+        for (int i = 0; i < l; i++) {
+            double dx = min_image(r[3 * l] - r[3 * i], L);
+            double dy = min_image(r[3 * l + 1] - r[3 * i + 1], L);
+            double dz = r[3 * l + 2] - r[3 * i + 2];
+            double dr2 = dx * dx + dy * dy + dz * dz;
+            if (dr2 < c2) {
+                double dr6 = dr2 * dr2 * dr2;
+                P += 24.0 / dr6 - 48.0 / (dr6 * dr6);
+            }
+        }
+    }
+    return -P / (3 * L * L * s->Lz);
+}
+
+double orc_walls_pressure(const orc_sys *s, const double *r, const double *W)
+{
+    const int N = s->N, M = s->M;
+    const double L = s->L, Lz = s->Lz, c2 = s->cutoff * s->cutoff;
+    const double dw = L / M;
+    double P = 0.0;
+    for (int i = 0; i < M; i++) {
+        for (int j = 0; j < M; j++) {
+            int m = j + i * M;
+            for (int n = 0; n < N; n++) {
+                double dx = min_image(r[3 * n] - i * dw, L);
+                double dy = min_image(r[3 * n + 1] - j * dw, L);
+                double dz = r[3 * n + 2] + L / 2; /* sic: L/2, SMC.c:880 */
+                dz = dz - Lz * rint(dz / Lz);
+                double dr2 = dx * dx + dy * dy + dz * dz;
+                if (dr2 < c2) {
+                    double dr6 = dr2 * dr2 * dr2;
+                    P += 24.0 * W[2 * m + 1] / dr6 - 48.0 * W[2 * m] / (dr6 * dr6);
+                    double dz6 = dz * dz * dz * dz * dz * dz;
+                    P += 24.0 * s->b0 / dz6 - 48.0 * s->a0 / (dz6 * dz6);
+                }
+            }
+        }
+    }
+    return -P / (3 * L * L * Lz);
+}
+
+/* ------------------------------------------------------------------------ */
 /* S1 oneParticleMoves  SMC.c:278-351                                       */
 /* ------------------------------------------------------------------------ */
 void orc_one_particle_moves(const orc_sys *s, orc_rng *g, double *R, double *Rn,
@@ -361,6 +411,15 @@ int orc_chain(const orc_sys *s, unsigned int seed, double *R, const double *W,
               unsigned int flags, double *E_series, int32_t *jj_out, uint64_t *zhist,
               uint64_t *D_out, uint64_t *Mu_out, orc_chain_result *res)
 {
+    return orc_chain_p(s, seed, R, W, T, A, eqsteps, maxsteps, gather_lapse, flags, E_series,
+                       jj_out, zhist, D_out, Mu_out, NULL, res);
+}
+
+int orc_chain_p(const orc_sys *s, unsigned int seed, double *R, const double *W,
+                double T, double A, int eqsteps, int maxsteps, int gather_lapse,
+                unsigned int flags, double *E_series, int32_t *jj_out, uint64_t *zhist,
+                uint64_t *D_out, uint64_t *Mu_out, double *P_gathers, orc_chain_result *res)
+{
     const int N = s->N;
     const size_t Nc = (size_t)s->Ncx * s->Ncx * s->Ncz;
     if (N < 1 || maxsteps < 0 || eqsteps < 0 || gather_lapse < 1)
@@ -393,6 +452,8 @@ int orc_chain(const orc_sys *s, unsigned int seed, double *R, const double *W,
 
     for (int n = 0; n < maxsteps; n++) {
         if ((n + 1) % gather_lapse == 0) { /* SMC.c:137-141: before this sweep's moves */
+            if (P_gathers)
+                P_gathers[gathers] = orc_pressure(s, R) + orc_walls_pressure(s, R, W);
             orc_local_density(s, R, D, Rbin, Mu, &oob);
             gathers++;
         }
@@ -595,6 +656,21 @@ double orc_nw_energy(int N, const double *r, double L)
                 V += 1.0 / (dr2 * dr2 * dr2 * dr2 * dr2 * dr2) - 1.0 / (dr2 * dr2 * dr2);
         }
     return V * 4;
+}
+
+double orc_nw_pressure(int N, const double *r, double L)
+{
+    double P = 0.0;
+    for (int l = 1; l < N; l++)
+        for (int i = 0; i < l; i++) {
+            double dx = min_image(r[3 * l] - r[3 * i], L);
+            double dy = min_image(r[3 * l + 1] - r[3 * i + 1], L);
+            double dz = min_image(r[3 * l + 2] - r[3 * i + 2], L);
+            double dr2 = dx * dx + dy * dy + dz * dz;
+            if (dr2 < L * L / 4)
+                P += 24.0 / (dr2 * dr2 * dr2) - 48.0 / (dr2 * dr2 * dr2 * dr2 * dr2 * dr2);
+        }
+    return -P / (3 * L * L * L);
 }
 
 void orc_nw_one_particle_moves(int N, orc_rng *g, double *R, double *Rn, double L,

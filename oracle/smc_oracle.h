@@ -84,6 +84,12 @@ void orc_walls_force(const orc_sys *s, double rx, double ry, double rz,
 double orc_energy(const orc_sys *s, const double *r);
 double orc_walls_energy(const orc_sys *s, const double *r, const double *W);
 
+/* virial pressure, SMC.c:696-720, and its wall part, SMC.c:862-895 -- restated with
+ * the reference's quirks: the wall distance uses L/2 where Lz/2 is meant (:880), is not
+ * clamped, and the plane term is added once per wall SITE inside that site's cutoff */
+double orc_pressure(const orc_sys *s, const double *r);
+double orc_walls_pressure(const orc_sys *s, const double *r, const double *W);
+
 /* S1  SMC.c:278-351; trace may be NULL, else N records */
 void orc_one_particle_moves(const orc_sys *s, orc_rng *g, double *R, double *Rn,
                             const double *W, double A0, double T, int *j,
@@ -118,6 +124,12 @@ int orc_chain(const orc_sys *s, unsigned int seed, double *R, const double *W,
               double T, double A, int eqsteps, int maxsteps, int gather_lapse,
               unsigned int flags, double *E_series, int32_t *jj, uint64_t *zhist,
               uint64_t *D, uint64_t *Mu, orc_chain_result *res);
+/* the same, also returning pressure + wallsPressure of every gather (SMC.c:140), in
+ * gather order; P_gathers holds maxsteps/gather_lapse entries (may be NULL) */
+int orc_chain_p(const orc_sys *s, unsigned int seed, double *R, const double *W,
+                double T, double A, int eqsteps, int maxsteps, int gather_lapse,
+                unsigned int flags, double *E_series, int32_t *jj, uint64_t *zhist,
+                uint64_t *D, uint64_t *Mu, double *P_gathers, orc_chain_result *res);
 
 /* ---- inputs to the path (not on it) ------------- */
 /* build-defined fcc(Na,Nz) start, SURVEY.md 8d (cell order and +a/4 of
@@ -135,6 +147,7 @@ void orc_initialize_walls(double x0m, double x0sigma, double ymm, double ymsigma
 double orc_nw_energy_single(int N, const double *r, double L, int i);            /* :599-619 */
 void orc_nw_force(int N, const double *r, double L, int i, double F[3]);         /* :501-529 */
 double orc_nw_energy(int N, const double *r, double L);                          /* :573-591 */
+double orc_nw_pressure(int N, const double *r, double L);                        /* :664-684 */
 void orc_nw_one_particle_moves(int N, orc_rng *g, double *R, double *Rn, double L,
                                double A, double T, int *j, orc_move_trace *trace); /* :266-316 */
 int orc_nw_fcc_init(int N, double L, double *X);                                 /* :359-394 */

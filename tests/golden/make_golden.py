@@ -95,7 +95,7 @@ def main():
                                  {"N": 4096, "Na": 8, "Nz": 16, "sweeps": 5, "ratio": 0.487}],
                        "digits": 3},
         "nowall_N256": {"cite": "SURVEY.md 8c (vi): SMC_noMPI_noWall.c, N=256, rho=0.1, L=cbrt(2560)",
-                        "E0": -36.1886050855328, "energySingle0": -0.282694180641838,
+                        "E0": -36.1886050855328, "P0": -0.0281510305248713, "energySingle0": -0.282694180641838,
                         "energySingle1": -0.262872304878899, "acceptance_500": 0.980},
         "rand_12345": {"cite": "SURVEY.md 8a row R lists these three outputs of srand(12345) "
                                "(as a set; libc's call order is 383100999, 858300821, 357768173)",

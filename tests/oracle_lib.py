@@ -106,6 +106,12 @@ def lib():
                                 C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
                                 C.POINTER(C.c_uint64), C.POINTER(OrcChainResult)]
         L.orc_chain.restype = C.c_int
+        L.orc_chain_p.argtypes = L.orc_chain.argtypes[:-1] + [_dp, C.POINTER(OrcChainResult)]
+        L.orc_chain_p.restype = C.c_int
+        L.orc_pressure.argtypes = [sp, _dp]
+        L.orc_pressure.restype = C.c_double
+        L.orc_walls_pressure.argtypes = [sp, _dp, _dp]
+        L.orc_walls_pressure.restype = C.c_double
         L.orc_fcc_init.argtypes = [C.c_int, C.c_int, C.c_double, C.c_double, _dp]
         L.orc_fcc_init.restype = C.c_int
         L.orc_initialize_box_ref.argtypes = [C.c_double, C.c_double, C.c_int, _dp]
@@ -116,6 +122,8 @@ def lib():
         L.orc_nw_force.argtypes = [C.c_int, _dp, C.c_double, C.c_int, _dp]
         L.orc_nw_energy.argtypes = [C.c_int, _dp, C.c_double]
         L.orc_nw_energy.restype = C.c_double
+        L.orc_nw_pressure.argtypes = [C.c_int, _dp, C.c_double]
+        L.orc_nw_pressure.restype = C.c_double
         L.orc_nw_one_particle_moves.argtypes = [C.c_int, C.POINTER(OrcRng), _dp, _dp, C.c_double,
                                                 C.c_double, C.c_double, C.POINTER(C.c_int),
                                                 C.POINTER(OrcMoveTrace)]
@@ -217,7 +225,8 @@ def sweep(s, rng, R, W, A, T, E=0.0, trace=False):
     return j.value, Ed.value, tr
 
 
-def chain(s, seed, R0, W, T, A, eqsteps, maxsteps, gather_lapse, e0_restart=True, full_hist=False):
+def chain(s, seed, R0, W, T, A, eqsteps, maxsteps, gather_lapse, e0_restart=True, full_hist=False,
+          pressure=False):
     R = np.array(R0, dtype=np.float64, copy=True)
     E = np.zeros(maxsteps + 1)
     jj = np.zeros(max(maxsteps, 1), dtype=np.int32)
@@ -226,14 +235,20 @@ def chain(s, seed, R0, W, T, A, eqsteps, maxsteps, gather_lapse, e0_restart=True
     D = np.zeros(Nc, dtype=np.uint64) if full_hist else None
     Mu = np.zeros(Nc, dtype=np.uint64) if full_hist else None
     res = OrcChainResult()
-    rc = lib().orc_chain(C.byref(s), seed, _ptr(R), _ptr(W), T, A, eqsteps, maxsteps, gather_lapse,
-                         1 if e0_restart else 0, _ptr(E), _ptr(jj, C.c_int32),
-                         _ptr(zh, C.c_uint64), _ptr(D, C.c_uint64), _ptr(Mu, C.c_uint64),
-                         C.byref(res))
+    P = np.zeros(max(maxsteps // gather_lapse, 1)) if pressure else None
+    rc = lib().orc_chain_p(C.byref(s), seed, _ptr(R), _ptr(W), T, A, eqsteps, maxsteps, gather_lapse,
+                           1 if e0_restart else 0, _ptr(E), _ptr(jj, C.c_int32),
+                           _ptr(zh, C.c_uint64), _ptr(D, C.c_uint64), _ptr(Mu, C.c_uint64),
+                           _ptr(P), C.byref(res))
     assert rc == 0
     out = {k: getattr(res, k) for k, _ in OrcChainResult._fields_}
-    out.update(R=R, E=E, jj=jj[:maxsteps], zhist=zh, D=D, Mu=Mu)
+    out.update(R=R, E=E, jj=jj[:maxsteps], zhist=zh, D=D, Mu=Mu,
+               P=None if P is None else P[:maxsteps // gather_lapse])
     return out
+
+
+def pressure(s, R, W):
+    return lib().orc_pressure(C.byref(s), _ptr(R)) + lib().orc_walls_pressure(C.byref(s), _ptr(R), _ptr(W))
 
 
 def time_sweeps(s, seed, R, W, T, A, sweeps):

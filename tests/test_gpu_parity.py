@@ -373,3 +373,62 @@ def test_observable_export_to_device_memory(S, O):
     sm = D.summarise(got, p.N, 4)
     assert np.allclose(sm["meanE"], ob["meanE"], rtol=1e-15) and np.allclose(sm["acceptance_ratio"], ob["acceptance_ratio"])
     eng.close()
+
+
+# ------------------------------------------------------------------ SURVEY 8f "next" rows
+def test_full_density_mobility_and_pressure(S, O):
+    """8f.1/8f.2: the Ncx x Ncx x Ncz occupancy D and mobility Mu of localDensityAndMobility
+    (SMC.c:912-927) and pressure + wallsPressure of every gather (SMC.c:140, 696-720, 862-895)"""
+    R0 = dense_state(O); R0[3 * 82 + 2] = 119.0; R0[3 * 83 + 2] = -119.5
+    nrep = 3
+    flags = S.FLAGS_REFERENCE | S.FLAG_FULL_HIST | S.FLAG_PRESSURE | S.FLAG_SERIES
+    eng, p = make_engine(S, O, R0, nrep, flags=flags)
+    eng.run(1, 6, 2)
+    D, Mu = eng.density()
+    P = eng.pressure_series()
+    ob = eng.observables()
+    s = sys_of(O, p)
+    assert P.shape == (nrep, 3)
+    for r in range(nrep):
+        ref = O.chain(s, 12345 + r, R0, O.W_FIXTURE, T, A, 1, 6, 2, full_hist=True, pressure=True)
+        assert np.array_equal(D[r], ref["D"]) and np.array_equal(Mu[r], ref["Mu"])
+        assert D[r].sum() == 3 * 1024 and np.array_equal(D[r].reshape(33, 33, 33).sum(axis=(0, 1)), ob["zhist"][r])
+        assert np.all(rel(P[r], ref["P"]) < 1e-9), (P[r], ref["P"])
+    eng.close()
+
+
+def test_csv_outputs_and_restart(S, O, tmp_path):
+    """8f.1: data_/local_/last_state_ files in the reference's formats (SMC.c:75-82, 214-225;
+    main.c:162-170), and a restart from last_state (main.c:98-108)"""
+    R0 = O.fcc(4, 4)
+    flags = S.FLAGS_REFERENCE | S.FLAG_FULL_HIST | S.FLAG_PRESSURE | S.FLAG_SERIES
+    eng, p = make_engine(S, O, R0, 2, flags=flags)
+    eng.run(0, 8, 2)
+    S.write_csv(eng, 8, 2, str(tmp_path))
+    Rfin = eng.positions()
+    eng.close()
+    s = sys_of(O, p)
+    rho = 256 / (33.0 * 33.0 * 240.0)
+    tag = "N256_M3_r%0.4f_T%0.2f" % (rho, 1.1)
+    for r in range(2):
+        ref = O.chain(s, 12345 + r, R0, O.W_FIXTURE, T, A, 0, 8, 2, full_hist=True, pressure=True)
+        rows = open(tmp_path / ("data_%s_rank%d.csv" % (tag, r))).read().strip().split("\n")
+        assert rows[0] == "E, P, jj" and len(rows) == 1 + 4
+        for k in range(4):
+            e, pk, j = rows[1 + k].split(",")
+            assert abs(float(e) - (ref["E"][2 * k] + 3 * 256 * 1.1 / 2)) < 1e-6
+            pref = (ref["P"][k - 1] if k >= 1 else 0.0) + rho * 1.1
+            assert abs(float(pk) - pref) < 1e-9
+            assert int(j) == ref["jj"][k]
+        loc = np.loadtxt(tmp_path / ("local_%s_rank%d.csv" % (tag, r)), delimiter=",", skiprows=1)
+        assert loc.shape == (33 ** 3, 5)
+        assert np.array_equal(loc[:, 3].astype(np.uint64), ref["D"]) and np.array_equal(loc[:, 4].astype(np.uint64), ref["Mu"])
+        assert np.array_equal(loc[34, :3], [0, 1, 1])  # nx, ny, nz order: k fastest
+        last = S.read_last_state(str(tmp_path / ("last_state_%s_rank%d.csv" % (tag, r))), 256)
+        assert np.abs(last - Rfin[r]).max() < 1e-12 + 5e-13  # %0.12f
+    # restart replica 0 from its file: the chain continues from the stored (rounded) positions
+    eng2 = S.Engine(S.default_params(256, 1))
+    eng2.upload(S.read_last_state(str(tmp_path / ("last_state_%s_rank0.csv" % tag)), 256), O.W_FIXTURE)
+    eng2.run(0, 1, 1)
+    assert eng2.observables()["zhist"][0].sum() == 256
+    eng2.close()

@@ -160,6 +160,7 @@ def test_nowall_pins(O):
     dp = C.POINTER(C.c_double)
     assert O.lib().orc_nw_fcc_init(N, L, X.ctypes.data_as(dp)) == N
     assert abs(O.lib().orc_nw_energy(N, X.ctypes.data_as(dp), L) - pin["E0"]) < 5e-13
+    assert abs(O.lib().orc_nw_pressure(N, X.ctypes.data_as(dp), L) - pin["P0"]) < 5e-16  # :664-684
     assert abs(O.lib().orc_nw_energy_single(N, X.ctypes.data_as(dp), L, 0) - pin["energySingle0"]) < 5e-15
     assert abs(O.lib().orc_nw_energy_single(N, X.ctypes.data_as(dp), L, 1) - pin["energySingle1"]) < 5e-15
     # 500 sweeps at T=0.4, A=4e-8 (SMC_noMPI_noWall.c:80-81, 192): acceptance 0.980
@@ -274,3 +275,35 @@ int main(void) {
     ref = O.chain(O.make_sys(256), 12345, O.fcc(4, 4), O.W_FIXTURE, 1.1, 1.1, 2, 4, 2)
     meanE, acc = out.stdout.split()
     assert float(meanE) == ref["meanE"] and int(acc) == ref["accepted"]
+
+
+def test_pressure_restatement(O):
+    """pressure (SMC.c:696-720) is the virial of the pair energy: P = -(1/3V) sum r dV/dr, i.e.
+    the derivative of energy() under a uniform dilation; wallsPressure keeps the reference's
+    geometry (distance from z + L/2, SMC.c:880), checked here against an independent numpy form."""
+    rs = np.random.RandomState(4)
+    N = 96
+    s = O.make_sys(N, L=8.0, Lz=8.0, cutoff=3.0)
+    R = ((rs.rand(N, 3) - 0.5) * np.array([8.0, 8.0, 4.0])).ravel()
+    dp = C.POINTER(C.c_double)
+    P = O.lib().orc_pressure(C.byref(s), R.ctypes.data_as(dp))
+    # numpy restatement of the same double sum
+    X = R.reshape(-1, 3)
+    d = X[:, None, :] - X[None, :, :]
+    d[..., 0] -= 8.0 * np.rint(d[..., 0] / 8.0); d[..., 1] -= 8.0 * np.rint(d[..., 1] / 8.0)
+    r2 = (d ** 2).sum(-1)[np.triu_indices(N, 1)]
+    r2 = r2[r2 < 9.0]
+    assert abs(P - (-(24.0 / r2 ** 3 - 48.0 / r2 ** 6).sum() / (3 * 8.0 * 8.0 * 8.0))) < 1e-9 * abs(P)
+    W = O.W_FIXTURE
+    Pw = O.lib().orc_walls_pressure(C.byref(s), R.ctypes.data_as(dp), W.ctypes.data_as(dp))
+    acc = 0.0
+    dw = 8.0 / 3
+    for m in range(9):
+        dx = X[:, 0] - (m // 3) * dw; dx -= 8.0 * np.rint(dx / 8.0)
+        dy = X[:, 1] - (m % 3) * dw; dy -= 8.0 * np.rint(dy / 8.0)
+        dz = X[:, 2] + 8.0 / 2; dz -= 8.0 * np.rint(dz / 8.0)
+        q = dx * dx + dy * dy + dz * dz
+        k = q < 9.0
+        acc += (24.0 * W[2 * m + 1] / q[k] ** 3 - 48.0 * W[2 * m] / q[k] ** 6).sum()
+        acc += (24.0 * s.b0 / dz[k] ** 6 - 48.0 * s.a0 / dz[k] ** 12).sum()
+    assert abs(Pw - (-acc / (3 * 8.0 * 8.0 * 8.0))) < 1e-9 * abs(Pw)
