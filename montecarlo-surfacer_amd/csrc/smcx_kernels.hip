@@ -13,6 +13,8 @@
 #include "smcx_device.hpp"
 #include "smcx_kernels.h"
 
+#include <cstdlib>
+
 namespace smcx {
 
 // ---------------------------------------------------------------------------------
@@ -337,6 +339,201 @@ sweep_kernel(SweepArgs a, DevCtx c, int nsweeps, double A)
 }
 
 // ---------------------------------------------------------------------------------
+// The same sweep for replicas spread over several wavefronts, with the sequential part
+// of a move done ONCE: every wave runs the pass over its own slots and reduces its eight
+// partial sums, then only wave 0 (the leader) combines them, takes the Metropolis
+// decision, forms the next particle's Um,Fm and the next proposal, and publishes
+// {accepted, next probe A, next probe B} through LDS.  The kernel is bound by VALU issue,
+// so the ~150 instructions per move that the other WPR-1 waves no longer replicate are
+// worth more than the second workgroup barrier they cost.
+// ---------------------------------------------------------------------------------
+template <int WPR> struct LeadShared {
+    RoleTable roles;
+    double red[WPR][8];
+    double bc[8]; // accepted, Ax, Ay, Az, Bx, By, Bz, interior
+};
+
+template <int S, int WPR, int MINW, int G>
+__global__ void __launch_bounds__(64 * WPR, MINW)
+sweep_kernel_lead(SweepArgs a, DevCtx c, int nsweeps, double A)
+{
+    static_assert(WPR > 1, "leader/follower form needs several waves");
+    constexpr int T = 64 * WPR;
+    __shared__ LeadShared<WPR> sh;
+
+    const int rep = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = uniform(tid >> 6);
+    const bool leader = (wave == 0);
+    const int N = a.N;
+    double *Rg = a.R + (size_t)rep * 3 * N;
+
+    double x[S], y[S], z[S];
+#pragma unroll
+    for (int k = 0; k < S; k++) {
+        const int l = k * T + tid;
+        if (l < N) { x[k] = Rg[3 * l]; y[k] = Rg[3 * l + 1]; z[k] = Rg[3 * l + 2]; }
+        else { x[k] = 0.0; y[k] = 0.0; z[k] = FAR_PAD; }
+    }
+    int rot = 0;
+
+    if (leader) fill_roles(c, sh.roles, lane);
+    __syncthreads();
+    const int role = leader ? sh.roles.role[lane] : -1;
+
+    Geo g; g.L = a.L; g.invL = a.invL; g.cutoff2 = a.cutoff2;
+    double E = uniform_d(a.obs[rep].Ecur); // leader's
+    const double AoT = A * a.invT;
+    const double Ao4T = A * 0.25 * a.invT;
+
+#pragma unroll 1
+    for (int sw = 0; sw < nsweeps; sw++) {
+        __syncthreads(); // write-through of the previous sweep's last moves has reached L2
+        const double *displ = a.displ + ((size_t)rep * a.chunk + sw) * 3 * N;
+        const double *uni = a.uni + ((size_t)rep * a.chunk + sw) * N;
+        const int n0 = uniform(a.offs[(size_t)rep * a.chunk + sw]);
+        int jacc = 0;
+#pragma unroll 1
+        for (int run = 0; run < 2; run++) {
+            const int first = run == 0 ? n0 : 0;
+            const int len = run == 0 ? N - n0 : n0;
+            if (len == 0) continue;
+            const int vbase = run == 0 ? 0 : N - n0;
+            const int ks = first / T;
+            while (rot != ks) { rotate1<S>(x, y, z); rot = (rot + 1 == S) ? 0 : rot + 1; }
+            int tl = first - ks * T - 1;
+
+            // leader state
+            double Px = 0.0, Py = 0.0, Pz = FAR_PROBE, Um = 0.0, Fmx = 0.0, Fmy = 0.0, Fmz = 0.0;
+            double nBx = 0.0, nBy = 0.0, nBz = FAR_PROBE, bdx = 0.0, bdy = 0.0, bdz = 0.0, bu = 2.0;
+            // inputs of iteration -1: no proposal, probe B = the run's first particle
+            __syncthreads(); // every wave has read the previous run's last broadcast
+            if (leader) {
+                const double b0 = ld_coherent(Rg + 3 * first), b1 = ld_coherent(Rg + 3 * first + 1),
+                             b2 = ld_coherent(Rg + 3 * first + 2);
+                if (len > 1) {
+                    nBx = ld_coherent(Rg + 3 * (first + 1)); nBy = ld_coherent(Rg + 3 * (first + 1) + 1);
+                    nBz = ld_coherent(Rg + 3 * (first + 1) + 2);
+                }
+                if (lane == 0) {
+                    sh.bc[0] = 0.0; sh.bc[1] = 0.0; sh.bc[2] = 0.0; sh.bc[3] = FAR_PROBE;
+                    sh.bc[4] = b0; sh.bc[5] = b1; sh.bc[6] = b2;
+                    sh.bc[7] = (fmax(fabs(b0), fabs(b1)) <= a.edge) ? 1.0 : 0.0;
+                }
+            }
+            __syncthreads();
+            double Qx = 0.0, Qy = 0.0, Qz = FAR_PROBE;
+            double Bx = uniform_d(sh.bc[4]), By = uniform_d(sh.bc[5]), Bz = uniform_d(sh.bc[6]);
+            bool interior = uniform((int)(sh.bc[7] != 0.0)) != 0;
+
+#pragma unroll 1
+            for (int i = -1; i < len; i++) {
+                const int n = first + i;
+                const bool hasA = (i >= 0);
+                const bool hasB = (i + 1 < len);
+                const bool cross = hasB && (tl == T - 1);
+
+                Acc8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+                double side[4];
+                const bool exA0 = (tid == tl);
+                const bool exB0 = (hasA && tid == tl) || (hasB && !cross && tid == tl + 1);
+                const bool exB1 = cross && (tid == 0);
+                fused_pass<S, G>(g, x, y, z, Qx, Qy, Qz, Bx, By, Bz, exA0, exB0, exB1, interior, v);
+                if (leader)
+                    special_block(g, sh.roles, lane, role, hasA, hasB, hasA, Px, Py, Pz, Qx, Qy, Qz,
+                                  Bx, By, Bz, v, side);
+                const double r = reduce8(v.a0, v.a1, v.a2, v.a3, v.b0, v.b1, v.b2, v.b3, lane);
+                if ((lane & 7) == 0) sh.red[wave][lane >> 3] = r;
+                __syncthreads(); // #1: partial sums of all waves are in LDS
+
+                if (leader) {
+                    double t = 0.0;
+                    if (lane < 8 * WPR) t = sh.red[lane >> 3][lane & 7];
+                    if constexpr (WPR > 8) t += sh.red[(lane >> 3) + 8][lane & 7];
+                    if constexpr (WPR >= 8) t = sum_x32(t);
+                    if constexpr (WPR >= 4) t = sum_x16(t);
+                    t = sum_x8(t);
+                    double tot[8];
+#pragma unroll
+                    for (int j = 0; j < 8; j++) tot[j] = rdlane(t, j);
+
+                    bool acc = false;
+                    if (hasA) { // SMC acceptance, SMC.c:326-335
+                        const int j = i & 63;
+                        const double Un = 4.0 * tot[0], Fnx = tot[1], Fny = tot[2], Fnz = tot[3];
+                        const double dX = Fmx * AoT + rdlane(bdx, j);
+                        const double dY = Fmy * AoT + rdlane(bdy, j);
+                        const double dZ = Fmz * AoT + rdlane(bdz, j);
+                        const double gx = Fnx - Fmx, gy = Fny - Fmy, gz = Fnz - Fmz;
+                        const double deltaW = (gx * gx + gy * gy + gz * gz +
+                                               2.0 * (gx * Fmx + gy * Fmy + gz * Fmz)) * Ao4T;
+                        const double arg = Un - Um +
+                                           (dX * (Fnx + Fmx) + dY * (Fny + Fmy) + dZ * (Fnz + Fmz)) * 0.5 + deltaW;
+                        const double lu = rdlane(bu, j);
+                        acc = uniform((int)(lu < -arg * a.invT)) != 0;
+                        if (acc) { E = uniform_d(E + (Un - Um)); jacc++; }
+                    }
+                    // inputs of the next iteration: particle n+1 becomes the moving one
+                    double qx = 0.0, qy = 0.0, qz = FAR_PROBE, bx = 0.0, by = 0.0, bz = FAR_PROBE;
+                    if (hasB) {
+                        const int src = acc ? SIDE_LANE_NEW : SIDE_LANE_OLD; // the (n, n+1) pair term
+                        Um = uniform_d(4.0 * (tot[4] + rdlane(side[0], src)));
+                        Fmx = uniform_d(tot[5] + rdlane(side[1], src));
+                        Fmy = uniform_d(tot[6] + rdlane(side[2], src));
+                        Fmz = uniform_d(tot[7] + rdlane(side[3], src));
+                        Px = Bx; Py = By; Pz = Bz;
+                        const int i1 = i + 1;
+                        if ((i1 & 63) == 0) { // the next 64 displacements / log-uniforms
+                            if (i1 + lane < len) {
+                                const int pn = first + i1 + lane;
+                                bdx = displ[3 * pn]; bdy = displ[3 * pn + 1]; bdz = displ[3 * pn + 2];
+                                bu = uni[vbase + i1 + lane];
+                            }
+                        }
+                        const int j1 = i1 & 63; // proposal, SMC.c:307-316
+                        qx = Px + (Fmx * AoT + rdlane(bdx, j1));
+                        qy = Py + (Fmy * AoT + rdlane(bdy, j1));
+                        qz = Pz + (Fmz * AoT + rdlane(bdz, j1));
+                        qx = qx - a.L * __builtin_rint(qx * a.invL);
+                        qy = qy - a.L * __builtin_rint(qy * a.invL);
+                        if (i1 + 1 < len) { bx = nBx; by = nBy; bz = nBz; }
+                        if (i1 + 2 < len) { // fetched now, used one move later
+                            nBx = ld_coherent(Rg + 3 * (first + i1 + 2));
+                            nBy = ld_coherent(Rg + 3 * (first + i1 + 2) + 1);
+                            nBz = ld_coherent(Rg + 3 * (first + i1 + 2) + 2);
+                        }
+                    }
+                    if (lane == 0) {
+                        sh.bc[0] = acc ? 1.0 : 0.0;
+                        sh.bc[1] = qx; sh.bc[2] = qy; sh.bc[3] = qz;
+                        sh.bc[4] = bx; sh.bc[5] = by; sh.bc[6] = bz;
+                        sh.bc[7] = (fmax(fmax(fabs(qx), fabs(qy)), fmax(fabs(bx), fabs(by))) <= a.edge) ? 1.0 : 0.0;
+                    }
+                }
+                __syncthreads(); // #2: the leader's verdict and the next probes are in LDS
+
+                const bool acc = uniform((int)(sh.bc[0] != 0.0)) != 0;
+                const bool upd = acc && (tid == tl);
+                x[0] = upd ? Qx : x[0]; y[0] = upd ? Qy : y[0]; z[0] = upd ? Qz : z[0];
+                if (upd) { Rg[3 * n] = Qx; Rg[3 * n + 1] = Qy; Rg[3 * n + 2] = Qz; }
+                Qx = uniform_d(sh.bc[1]); Qy = uniform_d(sh.bc[2]); Qz = uniform_d(sh.bc[3]);
+                Bx = uniform_d(sh.bc[4]); By = uniform_d(sh.bc[5]); Bz = uniform_d(sh.bc[6]);
+                interior = uniform((int)(sh.bc[7] != 0.0)) != 0;
+                if (hasB) {
+                    if (cross) { rotate1<S>(x, y, z); rot = (rot + 1 == S) ? 0 : rot + 1; tl = 0; }
+                    else tl++;
+                }
+            }
+        }
+        if (tid == 0) {
+            SweepRec r; r.E = E; r.accepted = jacc; r.pad = 0;
+            a.rec[(size_t)rep * a.chunk + sw] = r;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------
 // C: chain bookkeeping of sMC for the sweeps of one launch, in sweep order
 // (SMC.c:116-117, 194-195, 210-211, 244-250); one thread per replica
 // ---------------------------------------------------------------------------------
@@ -576,16 +773,18 @@ typedef void (*sweep_fn)(SweepArgs, DevCtx, int, double);
 // MINW (second __launch_bounds__ argument, waves per SIMD) caps the register
 // allocation: 96 VGPRs of positions at S=16 fit 3 waves/SIMD, S=32 fits 2, S=64 one.
 // G = slots per cutoff-test group (more independent chains for the single-wave S=64).
-static sweep_fn lookup(int S, int WPR)
+static sweep_fn lookup(int S, int WPR, bool lead = true)
 {
-#define SMCX_CASE(s, w, m, gg) if (S == s && WPR == w) return sweep_kernel<s, w, m, gg>;
-    SMCX_CASE(1, 1, 4, 1) SMCX_CASE(2, 1, 4, 2) SMCX_CASE(4, 1, 4, 2) SMCX_CASE(8, 1, 4, 2)
-    SMCX_CASE(16, 1, 3, 2) SMCX_CASE(32, 1, 2, 2) SMCX_CASE(64, 1, 1, 2)
+#define SMCX_CASE1(s, m, gg) if (S == s && WPR == 1) return sweep_kernel<s, 1, m, gg>;
+#define SMCX_CASE(s, w, m, gg) if (S == s && WPR == w) return lead ? sweep_kernel_lead<s, w, m, gg> : sweep_kernel<s, w, m, gg>;
+    SMCX_CASE1(1, 4, 1) SMCX_CASE1(2, 4, 2) SMCX_CASE1(4, 4, 2) SMCX_CASE1(8, 4, 2)
+    SMCX_CASE1(16, 3, 2) SMCX_CASE1(32, 2, 2) SMCX_CASE1(64, 1, 2)
     SMCX_CASE(8, 2, 4, 2) SMCX_CASE(16, 2, 3, 2) SMCX_CASE(32, 2, 2, 2)
     SMCX_CASE(4, 4, 4, 2) SMCX_CASE(8, 4, 4, 2) SMCX_CASE(16, 4, 3, 2) SMCX_CASE(32, 4, 2, 2)
     SMCX_CASE(8, 8, 4, 2) SMCX_CASE(16, 8, 3, 2) SMCX_CASE(32, 8, 2, 2)
     SMCX_CASE(16, 16, 4, 2) SMCX_CASE(32, 16, 2, 2)
 #undef SMCX_CASE
+#undef SMCX_CASE1
     return nullptr;
 }
 
@@ -599,7 +798,11 @@ hipError_t launch_rng_prepass(const DevCtx &c, int nsweeps, double A, hipStream_
 
 hipError_t launch_sweeps(const DevCtx &c, int S, int WPR, int nsweeps, double A, hipStream_t st)
 {
-    sweep_fn f = lookup(S, WPR);
+    // leader/follower form where it measured faster (profiles/r01_leader_follower.log): many
+    // waves with few slots each; SMCX_NO_LEAD / SMCX_LEAD force one form for A/B measurements
+    static const bool no_lead = getenv("SMCX_NO_LEAD") != nullptr, force_lead = getenv("SMCX_LEAD") != nullptr;
+    const bool lead = force_lead || (!no_lead && S <= 16 && WPR >= 4);
+    sweep_fn f = lookup(S, WPR, lead);
     if (!f) return hipErrorInvalidValue;
     SweepArgs a;
     a.N = c.N; a.chunk = c.chunk;
