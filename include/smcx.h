@@ -131,6 +131,14 @@ int smcx_density(smcx_handle *h, uint64_t *D, uint64_t *Mu);
  * at SMC.c:207-208, and with wallsPressure's geometry as the reference has it (SMC.c:880) */
 int smcx_pressure_series(smcx_handle *h, double *P, int *ngathers);
 
+/* Autocorrelation of the production energy series of the last run, as the reference's
+ * fft_acf computes it (SMC.c:1051-1089, called at SMC.c:234 with KMAX = 2500000), for
+ * every replica (needs SMCX_FLAG_SERIES): acf[nrep][*k_eff] with k_eff = k_max, or
+ * (maxsteps+1)/2 - 2 when the series is shorter than 2 k_max + 1 (SMC.c:1054-1057);
+ * tau[nrep] = sum(acf) (SMC.c:235); cv[nrep] = variance(E)/T^2 (SMC.c:250).  Pass acf = NULL
+ * to ask for k_eff only... all output pointers may be NULL. */
+int smcx_acf(smcx_handle *h, int k_max, double *acf, int *k_eff, double *tau, double *cv);
+
 /* current positions, [nrep][3N] (struct Sim.Rfinal, SMC.h:84) */
 int smcx_download_positions(smcx_handle *h, double *R);
 

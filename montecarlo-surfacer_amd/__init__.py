@@ -52,7 +52,7 @@ EXPORTS = [
     "smcx_default_params", "smcx_device_count", "smcx_create", "smcx_destroy", "smcx_strerror",
     "smcx_last_error_string", "smcx_upload", "smcx_run", "smcx_observables",
     "smcx_therm_acceptance", "smcx_hist_info", "smcx_series", "smcx_density",
-    "smcx_pressure_series", "smcx_download_positions",
+    "smcx_pressure_series", "smcx_acf", "smcx_download_positions",
     "smcx_total_energy", "smcx_rng_export", "smcx_rng_import", "smcx_obs_device_bytes",
     "smcx_export_observables_device", "smcx_last_kernel_ms", "smcx_last_run_ms", "smcx_geometry", "smcx_eval_moves",
     "smcx_rng_seed", "smcx_one_particle_moves",
@@ -84,6 +84,7 @@ def _lib():
         L.smcx_series.argtypes = [vp, _dp, _i32p]
         L.smcx_density.argtypes = [vp, _u64p, _u64p]
         L.smcx_pressure_series.argtypes = [vp, _dp, C.POINTER(C.c_int)]
+        L.smcx_acf.argtypes = [vp, C.c_int, _dp, C.POINTER(C.c_int), _dp, _dp]
         L.smcx_download_positions.argtypes = [vp, _dp]
         L.smcx_total_energy.argtypes = [vp, _dp]
         L.smcx_rng_export.argtypes = [vp, _u32p]
@@ -244,6 +245,19 @@ class Engine:
         P = np.zeros((self.p.nrep, max(n.value, 1)))
         self._chk(_lib().smcx_pressure_series(self._h, _p(P, C.c_double), C.byref(n)), "smcx_pressure_series")
         return P[:, :n.value]
+
+    def acf(self, k_max=2500000):
+        """fft_acf of the energy series (SMC.c:1051-1089): (acf[nrep][k], tau[nrep], cv[nrep])"""
+        k = C.c_int(0)
+        maxsteps_plus1 = None
+        # k_eff depends only on the series length; ask with a throw-away buffer sized for the worst case
+        tau = np.zeros(self.p.nrep); cv = np.zeros(self.p.nrep)
+        rc = _lib().smcx_acf(self._h, k_max, None, C.byref(k), _p(tau, C.c_double), _p(cv, C.c_double))
+        self._chk(rc, "smcx_acf")
+        acf = np.zeros((self.p.nrep, k.value))
+        self._chk(_lib().smcx_acf(self._h, k_max, _p(acf, C.c_double), C.byref(k), _p(tau, C.c_double),
+                                  _p(cv, C.c_double)), "smcx_acf")
+        return acf, tau, cv
 
     def positions(self):
         R = np.zeros((self.p.nrep, 3 * self.p.N))

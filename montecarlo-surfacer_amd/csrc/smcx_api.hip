@@ -558,6 +558,18 @@ extern "C" int smcx_series(smcx_handle *hh, double *E_series, int32_t *jj)
     return SMCX_OK;
 }
 
+// for smcx_acf.hip: where the energy series of the last run lives
+extern "C" int smcx_internal_series_view(smcx_handle *hh, const double **E, int *stride, int *maxsteps,
+                                          int *nrep, double *T, int *device, void **stream)
+{
+    if (!hh) return SMCX_ERR_PARAM;
+    Handle &h = hh->h;
+    if (!(h.p.flags & SMCX_FLAG_SERIES) || !h.c.Eseries) return SMCX_ERR_STATE;
+    *E = h.c.Eseries; *stride = h.c.series_stride; *maxsteps = h.last_maxsteps; *nrep = h.p.nrep;
+    *T = h.p.T; *device = h.p.device; *stream = (void *)h.stream;
+    return SMCX_OK;
+}
+
 extern "C" int smcx_density(smcx_handle *hh, uint64_t *D, uint64_t *Mu)
 {
     if (!hh) return SMCX_ERR_PARAM;

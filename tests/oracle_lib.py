@@ -255,3 +255,39 @@ def time_sweeps(s, seed, R, W, T, A, sweeps):
     acc = C.c_uint64(0)
     t = lib().orc_time_sweeps(C.byref(s), seed, _ptr(R), _ptr(W), T, A, sweeps, C.byref(acc))
     return t, acc.value
+
+
+def fft_acf(H, k_max):
+    """numpy restatement of the reference's fft_acf (SMC.c:1051-1089; FFTW is absent from the
+    image, so this row is pinned only against a direct O(n^2) evaluation of the same sums):
+    r2c transform of H - mean(H), |.|^2 of its first lfft = n/2 + n%2 bins, backward complex
+    transform of THAT length (FFTW_BACKWARD is unnormalised), acf[i] = Re C[i] / Re C[0]."""
+    H = np.asarray(H, dtype=np.float64)
+    n = len(H)
+    if n < k_max * 2 + 1:
+        k_max = n // 2 - 2                                     # SMC.c:1054-1057
+    lfft = n // 2 + n % 2                                      # SMC.c:1063
+    s = 0.0
+    for v in H:                                                # mean() adds in index order
+        s += v
+    Z = H - s / n
+    F = np.fft.rfft(Z)[:lfft]
+    T = (F * np.conj(F)).real + 0.0j
+    Cc = np.fft.ifft(T) * lfft
+    return (Cc.real[:k_max] / Cc.real[0]).copy()
+
+
+def fft_acf_direct(H, k_max):
+    """the same quantity from the defining sums, no FFT (O(n^2); small n only)"""
+    H = np.asarray(H, dtype=np.float64)
+    n = len(H)
+    if n < k_max * 2 + 1:
+        k_max = n // 2 - 2
+    lfft = n // 2 + n % 2
+    Z = H - H.sum() / n
+    j = np.arange(n)
+    F = np.array([(Z * np.exp(-2j * np.pi * k * j / n)).sum() for k in range(lfft)])
+    T = np.abs(F) ** 2
+    k = np.arange(lfft)
+    Cc = np.array([(T * np.exp(2j * np.pi * k * i / lfft)).sum() for i in range(k_max)])
+    return Cc.real / Cc.real[0]

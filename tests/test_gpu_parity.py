@@ -432,3 +432,24 @@ def test_csv_outputs_and_restart(S, O, tmp_path):
     eng2.run(0, 1, 1)
     assert eng2.observables()["zhist"][0].sum() == 256
     eng2.close()
+
+
+def test_energy_autocorrelation(S, O):
+    """8f.3: fft_acf of the production energy series (SMC.c:1051-1089, 234-235, 250) via hipFFT"""
+    R0 = O.fcc(4, 4)
+    for maxsteps in (40, 33):  # even and odd series length
+        eng, p = make_engine(S, O, R0, 3, flags=S.FLAGS_REFERENCE | S.FLAG_SERIES)
+        eng.run(0, maxsteps, 10)
+        Es, _ = eng.series(maxsteps)
+        acf, tau, cv = eng.acf()
+        ob = eng.observables()
+        k = (maxsteps + 1) // 2 - 2
+        assert acf.shape == (3, k)
+        for r in range(3):
+            ref = O.fft_acf(Es[r], 2500000)   # same series in, restated transform out
+            assert np.abs(acf[r] - ref).max() < 1e-9
+            assert abs(tau[r] - ref.sum()) < 1e-9 * max(1.0, abs(ref.sum()))
+            assert abs(cv[r] - ob["dE"][r] ** 2 / 1.1 ** 2) < 1e-12 * max(1.0, cv[r])
+        acf5, _, _ = eng.acf(k_max=5)
+        assert acf5.shape == (3, 5) and np.abs(acf5 - acf[:, :5]).max() < 1e-12
+        eng.close()

@@ -307,3 +307,13 @@ def test_pressure_restatement(O):
         acc += (24.0 * W[2 * m + 1] / q[k] ** 3 - 48.0 * W[2 * m] / q[k] ** 6).sum()
         acc += (24.0 * s.b0 / dz[k] ** 6 - 48.0 * s.a0 / dz[k] ** 12).sum()
     assert abs(Pw - (-acc / (3 * 8.0 * 8.0 * 8.0))) < 1e-9 * abs(Pw)
+
+
+def test_fft_acf_restatement(O):
+    """8f.3: the FFT form of the reference's autocorrelation against its defining sums"""
+    rs = np.random.RandomState(8)
+    for n, kmax in ((64, 10), (65, 10), (41, 2500000), (200, 2500000)):
+        H = -300 + np.cumsum(rs.standard_normal(n))
+        a, b = O.fft_acf(H, kmax), O.fft_acf_direct(H, kmax)
+        assert len(a) == len(b) == (kmax if n >= 2 * kmax + 1 else n // 2 - 2)
+        assert a[0] == 1.0 and np.abs(a - b).max() < 1e-10
