@@ -186,6 +186,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "smcx::sweep_kernel<S=%d,WPR=%d>" % (S_, W_),
                          "launches": launches, "avg_launch_ms": sweep_ms / max(launches, 1),
+                         "ms_per_sweep": sweep_ms / a.steps,
                          "algorithmic_bytes_per_launch": algo_bytes_per_launch,
                          "note": "algorithmic bytes = 24 B x pair-evals (streaming model, SURVEY 8d); "
                                  "positions are register-resident, so frac > 1 is legitimate and the "
