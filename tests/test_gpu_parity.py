@@ -453,3 +453,37 @@ def test_energy_autocorrelation(S, O):
         acf5, _, _ = eng.acf(k_max=5)
         assert acf5.shape == (3, 5) and np.abs(acf5 - acf[:, :5]).max() < 1e-12
         eng.close()
+
+
+@pytest.mark.parametrize("N", [66, 130, 1000, 2050, 4000])
+def test_ragged_sizes_with_padding(S, O, N):
+    """N that does not fill the launch geometry (padding lanes/slots, partial last slot, runs
+    that wrap inside a slot): two free-running sweeps against the oracle"""
+    rs = np.random.RandomState(N)
+    Na = int(np.ceil((N / 4.0) ** (1 / 3.0))) + 1
+    R0 = O.fcc(Na, Na).reshape(-1, 3)
+    R0 = R0[rs.permutation(len(R0))[:N]].ravel().copy()
+    nrep = 3
+    eng, p = make_engine(S, O, R0, nrep)
+    assert eng.geometry[0] * eng.geometry[1] * 64 >= N
+    eng.run(0, 2, 1)
+    ob = eng.observables()
+    Rg = eng.positions()
+    s = sys_of(O, p)
+    for r in range(nrep):
+        ref = O.chain(s, 12345 + r, R0, O.W_FIXTURE, T, A, 0, 2, 1)
+        assert int(ob["accepted"][r]) == ref["accepted"], (N, r)
+        assert rel(ob["E_last"][r], ref["Efinal"], 1e-9) < 1e-9
+        assert np.abs(Rg[r] - ref["R"]).max() < 1e-8
+        assert np.array_equal(ob["zhist"][r], ref["zhist"])
+    eng.close()
+
+
+def test_upload_rejects_unwrapped_positions(S, O):
+    R0 = O.fcc(4, 4)
+    R0[0] = 20.0  # outside [-L/2, L/2]
+    eng = S.Engine(S.default_params(256, 1))
+    with pytest.raises(S.SmcxError) as e:
+        eng.upload(R0, O.W_FIXTURE)
+    assert e.value.status == S.ERR_PARAM
+    eng.close()
