@@ -160,6 +160,7 @@ def main():
         launch_s = sweep_ms * 1e-3 / max(launches, 1)
         achieved = algo_bytes_per_launch / launch_s / 1e9
         traffic = None
+        valu = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
@@ -167,6 +168,17 @@ def main():
                 key = "N%d_R%d_S%d_W%d" % (N, nrep, S_, W_)
                 if key in tj:
                     traffic = tj[key]["hbm_bytes_per_sweep"] * (a.steps / max(launches, 1))  # per launch
+                    if "valu_wave_instr_per_sweep" in tj[key]:
+                        wi = tj[key]["valu_wave_instr_per_sweep"]
+                        # what actually binds the kernel: VALU issue (one fp64 wave-instruction per
+                        # ~4.1 clocks per SIMD, 1024 SIMDs), from the committed PMC run
+                        valu = {"wave_instr_per_sweep": wi,
+                                "wave_instr_per_64_pair_evals": wi / (nrep * 2.0 * N * (N - 1.0) / 64.0),
+                                "floor_wave_instr_per_64_pair_evals": 7.0,
+                                "issue_slots_used": wi * 4.1 / (sweep_ms * 1e-3 / a.steps * 1024 * 2.15e9),
+                                "note": "SQ_INSTS_VALU from profiles/r01_pmc_summary.txt; 4.1 clocks per fp64 "
+                                        "wave-instruction and 2.15 GHz under load are measured "
+                                        "(profiles/r01_valu_issue_costs.log)"}
             except Exception:
                 traffic = None
         out = {
@@ -191,6 +203,7 @@ def main():
                          "note": "algorithmic bytes = 24 B x pair-evals (streaming model, SURVEY 8d); "
                                  "positions are register-resident, so frac > 1 is legitimate and the "
                                  "binding resource is fp64 VALU issue, not HBM"},
+            "valu": valu,
             "device_ms": {"sweep_kernels": sweep_ms, "whole_run": run_ms},
             "observables": {"mean_acceptance": summ["mean_acceptance"], "mean_energy": summ["mean_of_meanE"],
                             "replicas_gathered": int(len(obs["accepted"]))},
