@@ -53,6 +53,7 @@ extern "C" {
                                      columns, SMC.c:214-215) for the last smcx_run */
 #define SMCX_FLAG_FULL_HIST 0x8u   /* keep the full Ncx x Ncx x Ncz density and mobility counters of
                                      localDensityAndMobility (local_*.csv, SMC.c:218-225) */
+#define SMCX_FLAG_CLUSTERS 0x20u   /* clusterAnalysis every lca_time-th gather (SMC.c:143-155) */
 #define SMCX_FLAG_PRESSURE 0x10u   /* evaluate pressure + wallsPressure at every gather (SMC.c:140) */
 #define SMCX_FLAGS_REFERENCE (SMCX_FLAG_WALLS | SMCX_FLAG_E0_RESTART)
 
@@ -72,6 +73,9 @@ typedef struct smcx_params {
     uint32_t first_replica; /* global index of this handle's first replica (multi-GPU shard) */
     int32_t tune_slots;     /* 0 = auto; else particles per lane (1,2,4,...,64) */
     int32_t tune_waves;     /* 0 = auto; else wavefronts per replica (1,2,4,8,16) */
+    int32_t lca_time;       /* LCA_TIME: cluster analysis every lca_time-th gather (SMC.h:48) */
+    int32_t reserved0;
+    double lca_cutoff;      /* LCA_cutoff (SMC.h:50) */
 } smcx_params;
 
 /* fills *p with the reference's defaults (SMC.h macros, main.c:35-51: L=33,
@@ -130,6 +134,26 @@ int smcx_density(smcx_handle *h, uint64_t *D, uint64_t *Mu);
  * SMCX_FLAG_PRESSURE): P[nrep][ngathers]; without the ideal-gas term rho*T the reference adds
  * at SMC.c:207-208, and with wallsPressure's geometry as the reference has it (SMC.c:880) */
 int smcx_pressure_series(smcx_handle *h, double *P, int *ngathers);
+
+/* ---- common-neighbour cluster analysis (clusterAnalysis, SMC.h:116, SMC.c:971-1045) ----
+ * With SMCX_FLAG_CLUSTERS smcx_run analyses every replica at the gathers k with
+ * k % lca_time == 0 (k = 1, 2, ... counts gathers, SMC.c:138, 143) and accumulates, per replica,
+ * what the loop at SMC.c:146-155 walks over: n1 = pair entries with num1 != 0, h2[v] / h3[v] =
+ * those of them with num2 == v / num3 == v (v > 15 lands in bin 15).  These are plain counts:
+ * the reference adds the weight 1/(gather_steps/LCA_TIME) -- an int division, 0 unless the
+ * ratio is 1 -- into l1, l2[num2], l3[num3]; a caller applies whatever weight it wants.
+ * The reference's pair index (l*l-3*l+2)/2+i, under which (l,l-1) and (l+1,0) share an entry,
+ * its (i,i2) look-up for i > i2 and its consecutive-only bond test are reproduced exactly;
+ * stores past its common_nn[8] (undefined behaviour there) are dropped and counted in
+ * `overflow`.  Any output pointer may be NULL.  Counters restart at every smcx_run. */
+int smcx_cluster_counts(smcx_handle *h, uint64_t *n1 /*[nrep]*/, uint64_t *h2 /*[nrep][16]*/,
+                        uint64_t *h3 /*[nrep][16]*/, uint64_t *overflow /*[nrep]*/,
+                        int *analyses);
+/* analyse the positions as they are now and add to the counters (any flags) */
+int smcx_cluster_update(smcx_handle *h);
+/* clusterAnalysis(r, N, L, LCA) for one replica's current positions: LCA[3*idx + {0,1,2}] =
+ * num1, num2, num3, N(N-1)/2 entries (SMC.c:1038-1044); counters are not touched */
+int smcx_cluster_analysis(smcx_handle *h, int replica, int32_t *LCA, uint64_t *overflow);
 
 /* Autocorrelation of the production energy series of the last run, as the reference's
  * fft_acf computes it (SMC.c:1051-1089, called at SMC.c:234 with KMAX = 2500000), for

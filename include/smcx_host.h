@@ -42,7 +42,7 @@ void smcx_host_initialize_walls(double x0m, double x0sigma, double ymm, double y
 void smcx_host_box_for_N(int N, double *L, double *Lz);
 
 /* ensemble results of one smcx_host_sMC call (struct Sim, SMC.h:76-88, per replica
- * and averaged over replicas; pressure, cluster analysis and ACF are not computed) */
+ * and averaged over replicas; pressure and ACF come from smcx_pressure_series / smcx_acf) */
 typedef struct smcx_sim {
     int nrep, N, Ncz;
     double E, dE;              /* ensemble mean of the replicas' mean energy / of their dE */
@@ -53,6 +53,12 @@ typedef struct smcx_sim {
     double *rep_acceptance;    /* [nrep] */
     double *zprofile;          /* [Ncz] particles per z cell per gather, ensemble mean */
     double *Rfinal;            /* [nrep][3N] */
+    /* cluster analysis (SMCX_FLAG_CLUSTERS): bonded pair entries, and those with num2 == v /
+     * num3 == v, per analysis and replica (ensemble mean).  This is what the weight at
+     * SMC.c:149-153 is after; the reference's own `1 / (gather_steps/LCA_TIME)` is an int
+     * division (0 unless the ratio is 1) added into uninitialised l2[7], l3[7]. */
+    double l1, l2[16], l3[16];
+    int lca_analyses;
     double kernel_ms;          /* device time of the sweep kernels */
     double pair_evals_per_s;   /* nrep*maxsteps*2N(N-1) / kernel time */
 } smcx_sim;

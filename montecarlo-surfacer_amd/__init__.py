@@ -18,7 +18,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsmcx.so")
 
 OK, ERR_PARAM, ERR_HIP, ERR_STATE, ERR_NOMEM, ERR_UNSUPPORTED, ERR_NODEVICE = range(7)
-FLAG_WALLS, FLAG_E0_RESTART, FLAG_SERIES, FLAG_FULL_HIST, FLAG_PRESSURE = 1, 2, 4, 8, 16
+FLAG_WALLS, FLAG_E0_RESTART, FLAG_SERIES, FLAG_FULL_HIST, FLAG_PRESSURE, FLAG_CLUSTERS = 1, 2, 4, 8, 16, 32
 FLAGS_REFERENCE = FLAG_WALLS | FLAG_E0_RESTART
 OBS_RECORD_DOUBLES = 8
 
@@ -30,7 +30,8 @@ class Params(C.Structure):
                 ("cutoff", C.c_double), ("a0", C.c_double), ("b0", C.c_double),
                 ("Ncx", C.c_int32), ("Ncz", C.c_int32), ("flags", C.c_uint32),
                 ("base_seed", C.c_uint32), ("first_replica", C.c_uint32),
-                ("tune_slots", C.c_int32), ("tune_waves", C.c_int32)]
+                ("tune_slots", C.c_int32), ("tune_waves", C.c_int32),
+                ("lca_time", C.c_int32), ("reserved0", C.c_int32), ("lca_cutoff", C.c_double)]
 
 
 class SmcxError(RuntimeError):
@@ -56,6 +57,7 @@ EXPORTS = [
     "smcx_total_energy", "smcx_rng_export", "smcx_rng_import", "smcx_obs_device_bytes",
     "smcx_export_observables_device", "smcx_last_kernel_ms", "smcx_last_run_ms", "smcx_geometry", "smcx_eval_moves",
     "smcx_rng_seed", "smcx_one_particle_moves",
+    "smcx_cluster_counts", "smcx_cluster_update", "smcx_cluster_analysis",
 ]
 
 
@@ -84,6 +86,9 @@ def _lib():
         L.smcx_series.argtypes = [vp, _dp, _i32p]
         L.smcx_density.argtypes = [vp, _u64p, _u64p]
         L.smcx_pressure_series.argtypes = [vp, _dp, C.POINTER(C.c_int)]
+        L.smcx_cluster_counts.argtypes = [vp, _u64p, _u64p, _u64p, _u64p, C.POINTER(C.c_int)]
+        L.smcx_cluster_update.argtypes = [vp]
+        L.smcx_cluster_analysis.argtypes = [vp, C.c_int, _i32p, _u64p]
         L.smcx_acf.argtypes = [vp, C.c_int, _dp, C.POINTER(C.c_int), _dp, _dp]
         L.smcx_download_positions.argtypes = [vp, _dp]
         L.smcx_total_energy.argtypes = [vp, _dp]
@@ -245,6 +250,30 @@ class Engine:
         P = np.zeros((self.p.nrep, max(n.value, 1)))
         self._chk(_lib().smcx_pressure_series(self._h, _p(P, C.c_double), C.byref(n)), "smcx_pressure_series")
         return P[:, :n.value]
+
+    def cluster_counts(self):
+        """counts behind l1, l2[], l3[] of SMC.c:146-155: (n1[nrep], h2[nrep][16], h3[nrep][16],
+        overflow[nrep], analyses)"""
+        n = self.p.nrep
+        n1 = np.zeros(n, dtype=np.uint64); ov = np.zeros(n, dtype=np.uint64)
+        h2 = np.zeros((n, 16), dtype=np.uint64); h3 = np.zeros((n, 16), dtype=np.uint64)
+        k = C.c_int(0)
+        self._chk(_lib().smcx_cluster_counts(self._h, _p(n1, C.c_uint64), _p(h2, C.c_uint64),
+                                             _p(h3, C.c_uint64), _p(ov, C.c_uint64), C.byref(k)),
+                  "smcx_cluster_counts")
+        return n1, h2, h3, ov, k.value
+
+    def cluster_update(self):
+        self._chk(_lib().smcx_cluster_update(self._h), "smcx_cluster_update")
+
+    def cluster_analysis(self, replica=0):
+        """clusterAnalysis (SMC.c:971-1045) of one replica: (LCA[N(N-1)/2][3], overflow)"""
+        npairs = self.p.N * (self.p.N - 1) // 2
+        LCA = np.zeros((npairs, 3), dtype=np.int32)
+        ov = np.zeros(1, dtype=np.uint64)
+        self._chk(_lib().smcx_cluster_analysis(self._h, replica, _p(LCA, C.c_int32), _p(ov, C.c_uint64)),
+                  "smcx_cluster_analysis")
+        return LCA, int(ov[0])
 
     def acf(self, k_max=2500000):
         """fft_acf of the energy series (SMC.c:1051-1089): (acf[nrep][k], tau[nrep], cv[nrep])"""

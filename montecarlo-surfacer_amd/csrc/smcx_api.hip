@@ -37,6 +37,12 @@ struct Handle {
     std::vector<hipEvent_t> evs; // start/stop pairs around the sweep launches
     std::vector<int> last_sweeps; // sweeps in each launch of the last run
     int last_gathers = 0;
+    // cluster analysis (SMCX_FLAG_CLUSTERS or on demand)
+    unsigned *lca_bits = nullptr;          // [lca_batch][lca_words]
+    unsigned long long *lca_counts = nullptr; // [nrep + 1][LCA_COUNTS]; the last row is scratch
+    long lca_words = 0;
+    int lca_batch = 0;
+    int lca_analyses = 0;
     std::string err;
 };
 
@@ -104,6 +110,8 @@ extern "C" void smcx_default_params(smcx_params *p, int32_t N, int32_t nrep)
     p->flags = SMCX_FLAGS_REFERENCE;
     p->base_seed = 12345;
     p->first_replica = 0;
+    p->lca_time = 10;                // SMC.h:48
+    p->lca_cutoff = 1.7;             // SMC.h:50
 }
 
 extern "C" const char *smcx_strerror(int status)
@@ -152,6 +160,8 @@ static int validate(const smcx_params *p)
         if (p->M < 1) return SMCX_ERR_PARAM;
         if (p->M * p->M + 1 > 30) return SMCX_ERR_UNSUPPORTED;
     }
+    if ((p->flags & SMCX_FLAG_CLUSTERS) && (p->lca_time < 1 || !(p->lca_cutoff > 0)))
+        return SMCX_ERR_PARAM;
     return SMCX_OK;
 }
 
@@ -217,6 +227,7 @@ extern "C" int smcx_destroy(smcx_handle *hh)
     hipFree(c.uni); hipFree(c.offs); hipFree(c.obs); hipFree(c.zhist); hipFree(c.Eseries);
     hipFree(c.jjseries); hipFree(c.rec); hipFree(h.d_save); hipFree(h.d_tmp);
     hipFree(c.D); hipFree(c.Mu); hipFree(c.Rbin); hipFree(c.Pseries);
+    hipFree(h.lca_bits); hipFree(h.lca_counts);
     for (hipEvent_t e : h.evs) hipEventDestroy(e);
     if (h.ev0) hipEventDestroy(h.ev0);
     if (h.ev1) hipEventDestroy(h.ev1);
@@ -354,6 +365,48 @@ extern "C" int smcx_upload(smcx_handle *hh, const double *R0, int r0_per_replica
     return SMCX_OK;
 }
 
+// buffers of the cluster analysis: the bit matrices of a batch of replicas (at most ~8 GB)
+// and the per-replica counters
+static int ensure_lca(Handle &h)
+{
+    if (h.lca_counts) return SMCX_OK;
+    if (!(h.p.lca_cutoff > 0)) return SMCX_ERR_PARAM;
+    const long np = (long)h.p.N * (h.p.N - 1) / 2;
+    h.lca_words = (np + 31) / 32 + 1;
+    long batch = (long)(8.0e9 / (4.0 * h.lca_words));
+    if (batch < 1) batch = 1;
+    if (batch > h.p.nrep) batch = h.p.nrep;
+    if (batch > 65535) batch = 65535; // gridDim.y
+    h.lca_batch = (int)batch;
+    HIPCHK(&h, hipMalloc(&h.lca_bits, (size_t)batch * h.lca_words * sizeof(unsigned)));
+    HIPCHK(&h, hipMalloc(&h.lca_counts, ((size_t)h.p.nrep + 1) * LCA_COUNTS * sizeof(unsigned long long)));
+    HIPCHK(&h, hipMemsetAsync(h.lca_counts, 0, ((size_t)h.p.nrep + 1) * LCA_COUNTS * sizeof(unsigned long long), h.stream));
+    return SMCX_OK;
+}
+
+static LcaArgs lca_args(const Handle &h)
+{
+    LcaArgs a;
+    a.N = h.p.N; a.rep0 = 0;
+    a.L = h.p.L; a.cut2 = h.p.lca_cutoff * h.p.lca_cutoff;
+    a.R = h.c.R; a.bits = h.lca_bits; a.words = h.lca_words;
+    a.counts = h.lca_counts; a.LCA = nullptr;
+    return a;
+}
+
+// clusterAnalysis of every replica, batch by batch (SMC.c:145)
+static int lca_all(Handle &h)
+{
+    LcaArgs a = lca_args(h);
+    for (int r0 = 0; r0 < h.p.nrep; r0 += h.lca_batch) {
+        a.rep0 = r0;
+        const int nb = (h.p.nrep - r0 < h.lca_batch) ? h.p.nrep - r0 : h.lca_batch;
+        HIPCHK(&h, launch_lca(a, nb, h.stream));
+    }
+    h.lca_analyses++;
+    return SMCX_OK;
+}
+
 static int ensure_series(Handle &h, int maxsteps)
 {
     DevCtx &c = h.c;
@@ -387,6 +440,10 @@ static int run_phase(Handle &h, int steps, double A, int production, int gather_
                 if (h.c.Pseries) HIPCHK(&h, launch_pressure(h.c, h.last_gathers, h.stream));
                 HIPCHK(&h, launch_hist(h.c, h.stream));
                 h.last_gathers++;
+                if ((h.p.flags & SMCX_FLAG_CLUSTERS) && h.last_gathers % h.p.lca_time == 0) { // SMC.c:143
+                    const int rc = lca_all(h);
+                    if (rc != SMCX_OK) return rc;
+                }
             }
             // next sweep index n > done with (n+1) % gather_lapse == 0
             const int next = ((done + 1) / gather_lapse + 1) * gather_lapse - 1;
@@ -437,6 +494,12 @@ extern "C" int smcx_run(smcx_handle *hh, int eqsteps, int maxsteps, int gather_l
             HIPCHK(&h, hipMalloc(&h.c.Pseries, (size_t)h.p.nrep * need * sizeof(double)));
         }
         HIPCHK(&h, hipMemsetAsync(h.c.Pseries, 0, (size_t)h.p.nrep * h.c.pstride * sizeof(double), h.stream));
+    }
+    if (h.p.flags & SMCX_FLAG_CLUSTERS) { // l1, l2, l3 start from zero in every sMC call (SMC.c:58-60)
+        rc = ensure_lca(h);
+        if (rc != SMCX_OK) return rc;
+        HIPCHK(&h, hipMemsetAsync(h.lca_counts, 0, ((size_t)h.p.nrep + 1) * LCA_COUNTS * sizeof(unsigned long long), h.stream));
+        h.lca_analyses = 0;
     }
     // zero the accumulators, remember E at entry (the reference's E[0])
     HIPCHK(&h, launch_obs_op(h.c, h.d_save, 0, h.stream));
@@ -579,6 +642,74 @@ extern "C" int smcx_density(smcx_handle *hh, uint64_t *D, uint64_t *Mu)
     const size_t bytes = (size_t)h.p.nrep * h.p.Ncx * h.p.Ncx * h.p.Ncz * sizeof(uint64_t);
     if (D) HIPCHK(&h, hipMemcpy(D, h.c.D, bytes, hipMemcpyDeviceToHost));
     if (Mu) HIPCHK(&h, hipMemcpy(Mu, h.c.Mu, bytes, hipMemcpyDeviceToHost));
+    return SMCX_OK;
+}
+
+extern "C" int smcx_cluster_update(smcx_handle *hh)
+{
+    if (!hh) return SMCX_ERR_PARAM;
+    Handle &h = hh->h;
+    if (!h.uploaded) return SMCX_ERR_STATE;
+    HIPCHK(&h, hipSetDevice(h.p.device));
+    int rc = ensure_lca(h);
+    if (rc != SMCX_OK) return rc;
+    rc = lca_all(h);
+    if (rc != SMCX_OK) return rc;
+    HIPCHK(&h, hipStreamSynchronize(h.stream));
+    return SMCX_OK;
+}
+
+extern "C" int smcx_cluster_counts(smcx_handle *hh, uint64_t *n1, uint64_t *h2, uint64_t *h3,
+                                   uint64_t *overflow, int *analyses)
+{
+    if (!hh) return SMCX_ERR_PARAM;
+    Handle &h = hh->h;
+    if (!h.lca_counts) return SMCX_ERR_STATE;
+    HIPCHK(&h, hipSetDevice(h.p.device));
+    const size_t nrep = h.p.nrep;
+    std::vector<unsigned long long> tmp(nrep * LCA_COUNTS);
+    HIPCHK(&h, hipMemcpy(tmp.data(), h.lca_counts, tmp.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    for (size_t r = 0; r < nrep; r++) {
+        const unsigned long long *c = &tmp[r * LCA_COUNTS];
+        if (n1) n1[r] = c[0];
+        for (int v = 0; v < 16; v++) {
+            if (h2) h2[r * 16 + v] = c[1 + v];
+            if (h3) h3[r * 16 + v] = c[17 + v];
+        }
+        if (overflow) overflow[r] = c[33];
+    }
+    if (analyses) *analyses = h.lca_analyses;
+    return SMCX_OK;
+}
+
+extern "C" int smcx_cluster_analysis(smcx_handle *hh, int replica, int32_t *LCA, uint64_t *overflow)
+{
+    if (!hh || !LCA) return SMCX_ERR_PARAM;
+    Handle &h = hh->h;
+    if (!h.uploaded) return SMCX_ERR_STATE;
+    if (replica < 0 || replica >= h.p.nrep) return SMCX_ERR_PARAM;
+    HIPCHK(&h, hipSetDevice(h.p.device));
+    int rc = ensure_lca(h);
+    if (rc != SMCX_OK) return rc;
+    const size_t np = (size_t)h.p.N * (h.p.N - 1) / 2;
+    int *d_lca = nullptr;
+    HIPCHK(&h, hipMalloc(&d_lca, 3 * np * sizeof(int)));
+    hipError_t e = hipMemsetAsync(d_lca, 0, 3 * np * sizeof(int), h.stream);
+    // counters of this call go to the scratch row: shift the base so that row `replica` is it
+    unsigned long long *scratch = h.lca_counts + (size_t)h.p.nrep * LCA_COUNTS;
+    if (e == hipSuccess) e = hipMemsetAsync(scratch, 0, LCA_COUNTS * sizeof(unsigned long long), h.stream);
+    LcaArgs a = lca_args(h);
+    a.rep0 = replica;
+    a.counts = scratch - (size_t)replica * LCA_COUNTS;
+    a.LCA = d_lca;
+    if (e == hipSuccess) e = launch_lca(a, 1, h.stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h.stream);
+    if (e == hipSuccess) e = hipMemcpy(LCA, d_lca, 3 * np * sizeof(int), hipMemcpyDeviceToHost);
+    unsigned long long ov = 0;
+    if (e == hipSuccess) e = hipMemcpy(&ov, scratch + 33, sizeof(ov), hipMemcpyDeviceToHost);
+    hipFree(d_lca);
+    HIPCHK(&h, e);
+    if (overflow) *overflow = ov;
     return SMCX_OK;
 }
 

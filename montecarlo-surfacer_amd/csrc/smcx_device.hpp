@@ -70,6 +70,18 @@ struct DevCtx {
     int pstride;
 };
 
+// cluster analysis (smcx_lca.hip): per-replica counters n1, h2[16], h3[16], dropped stores
+constexpr int LCA_COUNTS = 34;
+struct LcaArgs {
+    int N, rep0;                  // rep0: first replica of this batch
+    double L, cut2;               // LCA_cutoff^2 (SMC.h:50)
+    const double *R;              // [nrep][3N]
+    unsigned *bits;               // [batch][words] num1 as a bit matrix
+    long words;                   // 32-bit words per replica
+    unsigned long long *counts;   // [nrep][LCA_COUNTS]
+    int *LCA;                     // optional [3*N(N-1)/2] output of a single replica
+};
+
 // the (few) things the hot kernel needs; everything cold stays in DevCtx
 struct SweepArgs {
     int N, chunk;

@@ -13,6 +13,8 @@ hipError_t launch_finalize(const DevCtx &c, int nsweeps, int production, int swe
                            int first_production, hipStream_t st);
 hipError_t launch_hist(const DevCtx &c, hipStream_t st);
 hipError_t launch_pressure(const DevCtx &c, int gather, hipStream_t st);
+// clusterAnalysis of replicas a.rep0 .. a.rep0+nbatch-1, counters accumulated (smcx_lca.hip)
+hipError_t launch_lca(const LcaArgs &a, int nbatch, hipStream_t st);
 hipError_t launch_total_energy(const DevCtx &c, double *out, hipStream_t st);
 hipError_t launch_eval_moves(const DevCtx &c, const int *nsel, const double *prop, double *out,
                              hipStream_t st);

@@ -181,6 +181,23 @@ int smcx_host_sMC(const smcx_params *p, const double *W, const double *R0, int m
         }
         if (gsum > 0)
             for (int k = 0; k < Ncz; k++) out->zprofile[k] /= gsum;
+        if (p->flags & SMCX_FLAG_CLUSTERS) {
+            uint64_t *c = (uint64_t *)calloc((size_t)nrep * 33, sizeof(uint64_t));
+            if (!c) { rc = SMCX_ERR_NOMEM; break; }
+            rc = smcx_cluster_counts(h, c, c + nrep, c + (size_t)nrep * 17, NULL, &out->lca_analyses);
+            if (rc == SMCX_OK && out->lca_analyses > 0) {
+                const double w = 1.0 / ((double)nrep * out->lca_analyses);
+                for (int r = 0; r < nrep; r++) {
+                    out->l1 += w * (double)c[r];
+                    for (int v = 0; v < 16; v++) {
+                        out->l2[v] += w * (double)c[nrep + (size_t)r * 16 + v];
+                        out->l3[v] += w * (double)c[(size_t)nrep * 17 + (size_t)r * 16 + v];
+                    }
+                }
+            }
+            free(c);
+            if (rc != SMCX_OK) break;
+        }
         int launches = 0;
         smcx_last_kernel_ms(h, &out->kernel_ms, &launches);
         if (out->kernel_ms > 0)

@@ -34,6 +34,7 @@ int main(int argc, char **argv)
     smcx_host_box_for_N(N, &p.L, &p.Lz);
     p.T = T;
     p.A = 1.0 * T; /* gamma = 1, main.c:48-51 */
+    p.flags |= SMCX_FLAG_CLUSTERS; /* sMC always runs the cluster analysis (SMC.c:143-155) */
 
     double W[2 * 3 * 3];
     smcx_host_initialize_walls(1.6, 0.0, 3.0, 0.5, p.M, 0.0, W); /* main.c:74-87 */
@@ -65,6 +66,13 @@ int main(int argc, char **argv)
     printf("\nMean energy: %f +- %f", sim.E, sim.dE);
     printf("\nAverage acceptance ratio: %f (thermalisation %f)", sim.acceptance_ratio, sim.therm_acceptance);
     printf("\nDevice time %0.1f ms, %0.3e pair-evals/s", sim.kernel_ms, sim.pair_evals_per_s);
+    if (sim.lca_analyses > 0) { /* SMC.c:227-231 */
+        printf("\nl1[1] = %0.9f (%d analyses)", sim.l1, sim.lca_analyses);
+        printf("\nl2[0..5] =");
+        for (int v = 0; v < 6; v++) printf(" %0.9f", sim.l2[v]);
+        printf("\nl3[0..5] =");
+        for (int v = 0; v < 6; v++) printf(" %0.9f", sim.l3[v]);
+    }
     printf("\nz profile (particles per cell per gather):");
     for (int k = 0; k < sim.Ncz; k++) printf(" %0.3f", sim.zprofile[k]);
     printf("\n");

@@ -420,7 +420,22 @@ int orc_chain_p(const orc_sys *s, unsigned int seed, double *R, const double *W,
                 unsigned int flags, double *E_series, int32_t *jj_out, uint64_t *zhist,
                 uint64_t *D_out, uint64_t *Mu_out, double *P_gathers, orc_chain_result *res)
 {
+    return orc_chain_lca(s, seed, R, W, T, A, eqsteps, maxsteps, gather_lapse, flags, E_series,
+                         jj_out, zhist, D_out, Mu_out, P_gathers, 0, 0.0, NULL, res);
+}
+
+int orc_chain_lca(const orc_sys *s, unsigned int seed, double *R, const double *W,
+                  double T, double A, int eqsteps, int maxsteps, int gather_lapse,
+                  unsigned int flags, double *E_series, int32_t *jj_out, uint64_t *zhist,
+                  uint64_t *D_out, uint64_t *Mu_out, double *P_gathers, int lca_time,
+                  double lca_cutoff, orc_lca_counts *lca, orc_chain_result *res)
+{
     const int N = s->N;
+    int32_t *LCA = NULL;
+    if (lca && lca_time > 0) {
+        memset(lca, 0, sizeof(*lca));
+        LCA = (int32_t *)calloc(3 * ((size_t)N * (N - 1) / 2) + 3, sizeof(int32_t));
+    }
     const size_t Nc = (size_t)s->Ncx * s->Ncx * s->Ncz;
     if (N < 1 || maxsteps < 0 || eqsteps < 0 || gather_lapse < 1)
         return -1;
@@ -456,6 +471,12 @@ int orc_chain_p(const orc_sys *s, unsigned int seed, double *R, const double *W,
                 P_gathers[gathers] = orc_pressure(s, R) + orc_walls_pressure(s, R, W);
             orc_local_density(s, R, D, Rbin, Mu, &oob);
             gathers++;
+            const int k = (n + 1) / gather_lapse; /* SMC.c:138 */
+            if (LCA && k % lca_time == 0) {       /* SMC.c:143-155 */
+                orc_cluster_analysis(N, R, s->L, lca_cutoff, LCA, &lca->overflow);
+                orc_cluster_counts(N, LCA, lca);
+                lca->analyses++;
+            }
         }
         E[n + 1] = E[n]; /* SMC.c:194: production restarts from E[0] */
         int jtmp = 0;
@@ -508,8 +529,99 @@ int orc_chain_p(const orc_sys *s, unsigned int seed, double *R, const double *W,
         memcpy(D_out, D, Nc * sizeof(uint64_t));
     if (Mu_out)
         memcpy(Mu_out, Mu, Nc * sizeof(uint64_t));
-    free(E); free(Rn); free(jj); free(jt); free(Rbin); free(D); free(Mu);
+    free(E); free(Rn); free(jj); free(jt); free(Rbin); free(D); free(Mu); free(LCA);
     return 0;
+}
+
+/* ------------------------------------------------------------------------ */
+/* LCA  common-neighbour cluster analysis, SMC.c:971-1045, with the          */
+/* reference's arithmetic kept as written:                                   */
+/*  - the pair index (l*l-3*l+2)/2 + i advances by l-1 per row although row  */
+/*    l has l entries, so (l,l-1) and (l+1,0) share an entry: num1 is the OR */
+/*    of the two, num2/num3 accumulate over both (in that order, which is    */
+/*    also consecutive in the loop, so common_nn simply grows);              */
+/*  - the i-i2 entry is taken at (i2*i2-3*i2+2)/2 + i also when i > i2;      */
+/*  - only consecutive common neighbours (m-1, m) are tested for a bond.     */
+/* common_nn has 8 slots in the reference and is written without a bound     */
+/* (undefined behaviour past 8): here such stores and the reads of slots     */
+/* >= 8 are skipped and counted in *overflow.                                */
+/* ------------------------------------------------------------------------ */
+void orc_cluster_analysis(int N_, const double *r, double L, double cutoff, int32_t *LCA,
+                          uint64_t *overflow)
+{
+    const size_t np = (size_t)N_ * (N_ - 1) / 2;
+    unsigned char *num1 = (unsigned char *)calloc(np + 1, 1);
+    int32_t *num2 = (int32_t *)calloc(np + 1, sizeof(int32_t));
+    int32_t *num3 = (int32_t *)calloc(np + 1, sizeof(int32_t));
+    int common_nn[8];
+    int idx, idx2, idx3;
+    double dx, dy, dz, dist2;
+
+    for (int l = 1; l < N_; l++) { /* :984-1000 */
+        for (int i = 0; i < l; i++) {
+            idx = (l * l - 3 * l + 2) / 2 + i;
+            dx = r[3 * l] - r[3 * i];
+            dx = dx - L * rint(dx / L);
+            dy = r[3 * l + 1] - r[3 * i + 1];
+            dy = dy - L * rint(dy / L);
+            dz = r[3 * l + 2] - r[3 * i + 2];
+            dist2 = dx * dx + dy * dy + dz * dz;
+            if (dist2 < cutoff * cutoff)
+                num1[idx] = 1;
+        }
+    }
+    for (int l = 1; l < N_; l++) { /* :1003-1035 */
+        for (int i = 0; i < l; i++) {
+            idx = (l * l - 3 * l + 2) / 2 + i;
+            if (!num1[idx])
+                continue;
+            for (int i2 = 0; i2 < l; i2++) {
+                if (i2 == i)
+                    continue;
+                idx2 = idx - i + i2;
+                idx3 = (i2 * i2 - 3 * i2 + 2) / 2 + i;
+                if (num1[idx2] & num1[idx3]) {
+                    if (num2[idx] < 8)
+                        common_nn[num2[idx]] = i2;
+                    else if (overflow)
+                        (*overflow)++;
+                    num2[idx]++;
+                }
+            }
+            if (num2[idx] > 1) {
+                for (int m = 1; m < num2[idx]; m++) {
+                    if (m >= 8)
+                        break; /* slots the reference never owned */
+                    idx2 = (common_nn[m] * common_nn[m] - 3 * common_nn[m] + 2) / 2 + common_nn[m - 1];
+                    if (num1[idx2])
+                        num3[idx]++;
+                }
+            }
+        }
+    }
+    for (size_t n = 0; n < np; n++) { /* :1038-1044 */
+        LCA[3 * n + 0] = (int32_t)num1[n];
+        LCA[3 * n + 1] = num2[n];
+        LCA[3 * n + 2] = num3[n];
+    }
+    free(num1); free(num2); free(num3);
+}
+
+/* the accumulation loop of sMC, SMC.c:146-155, as plain counts: the reference adds the
+ * weight 1/(gather_steps/LCA_TIME) -- an int division, 0 unless the ratio is 1 -- into
+ * l1, l2[num2], l3[num3] (l2, l3 uninitialised, 7 entries); the counts are what a caller
+ * needs to apply any weight.  Values above 15 land in bin 15. */
+void orc_cluster_counts(int N_, const int32_t *LCA, orc_lca_counts *c)
+{
+    const size_t np = (size_t)N_ * (N_ - 1) / 2;
+    for (size_t i = 0; i < np; i++) {
+        if (LCA[3 * i] != 0) {
+            c->n1++;
+            int a = LCA[3 * i + 1], b = LCA[3 * i + 2];
+            c->h2[a > 15 ? 15 : a]++;
+            c->h3[b > 15 ? 15 : b]++;
+        }
+    }
 }
 
 /* ------------------------------------------------------------------------ */

@@ -131,6 +131,28 @@ int orc_chain_p(const orc_sys *s, unsigned int seed, double *R, const double *W,
                 unsigned int flags, double *E_series, int32_t *jj, uint64_t *zhist,
                 uint64_t *D, uint64_t *Mu, double *P_gathers, orc_chain_result *res);
 
+/* ---- common-neighbour cluster analysis -------------------- */
+/* clusterAnalysis, SMC.c:971-1045: LCA[3*idx+{0,1,2}] = num1,num2,num3 of pair entry idx,
+ * N(N-1)/2 entries, the reference's (overlapping) pair index kept; cutoff = LCA_cutoff
+ * (SMC.h:50).  Stores/reads past the reference's common_nn[8] are skipped and counted. */
+void orc_cluster_analysis(int N, const double *r, double L, double cutoff, int32_t *LCA,
+                          uint64_t *overflow);
+typedef struct orc_lca_counts {
+    uint64_t n1;       /* entries with num1 != 0 (the l1 counter, SMC.c:149) */
+    uint64_t h2[16];   /* ... of those, by num2 (l2[], SMC.c:152) */
+    uint64_t h3[16];   /* ... by num3 (l3[], SMC.c:153) */
+    uint64_t analyses; /* clusterAnalysis calls */
+    uint64_t overflow;
+} orc_lca_counts;
+void orc_cluster_counts(int N, const int32_t *LCA, orc_lca_counts *c);
+/* orc_chain_p plus the analysis every lca_time-th gather (k % LCA_TIME == 0, SMC.c:143),
+ * counts accumulated over the run; lca_time = 0 or lca = NULL disables it */
+int orc_chain_lca(const orc_sys *s, unsigned int seed, double *R, const double *W,
+                  double T, double A, int eqsteps, int maxsteps, int gather_lapse,
+                  unsigned int flags, double *E_series, int32_t *jj, uint64_t *zhist,
+                  uint64_t *D, uint64_t *Mu, double *P_gathers, int lca_time,
+                  double lca_cutoff, orc_lca_counts *lca, orc_chain_result *res);
+
 /* ---- inputs to the path (not on it) ------------- */
 /* build-defined fcc(Na,Nz) start, SURVEY.md 8d (cell order and +a/4 of
  * SMC.c:432-461); N must be 4*Na*Na*Nz */

@@ -61,6 +61,11 @@ assert TRACE_DTYPE.itemsize == C.sizeof(OrcMoveTrace)
 _dp = C.POINTER(C.c_double)
 
 
+class OrcLcaCounts(C.Structure):
+    _fields_ = [("n1", C.c_uint64), ("h2", C.c_uint64 * 16), ("h3", C.c_uint64 * 16),
+                ("analyses", C.c_uint64), ("overflow", C.c_uint64)]
+
+
 def _ptr(a, t=C.c_double):
     return a.ctypes.data_as(C.POINTER(t)) if a is not None else None
 
@@ -108,6 +113,15 @@ def lib():
         L.orc_chain.restype = C.c_int
         L.orc_chain_p.argtypes = L.orc_chain.argtypes[:-1] + [_dp, C.POINTER(OrcChainResult)]
         L.orc_chain_p.restype = C.c_int
+        L.orc_chain_lca.argtypes = L.orc_chain_p.argtypes[:-1] + [C.c_int, C.c_double,
+                                                                 C.POINTER(OrcLcaCounts),
+                                                                 C.POINTER(OrcChainResult)]
+        L.orc_chain_lca.restype = C.c_int
+        L.orc_cluster_analysis.argtypes = [C.c_int, _dp, C.c_double, C.c_double,
+                                           C.POINTER(C.c_int32), C.POINTER(C.c_uint64)]
+        L.orc_cluster_analysis.restype = None
+        L.orc_cluster_counts.argtypes = [C.c_int, C.POINTER(C.c_int32), C.POINTER(OrcLcaCounts)]
+        L.orc_cluster_counts.restype = None
         L.orc_pressure.argtypes = [sp, _dp]
         L.orc_pressure.restype = C.c_double
         L.orc_walls_pressure.argtypes = [sp, _dp, _dp]
@@ -226,7 +240,7 @@ def sweep(s, rng, R, W, A, T, E=0.0, trace=False):
 
 
 def chain(s, seed, R0, W, T, A, eqsteps, maxsteps, gather_lapse, e0_restart=True, full_hist=False,
-          pressure=False):
+          pressure=False, lca_time=0, lca_cutoff=1.7):
     R = np.array(R0, dtype=np.float64, copy=True)
     E = np.zeros(maxsteps + 1)
     jj = np.zeros(max(maxsteps, 1), dtype=np.int32)
@@ -236,15 +250,35 @@ def chain(s, seed, R0, W, T, A, eqsteps, maxsteps, gather_lapse, e0_restart=True
     Mu = np.zeros(Nc, dtype=np.uint64) if full_hist else None
     res = OrcChainResult()
     P = np.zeros(max(maxsteps // gather_lapse, 1)) if pressure else None
-    rc = lib().orc_chain_p(C.byref(s), seed, _ptr(R), _ptr(W), T, A, eqsteps, maxsteps, gather_lapse,
-                           1 if e0_restart else 0, _ptr(E), _ptr(jj, C.c_int32),
-                           _ptr(zh, C.c_uint64), _ptr(D, C.c_uint64), _ptr(Mu, C.c_uint64),
-                           _ptr(P), C.byref(res))
+    lca = OrcLcaCounts()
+    rc = lib().orc_chain_lca(C.byref(s), seed, _ptr(R), _ptr(W), T, A, eqsteps, maxsteps, gather_lapse,
+                             1 if e0_restart else 0, _ptr(E), _ptr(jj, C.c_int32),
+                             _ptr(zh, C.c_uint64), _ptr(D, C.c_uint64), _ptr(Mu, C.c_uint64),
+                             _ptr(P), lca_time, lca_cutoff, C.byref(lca), C.byref(res))
     assert rc == 0
     out = {k: getattr(res, k) for k, _ in OrcChainResult._fields_}
+    out["lca"] = dict(n1=int(lca.n1), h2=np.array(lca.h2[:], dtype=np.uint64),
+                      h3=np.array(lca.h3[:], dtype=np.uint64), analyses=int(lca.analyses),
+                      overflow=int(lca.overflow))
     out.update(R=R, E=E, jj=jj[:maxsteps], zhist=zh, D=D, Mu=Mu,
                P=None if P is None else P[:maxsteps // gather_lapse])
     return out
+
+
+def cluster_analysis(N, R, L, cutoff=1.7):
+    """orc_cluster_analysis: (LCA[N(N-1)/2][3], overflow)"""
+    R = np.ascontiguousarray(R, dtype=np.float64)
+    LCA = np.zeros((N * (N - 1) // 2, 3), dtype=np.int32)
+    ov = C.c_uint64(0)
+    lib().orc_cluster_analysis(N, _ptr(R), L, cutoff, _ptr(LCA, C.c_int32), C.byref(ov))
+    return LCA, ov.value
+
+
+def cluster_counts(N, LCA):
+    c = OrcLcaCounts()
+    LCA = np.ascontiguousarray(LCA, dtype=np.int32)
+    lib().orc_cluster_counts(N, _ptr(LCA, C.c_int32), C.byref(c))
+    return int(c.n1), np.array(c.h2[:], dtype=np.uint64), np.array(c.h3[:], dtype=np.uint64)
 
 
 def pressure(s, R, W):

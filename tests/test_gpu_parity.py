@@ -456,6 +456,68 @@ def test_energy_autocorrelation(S, O):
 
 
 @pytest.mark.parametrize("N", [66, 130, 1000, 2050, 4000])
+def film_state(O, Na, Nz, L, jitter, seed):
+    """a dense fcc film (nearest neighbours inside LCA_cutoff) with thermal jitter"""
+    rs = np.random.RandomState(seed)
+    R = O.fcc(Na, Nz, L=L).reshape(-1, 3).copy()
+    R += jitter * rs.standard_normal(R.shape)
+    R[:, 0] -= L * np.rint(R[:, 0] / L)
+    R[:, 1] -= L * np.rint(R[:, 1] / L)
+    return R.ravel()
+
+
+@pytest.mark.parametrize("N,Na,Nz,L,cut", [(256, 4, 4, 8.0, 1.7), (1024, 8, 4, 16.5, 1.7),
+                                           (256, 4, 4, 6.6, 1.9), (108, 3, 3, 6.0, 1.7)])
+def test_cluster_analysis_matches_oracle(S, O, N, Na, Nz, L, cut):
+    """8f.4: clusterAnalysis (SMC.c:971-1045) -- num1/num2/num3 of every pair entry, bit-exact,
+    with the reference's overlapping pair index; the (6.6, 1.9) case has more than 8 common
+    neighbours per pair (the reference's common_nn[8] overflow, counted identically)"""
+    nrep = 3
+    R0 = np.stack([film_state(O, Na, Nz, L, 0.08, 10 * N + r) for r in range(nrep)])
+    p = S.default_params(N, nrep, L=L, lca_cutoff=cut)
+    eng = S.Engine(p)
+    eng.upload(R0, O.W_FIXTURE)
+    eng.cluster_update()
+    eng.cluster_update()
+    n1, h2, h3, ov, k = eng.cluster_counts()
+    assert k == 2
+    for r in range(nrep):
+        ref, ovr = O.cluster_analysis(N, R0[r], L, cut)
+        got, ovg = eng.cluster_analysis(r)
+        assert np.array_equal(got, ref), np.argwhere(got != ref)[:5]
+        assert ovg == ovr
+        c1, c2, c3 = O.cluster_counts(N, ref)
+        assert c1 > N and n1[r] == 2 * c1
+        assert np.array_equal(h2[r], 2 * c2) and np.array_equal(h3[r], 2 * c3) and ov[r] == 2 * ovr
+        if cut > 1.8:
+            assert ovr > 0
+    # entries shared by (l, l-1) and (l+1, 0): present in the comparison above; spot-check one
+    eng.close()
+
+
+def test_cluster_analysis_during_run(S, O):
+    """8f.4: the analysis at the gathers k with k % LCA_TIME == 0 (SMC.c:143) inside smcx_run"""
+    L = 8.0
+    R0 = film_state(O, 4, 4, L, 0.05, 77)
+    nrep = 2
+    flags = S.FLAGS_REFERENCE | S.FLAG_CLUSTERS
+    p = S.default_params(256, nrep, L=L, flags=flags, lca_time=2)
+    eng = S.Engine(p)
+    eng.upload(R0, O.W_FIXTURE)
+    eng.run(1, 9, 2)   # gathers k = 1..4, analyses at k = 2, 4
+    n1, h2, h3, ov, k = eng.cluster_counts()
+    assert k == 2
+    s = sys_of(O, p)
+    for r in range(nrep):
+        ref = O.chain(s, 12345 + r, R0, O.W_FIXTURE, T, A, 1, 9, 2, lca_time=2, lca_cutoff=1.7)["lca"]
+        assert ref["analyses"] == 2
+        assert n1[r] == ref["n1"] and np.array_equal(h2[r], ref["h2"]) and np.array_equal(h3[r], ref["h3"])
+        assert ov[r] == ref["overflow"]
+    eng.run(0, 2, 1)   # counters restart with every run (SMC.c:58-60)
+    assert eng.cluster_counts()[4] == 1
+    eng.close()
+
+
 def test_ragged_sizes_with_padding(S, O, N):
     """N that does not fill the launch geometry (padding lanes/slots, partial last slot, runs
     that wrap inside a slot): two free-running sweeps against the oracle"""

@@ -317,3 +317,79 @@ def test_fft_acf_restatement(O):
         a, b = O.fft_acf(H, kmax), O.fft_acf_direct(H, kmax)
         assert len(a) == len(b) == (kmax if n >= 2 * kmax + 1 else n // 2 - 2)
         assert a[0] == 1.0 and np.abs(a - b).max() < 1e-10
+
+
+# ------------------------------------------------------------------ SURVEY 8f.4
+def _cluster_analysis_py(N, r, L, cut):
+    """independent pure-Python restatement of clusterAnalysis (SMC.c:971-1045), small N only"""
+    r = np.asarray(r, dtype=np.float64).reshape(N, 3)
+    npairs = N * (N - 1) // 2
+    tri = lambda k: (k * k - 3 * k + 2) // 2          # SMC.c:987
+    num1 = np.zeros(npairs + 1, dtype=np.int64)
+    num2 = np.zeros(npairs + 1, dtype=np.int64)
+    num3 = np.zeros(npairs + 1, dtype=np.int64)
+    for l in range(1, N):
+        for i in range(l):
+            d = r[l] - r[i]
+            d[0] -= L * np.rint(d[0] / L)
+            d[1] -= L * np.rint(d[1] / L)
+            if d[0] * d[0] + d[1] * d[1] + d[2] * d[2] < cut * cut:
+                num1[tri(l) + i] = 1
+    cn = [0] * 8
+    over = 0
+    for l in range(1, N):
+        for i in range(l):
+            idx = tri(l) + i
+            if not num1[idx]:
+                continue
+            for i2 in range(l):
+                if i2 == i:
+                    continue
+                if num1[idx - i + i2] & num1[tri(i2) + i]:
+                    if num2[idx] < 8:
+                        cn[num2[idx]] = i2
+                    else:
+                        over += 1
+                    num2[idx] += 1
+            if num2[idx] > 1:
+                for m in range(1, min(num2[idx], 8)):
+                    if num1[tri(cn[m]) + cn[m - 1]]:
+                        num3[idx] += 1
+    return np.stack([num1[:npairs], num2[:npairs], num3[:npairs]], axis=1), over
+
+
+@pytest.mark.parametrize("N,L,cut,seed", [(48, 6.0, 1.7, 1), (64, 5.0, 1.7, 2), (40, 4.0, 2.2, 3)])
+def test_cluster_analysis_restatements_agree(O, N, L, cut, seed):
+    rs = np.random.RandomState(seed)
+    r = rs.uniform(-L / 2, L / 2, (N, 3))
+    r[:, 2] *= 0.6
+    got, ov = O.cluster_analysis(N, r.ravel(), L, cut)
+    ref, ovr = _cluster_analysis_py(N, r, L, cut)
+    assert np.array_equal(got, ref) and ov == ovr
+    assert got[:, 0].sum() > N
+    if cut > 2:
+        assert ov > 0   # the common_nn[8] overflow branch is exercised
+    n1, h2, h3 = O.cluster_counts(N, got)
+    assert n1 == got[:, 0].sum() and h2.sum() == n1 and h3.sum() == n1
+
+
+def test_cluster_analysis_shared_entries(O):
+    """the reference's pair index makes (l, l-1) and (l+1, 0) share an entry: a bond between
+    particles 2 and 1 alone also marks the (3,0) entry, and the entry's counters add up"""
+    N, L = 6, 50.0
+    r = np.array([[8.0 * k - 20.0, 0.0, 0.0] for k in range(N)])
+    r[2] = r[1] + [1.0, 0, 0]          # only (2,1) is inside the cutoff
+    LCA, ov = O.cluster_analysis(N, r.ravel(), L, 1.7)
+    tri = lambda k: (k * k - 3 * k + 2) // 2
+    assert tri(2) + 1 == tri(3) + 0 == 1
+    assert LCA[:, 0].tolist() == [0, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0]
+    assert ov == 0 and LCA[:, 1:].sum() == 0
+
+
+def test_chain_with_cluster_analysis_cadence(O):
+    """k % LCA_TIME == 0 with k = (n+1)/gather_lapse (SMC.c:138, 143)"""
+    s = O.make_sys(108, L=6.0)
+    R0 = O.fcc(3, 3, L=6.0)
+    out = O.chain(s, 7, R0, O.W_FIXTURE, 1.1, 1.1, 0, 12, 2, lca_time=3, lca_cutoff=1.7)
+    assert out["gathers"] == 6 and out["lca"]["analyses"] == 2
+    assert out["lca"]["n1"] > 0 and out["lca"]["h2"].sum() == out["lca"]["n1"]
