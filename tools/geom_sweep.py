@@ -32,6 +32,9 @@ if __name__ == "__main__":
             run(1024, (8, 4), 1024, 20, s, w)
         for s, w in ((16, 1), (8, 2)):
             run(1024, (8, 4), 8192, 5, s, w)
+    elif which == "one":   # geom_sweep.py one N Na Nz nrep sweeps S W
+        N, Na, Nz, nrep, sweeps, s, w = (int(v) for v in sys.argv[2:9])
+        run(N, (Na, Nz), nrep, sweeps, s, w)
     elif which == "16384":
         for s, w in ((32, 8), (16, 16), (32, 16)):
             run(16384, (16, 16), 512, 1, s, w)
