@@ -74,7 +74,7 @@ typedef struct smcx_params {
     int32_t tune_slots;     /* 0 = auto; else particles per lane (1,2,4,...,64) */
     int32_t tune_waves;     /* 0 = auto; else wavefronts per replica (1,2,4,8,16) */
     int32_t lca_time;       /* LCA_TIME: cluster analysis every lca_time-th gather (SMC.h:48) */
-    int32_t reserved0;
+    int32_t tune_kernel;    /* 0 = auto; 1 = fp64 sweep kernels; 2 = screened (compact-copy) sweep kernel */
     double lca_cutoff;      /* LCA_cutoff (SMC.h:50) */
 } smcx_params;
 

@@ -31,7 +31,7 @@ class Params(C.Structure):
                 ("Ncx", C.c_int32), ("Ncz", C.c_int32), ("flags", C.c_uint32),
                 ("base_seed", C.c_uint32), ("first_replica", C.c_uint32),
                 ("tune_slots", C.c_int32), ("tune_waves", C.c_int32),
-                ("lca_time", C.c_int32), ("reserved0", C.c_int32), ("lca_cutoff", C.c_double)]
+                ("lca_time", C.c_int32), ("tune_kernel", C.c_int32), ("lca_cutoff", C.c_double)]
 
 
 class SmcxError(RuntimeError):
@@ -125,6 +125,13 @@ def device_count():
     n = C.c_int(0)
     _lib().smcx_device_count(C.byref(n))
     return n.value
+
+
+def geometry_supported_fp64(slots, waves):
+    """geometries the fp64 sweep kernels are built for (csrc/smcx_kernels.hip: lookup)"""
+    return (slots, waves) in {(1, 1), (2, 1), (4, 1), (8, 1), (16, 1), (32, 1), (64, 1), (8, 2), (16, 2),
+                              (32, 2), (4, 4), (8, 4), (16, 4), (32, 4), (8, 8), (16, 8), (32, 8),
+                              (16, 16), (32, 16)}
 
 
 def rng_seed(seed):

@@ -156,6 +156,7 @@ static int validate(const smcx_params *p)
     if (!(p->L > 0) || !(p->Lz > 0) || !(p->T > 0) || !(p->A > 0) || !(p->cutoff > 0))
         return SMCX_ERR_PARAM;
     if (p->Ncx < 1 || p->Ncz < 1 || p->Ncx > 255 || p->Ncz > 255) return SMCX_ERR_PARAM;
+    if (p->tune_kernel < 0 || p->tune_kernel > 2) return SMCX_ERR_PARAM;
     if (p->flags & SMCX_FLAG_WALLS) {
         if (p->M < 1) return SMCX_ERR_PARAM;
         if (p->M * p->M + 1 > 30) return SMCX_ERR_UNSUPPORTED;
@@ -173,22 +174,34 @@ static int choose_geometry(const smcx_params *p, int *S, int *WPR)
         int s = p->tune_slots > 0 ? p->tune_slots : 16;
         int w = p->tune_waves > 0 ? p->tune_waves : 1;
         if (!geometry_supported(s, w) || (long)s * w * 64 < p->N) return SMCX_ERR_UNSUPPORTED;
+        if (p->tune_kernel == 1 && !fp64_supported(s, w)) return SMCX_ERR_UNSUPPORTED;
+        if (p->tune_kernel == 2 && !mx_supported(s, w)) return SMCX_ERR_UNSUPPORTED;
         *S = s; *WPR = w;
         return SMCX_OK;
     }
-    // Rule fitted to measurements on MI355X (profiles/r01_geometry_N*.log): 16 particles per
-    // lane (96 VGPRs of positions, 3 waves per SIMD) and N/1024 wavefronts per replica; 32 per
-    // lane once that would need more than 8 wavefronts (a 1024-thread workgroup is capped at
-    // 128 VGPRs); with few replicas, halve S and double the wavefronts until the chip has
-    // about two waves per SIMD to work on.
+    // Rule fitted to measurements on MI355X (profiles/r01_geometry_N*.log, r01_screened_kernel.log).
+    // Screened kernel (2 VGPRs per particle, S >= 16): as few wavefronts per replica as possible --
+    // 64 particles per lane, N/4096 wavefronts -- because every extra wavefront repeats the
+    // sequential part of a move and adds a barrier.  fp64 kernels (S < 16, or asked for): 16
+    // particles per lane (96 VGPRs of positions, 3 waves per SIMD) and N/1024 wavefronts, 32 per
+    // lane beyond 8 wavefronts.  With few replicas, halve S and double the wavefronts until the
+    // chip has about two waves per SIMD to work on.
     auto pow2_at_least = [](long v) { int r = 1; while (r < v) r *= 2; return r; };
     int s, w;
-    if (p->N <= 1024) { s = pow2_at_least((p->N + 63) / 64); w = 1; }
-    else {
-        s = 16; w = pow2_at_least((p->N + 1023) / 1024);
-        if (w > 8) { s = 32; w = pow2_at_least((p->N + 2047) / 2048); }
+    const bool fp64_only = (p->tune_kernel == 1);
+    if (!fp64_only && p->N > 512) {
+        s = pow2_at_least((p->N + 63) / 64); w = 1;
+        if (s < 16) s = 16;
+        while (s > 64) { s /= 2; w *= 2; }
+        while ((long)p->nrep * w < 2048 && s > 16 && w < 8 && geometry_supported(s / 2, w * 2)) { s /= 2; w *= 2; }
+    } else {
+        if (p->N <= 1024) { s = pow2_at_least((p->N + 63) / 64); w = 1; }
+        else {
+            s = 16; w = pow2_at_least((p->N + 1023) / 1024);
+            if (w > 8) { s = 32; w = pow2_at_least((p->N + 2047) / 2048); }
+        }
+        while ((long)p->nrep * w < 2048 && s > 4 && w < 8 && geometry_supported(s / 2, w * 2)) { s /= 2; w *= 2; }
     }
-    while ((long)p->nrep * w < 2048 && s > 4 && w < 8 && geometry_supported(s / 2, w * 2)) { s /= 2; w *= 2; }
     if (geometry_supported(s, w) && (long)s * w * 64 >= p->N) { *S = s; *WPR = w; return SMCX_OK; }
     static const int cand[][2] = {{1, 1}, {2, 1}, {4, 1}, {8, 1}, {8, 2}, {16, 2}, {16, 4},
                                   {32, 4}, {32, 8}, {32, 16}};
@@ -456,7 +469,7 @@ static int run_phase(Handle &h, int steps, double A, int production, int gather_
             h.evs.push_back(e);
         }
         HIPCHK(&h, hipEventRecord(h.evs[2 * h.last_launches], h.stream));
-        HIPCHK(&h, launch_sweeps(h.c, h.S, h.WPR, k, A, h.stream));
+        HIPCHK(&h, launch_sweeps(h.c, h.S, h.WPR, k, A, h.p.tune_kernel, h.stream));
         HIPCHK(&h, hipEventRecord(h.evs[2 * h.last_launches + 1], h.stream));
         HIPCHK(&h, launch_finalize(h.c, k, production, done, (production && first) ? 1 : 0, h.stream));
         h.last_launches++;

@@ -6,9 +6,16 @@
 namespace smcx {
 
 bool geometry_supported(int S, int WPR);
+bool fp64_supported(int S, int WPR);
+// fp32-screened sweep kernels (smcx_sweep_mx.hip)
+bool mx_supported(int S, int WPR);
+hipError_t launch_sweeps_mx(const SweepArgs &a, const DevCtx &c, int S, int WPR, int nsweeps, double A,
+                            hipStream_t st);
 
 hipError_t launch_rng_prepass(const DevCtx &c, int nsweeps, double A, hipStream_t st);
-hipError_t launch_sweeps(const DevCtx &c, int S, int WPR, int nsweeps, double A, hipStream_t st);
+// kernel: 0 = auto, 1 = fp64 kernels, 2 = screened kernel (smcx_sweep_mx.hip)
+hipError_t launch_sweeps(const DevCtx &c, int S, int WPR, int nsweeps, double A, int kernel, hipStream_t st);
+bool sweep_uses_mx(int S, int WPR, int kernel);
 hipError_t launch_finalize(const DevCtx &c, int nsweeps, int production, int sweep_base,
                            int first_production, hipStream_t st);
 hipError_t launch_hist(const DevCtx &c, hipStream_t st);

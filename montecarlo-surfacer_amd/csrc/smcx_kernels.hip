@@ -76,66 +76,7 @@ rng_prepass_kernel(DevCtx c, int nsweeps, double A)
 // S1: the sweep
 // ---------------------------------------------------------------------------------
 
-// rotate the register-resident particle slots by one: slot j <- slot j+1
-template <int S>
-__device__ __forceinline__ void rotate1(double (&x)[S], double (&y)[S], double (&z)[S])
-{
-    if constexpr (S > 1) {
-        const double tx = x[0], ty = y[0], tz = z[0];
-#pragma unroll
-        for (int k = 0; k + 1 < S; k++) { x[k] = x[k + 1]; y[k] = y[k + 1]; z[k] = z[k + 1]; }
-        x[S - 1] = tx; y[S - 1] = ty; z[S - 1] = tz;
-    }
-}
-
-__device__ __forceinline__ double ld_coherent(const double *p)
-{
-    // L1-bypassing load (global_load ... sc1): positions written through by another wave
-    unsigned long long b = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(p),
-                                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return __longlong_as_double((long long)b);
-}
-
-template <int WPR> struct SweepShared {
-    RoleTable roles;
-    double red[2][WPR][8];
-    double side[2][2][4];
-};
-
-// combine the eight wave totals (and, with several waves, the waves) into
-// tot[8], identical in every lane of the workgroup; also fetches the two side terms
-template <int WPR>
-__device__ __forceinline__ void combine(SweepShared<WPR> &sh, int &par, int lane, int wave,
-                                        const Acc8 &v, const double (&side)[4],
-                                        double (&tot)[8], double (&sOld)[4], double (&sNew)[4])
-{
-    const double r = reduce8(v.a0, v.a1, v.a2, v.a3, v.b0, v.b1, v.b2, v.b3, lane);
-    if constexpr (WPR == 1) {
-#pragma unroll
-        for (int j = 0; j < 8; j++) tot[j] = rdlane(r, 8 * j);
-#pragma unroll
-        for (int j = 0; j < 4; j++) { sOld[j] = side[j]; sNew[j] = side[j]; } // read by lane later
-    } else {
-        if ((lane & 7) == 0) sh.red[par][wave][lane >> 3] = r;
-        if (wave == 0 && (lane == SIDE_LANE_OLD || lane == SIDE_LANE_NEW)) {
-#pragma unroll
-            for (int j = 0; j < 4; j++) sh.side[par][lane - SIDE_LANE_OLD][j] = side[j];
-        }
-        __syncthreads();
-        // lane i reads the partial of wave i>>3 for value i&7, then the groups are summed
-        double t = 0.0;
-        if (lane < 8 * WPR) t = sh.red[par][lane >> 3][lane & 7];
-        if constexpr (WPR > 8) t += sh.red[par][(lane >> 3) + 8][lane & 7];
-        if constexpr (WPR >= 8) t = sum_x32(t);
-        if constexpr (WPR >= 4) t = sum_x16(t);
-        t = sum_x8(t);
-#pragma unroll
-        for (int j = 0; j < 8; j++) tot[j] = rdlane(t, j);
-#pragma unroll
-        for (int j = 0; j < 4; j++) { sOld[j] = sh.side[par][0][j]; sNew[j] = sh.side[par][1][j]; }
-        par ^= 1;
-    }
-}
+#include "smcx_sweep_common.hpp"
 
 // The hot kernel.  One workgroup = one replica chain; it keeps the chain's positions in
 // registers across the `nsweeps` sweeps of the launch.  Per trial move: ONE pass over
@@ -788,7 +729,8 @@ static sweep_fn lookup(int S, int WPR, bool lead = true)
     return nullptr;
 }
 
-bool geometry_supported(int S, int WPR) { return lookup(S, WPR) != nullptr; }
+bool geometry_supported(int S, int WPR) { return lookup(S, WPR) != nullptr || mx_supported(S, WPR); }
+bool fp64_supported(int S, int WPR) { return lookup(S, WPR) != nullptr; }
 
 hipError_t launch_rng_prepass(const DevCtx &c, int nsweeps, double A, hipStream_t st)
 {
@@ -796,19 +738,33 @@ hipError_t launch_rng_prepass(const DevCtx &c, int nsweeps, double A, hipStream_
     return hipGetLastError();
 }
 
-hipError_t launch_sweeps(const DevCtx &c, int S, int WPR, int nsweeps, double A, hipStream_t st)
+// which form runs: the screened kernel where it exists unless fp64 is asked for (SMCX_MX=0/1
+// overrides "auto" for A/B measurements)
+bool sweep_uses_mx(int S, int WPR, int kernel)
+{
+    static const char *env = getenv("SMCX_MX");
+    if (kernel == 0 && env) kernel = (env[0] == '0') ? 1 : 2;
+    const bool have64 = lookup(S, WPR) != nullptr;
+    if (kernel == 1 && have64) return false;
+    if (kernel == 2 || !have64) return mx_supported(S, WPR);
+    return mx_supported(S, WPR); // auto
+}
+
+hipError_t launch_sweeps(const DevCtx &c, int S, int WPR, int nsweeps, double A, int kernel, hipStream_t st)
 {
     // leader/follower form where it measured faster (profiles/r01_leader_follower.log): many
     // waves with few slots each; SMCX_NO_LEAD / SMCX_LEAD force one form for A/B measurements
     static const bool no_lead = getenv("SMCX_NO_LEAD") != nullptr, force_lead = getenv("SMCX_LEAD") != nullptr;
     const bool lead = force_lead || (!no_lead && S <= 16 && WPR >= 4);
     sweep_fn f = lookup(S, WPR, lead);
-    if (!f) return hipErrorInvalidValue;
+    const bool use_mx = sweep_uses_mx(S, WPR, kernel);
+    if (!f && !use_mx) return hipErrorInvalidValue;
     SweepArgs a;
     a.N = c.N; a.chunk = c.chunk;
     a.L = c.L; a.invL = c.invL; a.cutoff2 = c.cutoff2; a.invT = c.invT;
     a.R = c.R; a.displ = c.displ; a.uni = c.uni; a.offs = c.offs; a.obs = c.obs; a.rec = c.rec;
     a.edge = c.L / 2 - sqrt(c.cutoff2); // |x|,|y| up to here: no pair needs the periodic image
+    if (use_mx) return launch_sweeps_mx(a, c, S, WPR, nsweeps, A, st);
     hipLaunchKernelGGL(f, dim3(c.nrep), dim3(64 * WPR), 0, st, a, c, nsweeps, A);
     return hipGetLastError();
 }

@@ -1,0 +1,369 @@
+// smcx_sweep_mx.hip -- the fp32-screened form of the sweep kernel.  Its own translation
+// unit because it is built with -fno-slp-vectorize: the SLP vectoriser otherwise turns the
+// screening arithmetic into v_pk_*_f32 on shuffled register pairs, moves the probes into
+// VGPRs and spills the positions.
+#include "smcx_device.hpp"
+#include "smcx_kernels.h"
+
+#include <cmath>
+#include <cstdlib>
+
+namespace smcx {
+
+#include "smcx_sweep_common.hpp"
+
+// ---------------------------------------------------------------------------------
+// Screened form of the same sweep.  The cutoff test -- which 99.96 % of the pair
+// evaluations fail at the benchmark density -- is screened on compact copies of the
+// positions, with a threshold widened by a proven error bound; every candidate is then
+// decided and evaluated EXACTLY as in sweep_kernel, in fp64, from the fp64 positions in
+// memory.  The set of pairs inside the cutoff, the values added and their order are those
+// of the fp64 kernels, so the results are bit-identical to theirs.
+//
+// Compact copy, 2 VGPRs per particle instead of 6:
+//   x,y  two 16-bit fixed-point numbers in one register, the box [-L/2, L/2) mapped onto the
+//        whole int16 range: the subtraction of two of them (v_pk_sub_i16) wraps modulo 2^16,
+//        which IS the minimum image -- no rint, no branch on where the probe sits;
+//        dx^2 + dy^2 is one v_dot2_i32_i16 (saturating);
+//   z    fp32 (not periodic, unbounded).
+// 64 particles per lane fit beside everything else, so N = 4096 needs ONE wavefront per
+// replica -- no workgroup barrier, no cross-wave reduction -- at two waves per SIMD.
+//
+// Screening bound (host side: launch_sweeps_mx).  With u = L/65536 the stored x differs
+// from the true one by <= u/2, so an integer difference is within 1 unit of the true
+// (minimum-image) one and dxi^2 + dyi^2 <= (true, in units) + 2*sqrt(2)*R + 2 for a pair
+// inside the cutoff R = rc/u.  z: |fl32(z) - z| <= 2^-24 |z| with |z| <= zsafe.  The sum of
+// both, plus the fp32 rounding of the final expression, is `margin`; the test
+// `!(thr <= q)` with thr = rc^2 + margin never rejects a pair the fp64 test accepts.
+// A z outside [-zsafe, zsafe] is stored as NaN, which the (unordered) compare always
+// passes on to the exact evaluation.  Padding slots hold z = +inf, a disabled probe
+// z = -inf: never candidates.
+// ---------------------------------------------------------------------------------
+struct MxArgs {
+    float thr;      // screening threshold rc^2 + margin
+    float u2;       // (L/65536)^2: integer units^2 -> length^2
+    double toFix;   // 65536/L
+    float zsafe;    // |z| up to which the error bound holds
+};
+
+typedef short mx_s2 __attribute__((ext_vector_type(2)));
+
+// x,y -> two int16 in one register (x low, y high); x = +L/2 wraps onto -L/2, the same point
+__device__ __forceinline__ unsigned mx_pack_xy(double x, double y, double toFix)
+{
+    const int xi = (int)__builtin_rint(x * toFix), yi = (int)__builtin_rint(y * toFix);
+    return ((unsigned)xi & 0xffffu) | ((unsigned)yi << 16);
+}
+__device__ __forceinline__ float mx_store_z(double z, float zsafe)
+{
+    return (fabs(z) <= (double)zsafe) ? (float)z : __builtin_nanf("");
+}
+
+template <int S>
+__device__ __forceinline__ void rotate1m(unsigned (&xy)[S], float (&z)[S])
+{
+    if constexpr (S > 1) {
+        const unsigned t = xy[0]; const float tz = z[0];
+#pragma unroll
+        for (int k = 0; k + 1 < S; k++) { xy[k] = xy[k + 1]; z[k] = z[k + 1]; }
+        xy[S - 1] = t; z[S - 1] = tz;
+    }
+}
+
+// cand = 2*cand + !(thr <= q): compare into VCC, shift the bit in with add-with-carry
+__device__ __forceinline__ void mx_push(unsigned &cand, float q, float thr)
+{
+    asm("v_cmp_nle_f32_e32 vcc, %2, %1\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc"
+        : "+v"(cand) : "v"(q), "s"(thr) : "vcc");
+}
+
+// squared distance for the screen: u2 * (dxi^2 + dyi^2) + dz^2
+__device__ __forceinline__ float mx_q(unsigned pxy, float pz, unsigned xy, float z, float u2)
+{
+    const mx_s2 d = __builtin_bit_cast(mx_s2, pxy) - __builtin_bit_cast(mx_s2, xy); // wraps: minimum image
+    const int i2 = __builtin_amdgcn_sdot2(d, d, 0, true);
+    const float dz = pz - z;
+    return fmaf(u2, (float)i2, dz * dz);
+}
+
+// screening of the S register-resident neighbours against probes A and B: candidate
+// bits, slot 32w+j in bit 31-j (or W-1-j for the last, shorter word) of word w
+template <int S>
+__device__ __forceinline__ void mx_screen(const unsigned (&xy)[S], const float (&z)[S], unsigned axy,
+                                          float az, unsigned bxy, float bz, float u2, float thr,
+                                          unsigned (&ca)[(S + 31) / 32], unsigned (&cb)[(S + 31) / 32])
+{
+#pragma unroll
+    for (int k = 0; k < S; k++) {
+        const float qa = mx_q(axy, az, xy[k], z[k], u2);
+        const float qb = mx_q(bxy, bz, xy[k], z[k], u2);
+        mx_push(ca[k >> 5], qa, thr);
+        mx_push(cb[k >> 5], qb, thr);
+    }
+}
+
+// take this lane's lowest-slot candidate out of the words: its register slot, or -1
+template <int S>
+__device__ __forceinline__ int mx_pick(unsigned (&cw)[(S + 31) / 32])
+{
+    constexpr int NW = (S + 31) / 32;
+    int k = -1;
+#pragma unroll
+    for (int w = NW - 1; w >= 0; w--) {
+        const int width = (w == NW - 1) ? S - 32 * w : 32; // bits in use
+        if (cw[w] != 0u) k = 32 * w + width - 32 + __builtin_clz(cw[w]);
+    }
+    if (k >= 0) cw[k >> 5] &= ~(1u << ((((k >> 5) == NW - 1) ? S - 32 * (NW - 1) : 32) - 1 - (k & 31)));
+    return k;
+}
+
+template <int S>
+__device__ __forceinline__ bool mx_any(const unsigned (&cw)[(S + 31) / 32])
+{
+    unsigned u = 0;
+#pragma unroll
+    for (int w = 0; w < (S + 31) / 32; w++) u |= cw[w];
+    return u != 0u;
+}
+
+// fp64 position of the particle in register slot k of this thread, from memory.  With one
+// wavefront per replica every position is written and read by the same lane, so a plain
+// (L1-cached) load is coherent; several wavefronts need the L1-bypassing load.
+template <int S, int T, bool COHERENT>
+__device__ __forceinline__ void mx_fetch(const double *Rg, int tid, int rot, int k, double &X,
+                                         double &Y, double &Z)
+{
+    int ls = k + rot; // register slot -> logical slot
+    if (ls >= S) ls -= S;
+    const double *q = Rg + 3 * (ls * T + tid);
+    if constexpr (COHERENT) { X = ld_coherent(q); Y = ld_coherent(q + 1); Z = ld_coherent(q + 2); }
+    else { X = q[0]; Y = q[1]; Z = q[2]; }
+}
+
+template <int S, int WPR, int MINW>
+__global__ void __launch_bounds__(64 * WPR, MINW)
+sweep_kernel_mx(SweepArgs a, DevCtx c, int nsweeps, double A, MxArgs m)
+{
+    constexpr int T = 64 * WPR;
+    constexpr int NW = (S + 31) / 32;
+    __shared__ SweepShared<WPR> sh;
+
+    const int rep = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = uniform(tid >> 6);
+    const int N = a.N;
+    double *Rg = a.R + (size_t)rep * 3 * N;
+
+    // ---- register-resident compact copies: particle l in lane l % T, slot l / T ------
+    unsigned xy[S];
+    float z[S];
+#pragma unroll
+    for (int k = 0; k < S; k++) {
+        const int l = k * T + tid;
+        if (l < N) { xy[k] = mx_pack_xy(Rg[3 * l], Rg[3 * l + 1], m.toFix); z[k] = mx_store_z(Rg[3 * l + 2], m.zsafe); }
+        else { xy[k] = 0u; z[k] = __builtin_inff(); }
+    }
+    int rot = 0; // register slot j holds logical slot (j + rot) % S
+
+    if (wave == 0) fill_roles(c, sh.roles, lane);
+    __syncthreads();
+    const int role = (wave == 0) ? sh.roles.role[lane] : -1;
+
+    Geo g; g.L = a.L; g.invL = a.invL; g.cutoff2 = a.cutoff2;
+    double E = uniform_d(a.obs[rep].Ecur);
+    int par = 0;
+    const double AoT = A * a.invT;
+    const double Ao4T = A * 0.25 * a.invT;
+
+#pragma unroll 1
+    for (int sw = 0; sw < nsweeps; sw++) {
+        if constexpr (WPR > 1) __syncthreads();
+        const double *displ = a.displ + ((size_t)rep * a.chunk + sw) * 3 * N;
+        const double *uni = a.uni + ((size_t)rep * a.chunk + sw) * N;
+        const int n0 = uniform(a.offs[(size_t)rep * a.chunk + sw]);
+        int jacc = 0;
+#pragma unroll 1
+        for (int run = 0; run < 2; run++) {
+            const int first = run == 0 ? n0 : 0;
+            const int len = run == 0 ? N - n0 : n0;
+            if (len == 0) continue;
+            const int vbase = run == 0 ? 0 : N - n0;
+            const int ks = first / T;
+            while (rot != ks) { rotate1m<S>(xy, z); rot = (rot + 1 == S) ? 0 : rot + 1; }
+            int tl = first - ks * T - 1;
+
+            double Px = 0.0, Py = 0.0, Pz = FAR_PROBE;
+            double Um = 0.0, Fmx = 0.0, Fmy = 0.0, Fmz = 0.0;
+            // the next particle's fp64 position comes from memory, one move ahead of its use
+            double nBx = ld_coherent(Rg + 3 * first), nBy = ld_coherent(Rg + 3 * first + 1),
+                   nBz = ld_coherent(Rg + 3 * first + 2);
+            // this move's displacement and log-uniform: wave-uniform, read-only for the whole
+            // kernel -> scalar loads through the constant address space, one move ahead
+            typedef const __attribute__((address_space(4))) double *kptr;
+            const kptr dK = (kptr)(unsigned long long)displ + 3 * (size_t)first;
+            const kptr uK = (kptr)(unsigned long long)uni + vbase;
+            double ndx = dK[0], ndy = dK[1], ndz = dK[2], nlu = uK[0];
+#pragma unroll 1
+            for (int i = -1; i < len; i++) {
+                const int n = first + i;
+                const bool hasA = (i >= 0);
+                const double ddx = ndx, ddy = ndy, ddz = ndz, lu = nlu; // of move i (unused for i = -1)
+                if (i + 1 < len) {
+                    ndx = dK[3 * (i + 1)]; ndy = dK[3 * (i + 1) + 1]; ndz = dK[3 * (i + 1) + 2];
+                    nlu = uK[i + 1];
+                }
+                double Qx = 0.0, Qy = 0.0, Qz = FAR_PROBE; // proposal, SMC.c:307-316
+                if (hasA) {
+                    Qx = Px + (Fmx * AoT + ddx);
+                    Qy = Py + (Fmy * AoT + ddy);
+                    Qz = Pz + (Fmz * AoT + ddz);
+                    Qx = Qx - a.L * __builtin_rint(Qx * a.invL);
+                    Qy = Qy - a.L * __builtin_rint(Qy * a.invL);
+                    Qx = uniform_d(Qx); Qy = uniform_d(Qy); Qz = uniform_d(Qz);
+                }
+                const bool hasB = (i + 1 < len);
+                const bool cross = hasB && (tl == T - 1);
+                double Bx = 0.0, By = 0.0, Bz = FAR_PROBE;
+                if (hasB) { Bx = uniform_d(nBx); By = uniform_d(nBy); Bz = uniform_d(nBz); }
+                if (i + 2 < len) {
+                    nBx = ld_coherent(Rg + 3 * (n + 2)); nBy = ld_coherent(Rg + 3 * (n + 2) + 1);
+                    nBz = ld_coherent(Rg + 3 * (n + 2) + 2);
+                }
+
+                // ---- screening ------------------------------------------------------
+                const float ninf = -__builtin_inff();
+                const unsigned axy = (unsigned)uniform((int)mx_pack_xy(Qx, Qy, m.toFix));
+                const unsigned bxy = (unsigned)uniform((int)mx_pack_xy(Bx, By, m.toFix));
+                const float azf = hasA ? mx_store_z(Qz, m.zsafe) : ninf;
+                const float bzf = hasB ? mx_store_z(Bz, m.zsafe) : ninf;
+                unsigned ca[NW], cb[NW];
+#pragma unroll
+                for (int w = 0; w < NW; w++) { ca[w] = 0u; cb[w] = 0u; }
+                mx_screen<S>(xy, z, axy, azf, bxy, bzf, m.u2, m.thr, ca, cb);
+                // the moving particle itself and the particle probe B stands for are not neighbours
+                {
+                    constexpr unsigned top = 1u << ((NW == 1 ? S : 32) - 1); // slot 0
+                    const bool exA0 = (tid == tl);
+                    const bool exB0 = (hasA && tid == tl) || (hasB && !cross && tid == tl + 1);
+                    const bool exB1 = cross && (tid == 0);
+                    if (exA0) ca[0] &= ~top;
+                    if (exB0) cb[0] &= ~top;
+                    if constexpr (S > 1) { if (exB1) cb[0] &= ~(top >> 1); }
+                }
+                // ---- exact evaluation of the candidates ------------------------------
+                // every lane fetches its candidates' fp64 positions and decides and evaluates
+                // them exactly as the fp64 kernel does, in ascending slot order per probe
+                Acc8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+                double side[4], tot[8], sOld[4], sNew[4];
+                if (__builtin_amdgcn_ballot_w64(mx_any<S>(ca) || mx_any<S>(cb))) {
+                    int kA = mx_pick<S>(ca), kB = mx_pick<S>(cb);
+                    do {
+                        double XA = 0, YA = 0, ZA = 0, XB = 0, YB = 0, ZB = 0;
+                        if (kA >= 0) mx_fetch<S, T, (WPR > 1)>(Rg, tid, rot, kA, XA, YA, ZA);
+                        if (kB >= 0) mx_fetch<S, T, (WPR > 1)>(Rg, tid, rot, kB, XB, YB, ZB);
+                        if (kA >= 0 && pair_q<true>(g, Qx, Qy, Qz, XA, YA, ZA) < g.cutoff2)
+                            pair_hit(g, Qx, Qy, Qz, XA, YA, ZA, v.a0, v.a1, v.a2, v.a3);
+                        if (kB >= 0 && pair_q<true>(g, Bx, By, Bz, XB, YB, ZB) < g.cutoff2)
+                            pair_hit(g, Bx, By, Bz, XB, YB, ZB, v.b0, v.b1, v.b2, v.b3);
+                        kA = mx_pick<S>(ca); kB = mx_pick<S>(cb);
+                    } while (__builtin_amdgcn_ballot_w64(kA >= 0 || kB >= 0));
+                }
+                if (wave == 0)
+                    special_block(g, sh.roles, lane, role, hasA, hasB, hasA, Px, Py, Pz, Qx, Qy, Qz,
+                                  Bx, By, Bz, v, side);
+                else side[0] = side[1] = side[2] = side[3] = 0.0;
+                combine<WPR>(sh, par, lane, wave, v, side, tot, sOld, sNew);
+
+                bool acc = false;
+                if (hasA) {
+                    const double Un = 4.0 * tot[0], Fnx = tot[1], Fny = tot[2], Fnz = tot[3];
+                    const double dX = Fmx * AoT + ddx;
+                    const double dY = Fmy * AoT + ddy;
+                    const double dZ = Fmz * AoT + ddz;
+                    const double gx = Fnx - Fmx, gy = Fny - Fmy, gz = Fnz - Fmz;
+                    const double deltaW = (gx * gx + gy * gy + gz * gz +
+                                           2.0 * (gx * Fmx + gy * Fmy + gz * Fmz)) * Ao4T;
+                    const double arg = Un - Um +
+                                       (dX * (Fnx + Fmx) + dY * (Fny + Fmy) + dZ * (Fnz + Fmz)) * 0.5 + deltaW;
+                    acc = (lu < -arg * a.invT);
+                    acc = (uniform((int)acc) != 0);
+                    const bool upd = acc && (tid == tl);
+                    if (upd) {
+                        xy[0] = axy; z[0] = azf;
+                        Rg[3 * n] = Qx; Rg[3 * n + 1] = Qy; Rg[3 * n + 2] = Qz; // the fp64 state
+                    }
+                    if (acc) { E = uniform_d(E + (Un - Um)); jacc++; }
+                }
+
+                if (hasB) {
+                    double s0, s1, s2, s3;
+                    if constexpr (WPR == 1) {
+                        const int src = acc ? SIDE_LANE_NEW : SIDE_LANE_OLD;
+                        s0 = rdlane(sOld[0], src); s1 = rdlane(sOld[1], src);
+                        s2 = rdlane(sOld[2], src); s3 = rdlane(sOld[3], src);
+                    } else {
+                        s0 = acc ? sNew[0] : sOld[0]; s1 = acc ? sNew[1] : sOld[1];
+                        s2 = acc ? sNew[2] : sOld[2]; s3 = acc ? sNew[3] : sOld[3];
+                    }
+                    Um = uniform_d(4.0 * (tot[4] + s0));
+                    Fmx = uniform_d(tot[5] + s1);
+                    Fmy = uniform_d(tot[6] + s2);
+                    Fmz = uniform_d(tot[7] + s3);
+                    Px = Bx; Py = By; Pz = Bz;
+                    if (cross) {
+                        rotate1m<S>(xy, z);
+                        rot = (rot + 1 == S) ? 0 : rot + 1;
+                        tl = 0;
+                    } else {
+                        tl++;
+                    }
+                }
+            }
+        }
+        if (tid == 0) {
+            SweepRec r; r.E = E; r.accepted = jacc; r.pad = 0;
+            a.rec[(size_t)rep * a.chunk + sw] = r;
+        }
+    }
+}
+
+
+typedef void (*sweep_mx_fn)(SweepArgs, DevCtx, int, double, MxArgs);
+
+// 3 VGPRs per particle: twice the slots of the fp64 kernels at the same occupancy
+static sweep_mx_fn lookup_mx(int S, int WPR)
+{
+#define SMCX_MX(s, w, m) if (S == s && WPR == w) return sweep_kernel_mx<s, w, m>;
+    SMCX_MX(16, 1, 3) SMCX_MX(32, 1, 3) SMCX_MX(64, 1, 2)
+    SMCX_MX(16, 2, 3) SMCX_MX(32, 2, 3) SMCX_MX(64, 2, 2)
+    SMCX_MX(16, 4, 4) SMCX_MX(32, 4, 3) SMCX_MX(64, 4, 2)
+    SMCX_MX(32, 8, 3) SMCX_MX(64, 8, 2)
+#undef SMCX_MX
+    return nullptr;
+}
+
+bool mx_supported(int S, int WPR) { return lookup_mx(S, WPR) != nullptr; }
+
+hipError_t launch_sweeps_mx(const SweepArgs &a, const DevCtx &c, int S, int WPR, int nsweeps, double A,
+                            hipStream_t st)
+{
+    sweep_mx_fn fm = lookup_mx(S, WPR);
+    if (!fm) return hipErrorInvalidValue;
+    // screening threshold: see the bound in the comment of sweep_kernel_mx
+    const double rc = sqrt(c.cutoff2), eps = 5.9604644775390625e-8; // 2^-24
+    const double zsafe = 2.0 * c.Lz; // the walls keep particles within Lz/2; beyond zsafe the screen passes everything on
+    const double u = c.L / 65536.0, R = rc / u;
+    const double m_xy = (2.0 * sqrt(2.0) * R + 2.0) * u * u;           // fixed-point x,y
+    const double m_z = 2.0 * rc * (3.0 * eps * zsafe) + 1e-9;           // fp32 z of particle and probe
+    const double margin = (m_xy + m_z) * 1.01 + 8.0 * eps * (c.cutoff2 + m_xy + m_z) + 1e-6 * c.cutoff2;
+    MxArgs m;
+    m.thr = nextafterf((float)(c.cutoff2 + margin), INFINITY);
+    m.u2 = (float)(u * u);
+    m.toFix = 65536.0 / c.L;
+    m.zsafe = (float)zsafe;
+    hipLaunchKernelGGL(fm, dim3(c.nrep), dim3(64 * WPR), 0, st, a, c, nsweeps, A, m);
+    return hipGetLastError();
+}
+
+} // namespace smcx

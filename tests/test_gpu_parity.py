@@ -455,7 +455,50 @@ def test_energy_autocorrelation(S, O):
         eng.close()
 
 
-@pytest.mark.parametrize("N", [66, 130, 1000, 2050, 4000])
+@pytest.mark.parametrize("N,lat,L,slots,waves,nsw,walls", [
+    (4096, (8, 16), 33.0, 64, 1, 3, True),    # benchmark lattice, one wavefront per replica
+    (4096, (16, 4), 33.0, 32, 2, 2, True),    # dense film: ~40 neighbours inside the cutoff per particle
+    (4096, (16, 4), 33.0, 16, 4, 2, True),
+    (1024, (8, 4), 33.0, 16, 1, 6, True),
+    (1024, (8, 4), 16.0, 16, 1, 3, True),     # box of 5.3 cutoffs: most probes within a cutoff of a periodic edge
+    (2000, (8, 8), 33.0, 32, 1, 3, True),     # ragged: N is not a multiple of 64
+    (1024, (8, 4), 33.0, 16, 1, 3, False),    # no walls, a slab of particles beyond the fp32-safe z range
+])
+def test_screened_kernel_matches_fp64_kernel(S, O, N, lat, L, slots, waves, nsw, walls):
+    """the compact-copy (int16 x,y + fp32 z) screen of smcx_sweep_mx.hip only pre-selects pairs:
+    every pair inside the cutoff is then decided and evaluated in fp64 exactly as the fp64 kernels
+    do.  Two builds of the same fp64 arithmetic differ by rounding (FMA contraction, summation
+    order: 1e-14 after a sweep, also between two geometries of the fp64 kernel); one pair missed
+    by the screen would shift the energy by >= 4|V(rc)| = 5e-3.  Accept decisions must be the same."""
+    rs = np.random.RandomState(N + slots)
+    R0 = O.fcc(lat[0], lat[1], L=L).reshape(-1, 3)[:N].copy()
+    R0 += 0.05 * rs.standard_normal(R0.shape)
+    R0[:, 0] -= L * np.rint(R0[:, 0] / L); R0[:, 1] -= L * np.rint(R0[:, 1] / L)
+    R0[:2, 2] = [119.99, -119.999]            # at both walls
+    flags = S.FLAGS_REFERENCE | S.FLAG_SERIES
+    if not walls:                              # z beyond zsafe = 2 Lz is stored as NaN: always a candidate
+        flags = S.FLAG_E0_RESTART | S.FLAG_SERIES
+        R0[R0[:, 2] > 6.0, 2] += 600.0
+        assert (R0[:, 2] > 500).sum() > 100
+    nrep = 3
+    out = []
+    for kernel in (1, 2):
+        fp64_slots, fp64_waves = (slots, waves) if kernel == 2 or S.geometry_supported_fp64(slots, waves) else (0, 0)
+        p = S.default_params(N, nrep, L=L, tune_slots=fp64_slots, tune_waves=fp64_waves, tune_kernel=kernel,
+                             flags=flags)
+        eng = S.Engine(p)
+        eng.upload(R0.ravel(), O.W_FIXTURE)
+        eng.run(1, nsw, 1)
+        E, jj = eng.series(nsw)
+        out.append((eng.positions().copy(), E.copy(), jj.copy(), eng.observables()["zhist"].copy()))
+        eng.close()
+    (Ra, Ea, ja, za), (Rb, Eb, jb, zb) = out
+    assert np.array_equal(ja, jb) and ja.sum() > 0
+    assert np.all(np.abs(Ea - Eb) <= 1e-9 * (1.0 + np.abs(Ea))), np.abs(Ea - Eb).max()
+    assert np.abs(Ra - Rb).max() < 1e-8
+    assert np.array_equal(za, zb)
+
+
 def film_state(O, Na, Nz, L, jitter, seed):
     """a dense fcc film (nearest neighbours inside LCA_cutoff) with thermal jitter"""
     rs = np.random.RandomState(seed)
@@ -518,6 +561,7 @@ def test_cluster_analysis_during_run(S, O):
     eng.close()
 
 
+@pytest.mark.parametrize("N", [66, 130, 1000, 2050, 4000])
 def test_ragged_sizes_with_padding(S, O, N):
     """N that does not fill the launch geometry (padding lanes/slots, partial last slot, runs
     that wrap inside a slot): two free-running sweeps against the oracle"""

@@ -1,0 +1,70 @@
+// valu_rates3.hip -- issue cost of the exact instruction forms the fp32 screening uses, measured
+// with inline asm (16 independent chains, 2 waves per SIMD, one 512-thread block per CU).
+// hipcc -O2 --offload-arch=gfx950 valu_rates3.hip -o valu_rates3
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+#define ITER 400
+#define X16(m) m(0) m(1) m(2) m(3) m(4) m(5) m(6) m(7) m(8) m(9) m(10) m(11) m(12) m(13) m(14) m(15)
+
+template <int OP> __global__ void __launch_bounds__(512) k(float *out, float cf, long long *cyc)
+{
+    float f[16], g[16]; unsigned u[16];
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    f2 p[16];
+    for (int j = 0; j < 16; j++) { f[j] = threadIdx.x * 1e-3f + j; g[j] = f[j] * 0.5f; u[j] = j; p[j] = f2{f[j], g[j]}; }
+    const long long t0 = __builtin_amdgcn_s_memrealtime();
+#pragma unroll 1
+    for (int it = 0; it < ITER; it++) {
+#define SUB(j) asm volatile("v_sub_f32_e32 %0, %1, %0" : "+v"(f[j]) : "s"(cf));
+#define MUL(j) asm volatile("v_mul_f32_e32 %0, %1, %1" : "=v"(f[j]) : "v"(g[j]));
+#define FMAC(j) asm volatile("v_fmac_f32_e32 %0, %1, %1" : "+v"(f[j]) : "v"(g[j]));
+#define FMA3(j) asm volatile("v_fma_f32 %0, %1, %1, %0" : "+v"(f[j]) : "v"(g[j]));
+#define CMPADDC(j) asm volatile("v_cmp_nle_f32_e32 vcc, %1, %2\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc" : "+v"(u[j]) : "s"(cf), "v"(f[j]) : "vcc");
+#define CMP(j) asm volatile("v_cmp_nle_f32_e32 vcc, %0, %1" : : "s"(cf), "v"(f[j]) : "vcc");
+#define ADDC(j) asm volatile("v_addc_co_u32_e32 %0, vcc, %0, %0, vcc" : "+v"(u[j]) : : "vcc");
+#define RND(j) asm volatile("v_rndne_f32_e32 %0, %1" : "=v"(f[j]) : "v"(g[j]));
+#define PKFMA(j) asm volatile("v_pk_fma_f32 %0, %1, %1, %0" : "+v"(p[j]) : "v"(p[(j + 1) & 15]));
+#define PKADD(j) asm volatile("v_pk_add_f32 %0, %1, %0" : "+v"(p[j]) : "v"(p[(j + 1) & 15]));
+#define PKMUL(j) asm volatile("v_pk_mul_f32 %0, %1, %1" : "=v"(p[j]) : "v"(p[(j + 1) & 15]));
+#define DOT2(j) asm volatile("v_dot2_f32_f16 %0, %1, %1, %0" : "+v"(f[j]) : "v"(g[j]));
+#define DOT2C(j) asm volatile("v_dot2c_f32_f16_e32 %0, %1, %1" : "+v"(f[j]) : "v"(g[j]));
+#define PKADDH(j) asm volatile("v_pk_add_f16 %0, %1, %0" : "+v"(f[j]) : "v"(g[j]));
+#define MINABS(j) asm volatile("v_min_f32_e64 %0, |%1|, %0" : "+v"(f[j]) : "v"(g[j]));
+#define PAIR(j) asm volatile("v_sub_f32_e32 %0, %3, %1\n\tv_mul_f32_e32 %0, %0, %0\n\tv_sub_f32_e32 %2, %3, %1\n\tv_fmac_f32_e32 %0, %2, %2\n\tv_sub_f32_e32 %2, %3, %1\n\tv_fmac_f32_e32 %0, %2, %2" : "=&v"(f[j]), "+v"(g[j]), "=&v"(p[j].x) : "s"(cf));
+        if (OP == 0) { X16(SUB) } if (OP == 1) { X16(MUL) } if (OP == 2) { X16(FMAC) } if (OP == 3) { X16(FMA3) }
+        if (OP == 4) { X16(CMPADDC) } if (OP == 5) { X16(CMP) } if (OP == 6) { X16(ADDC) } if (OP == 7) { X16(RND) }
+        if (OP == 8) { X16(PKFMA) } if (OP == 9) { X16(PKADD) } if (OP == 10) { X16(PKMUL) } if (OP == 11) { X16(DOT2) }
+        if (OP == 12) { X16(PKADDH) } if (OP == 13) { X16(MINABS) } if (OP == 14) { X16(PAIR) } if (OP == 15) { X16(DOT2C) }
+    }
+    const long long t1 = __builtin_amdgcn_s_memrealtime();
+    float s = 0; for (int j = 0; j < 16; j++) s += f[j] + g[j] + u[j] + p[j].x + p[j].y;
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+    if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
+}
+
+template <int OP> void run(const char *name, int per)
+{
+    const int blocks = 256;
+    float *out; long long *cyc;
+    hipMalloc(&out, sizeof(float) * blocks * 512); hipMalloc(&cyc, sizeof(long long) * blocks);
+    hipLaunchKernelGGL(k<OP>, dim3(blocks), dim3(512), 0, 0, out, 1.0000001f, cyc);
+    hipLaunchKernelGGL(k<OP>, dim3(blocks), dim3(512), 0, 0, out, 1.0000001f, cyc);
+    hipDeviceSynchronize();
+    std::vector<long long> h(blocks); hipMemcpy(h.data(), cyc, sizeof(long long) * blocks, hipMemcpyDeviceToHost);
+    double avr = 0; for (int i = 0; i < blocks; i++) avr += h[i]; avr /= blocks;
+    // 2 waves per SIMD share it: SIMD time per wave-instruction = elapsed / (2 * ITER * 16 * per)
+    const double ns = avr * 10.0 / (2.0 * ITER * 16 * per);
+    printf("%-34s %6.3f ns per wave-instr per SIMD  (%.2f cycles at 2.4 GHz, %.2f at 2.1)\n", name, ns, ns * 2.4, ns * 2.1);
+    hipFree(out); hipFree(cyc);
+}
+
+int main()
+{
+    run<0>("v_sub_f32_e32 v, s, v", 1); run<1>("v_mul_f32_e32 v, v, v", 1); run<2>("v_fmac_f32_e32", 1);
+    run<3>("v_fma_f32 (VOP3)", 1); run<4>("v_cmp_nle_e32 + v_addc_co_e32", 2); run<5>("v_cmp_nle_f32_e32", 1);
+    run<6>("v_addc_co_u32_e32", 1); run<7>("v_rndne_f32_e32", 1); run<8>("v_pk_fma_f32", 1); run<9>("v_pk_add_f32", 1);
+    run<10>("v_pk_mul_f32", 1); run<11>("v_dot2_f32_f16", 1); run<15>("v_dot2c_f32_f16_e32", 1); run<12>("v_pk_add_f16", 1);
+    run<13>("v_min_f32_e64 |v|", 1); run<14>("interior pair-eval (6 instr)", 6);
+    return 0;
+}
