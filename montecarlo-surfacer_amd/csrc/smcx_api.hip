@@ -635,6 +635,19 @@ extern "C" int smcx_series(smcx_handle *hh, double *E_series, int32_t *jj)
 }
 
 // for smcx_acf.hip: where the energy series of the last run lives
+#ifdef SMCX_STAMPS
+// diagnostic build only: per-phase cycle counts the instrumented sweep kernel left at the head of
+// each replica's displacement block (tools/phase_stamps.py)
+extern "C" int smcx_debug_stamps(smcx_handle *hh, double *out /*[nrep][6]*/)
+{
+    Handle &h = hh->h;
+    const size_t stride = (size_t)h.chunk * 3 * h.p.N;
+    for (int r = 0; r < h.p.nrep; r++)
+        HIPCHK(&h, hipMemcpy(out + 6 * (size_t)r, h.c.displ + r * stride, 6 * sizeof(double), hipMemcpyDeviceToHost));
+    return SMCX_OK;
+}
+#endif
+
 extern "C" int smcx_internal_series_view(smcx_handle *hh, const double **E, int *stride, int *maxsteps,
                                           int *nrep, double *T, int *device, void **stream)
 {

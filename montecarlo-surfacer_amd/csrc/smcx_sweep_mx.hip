@@ -140,6 +140,12 @@ __device__ __forceinline__ void mx_fetch(const double *Rg, int tid, int rot, int
     else { X = q[0]; Y = q[1]; Z = q[2]; }
 }
 
+#ifdef SMCX_STAMPS // diagnostic build only (tools/profile_stamps.sh): cycles per phase of a move
+#define STAMP(k) do { const long long t_ = __builtin_amdgcn_s_memtime(); ph[k] += t_ - tlast; tlast = t_; } while (0)
+#else
+#define STAMP(k) do { } while (0)
+#endif
+
 template <int S, int WPR, int MINW>
 __global__ void __launch_bounds__(64 * WPR, MINW)
 sweep_kernel_mx(SweepArgs a, DevCtx c, int nsweeps, double A, MxArgs m)
@@ -173,6 +179,10 @@ sweep_kernel_mx(SweepArgs a, DevCtx c, int nsweeps, double A, MxArgs m)
     Geo g; g.L = a.L; g.invL = a.invL; g.cutoff2 = a.cutoff2;
     double E = uniform_d(a.obs[rep].Ecur);
     int par = 0;
+#ifdef SMCX_STAMPS
+    long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long tlast = __builtin_amdgcn_s_memtime();
+#endif
     const double AoT = A * a.invT;
     const double Ao4T = A * 0.25 * a.invT;
 
@@ -231,6 +241,7 @@ sweep_kernel_mx(SweepArgs a, DevCtx c, int nsweeps, double A, MxArgs m)
                     nBz = ld_coherent(Rg + 3 * (n + 2) + 2);
                 }
 
+                STAMP(0); // proposal, probe fetch
                 // ---- screening ------------------------------------------------------
                 const float ninf = -__builtin_inff();
                 const unsigned axy = (unsigned)uniform((int)mx_pack_xy(Qx, Qy, m.toFix));
@@ -251,32 +262,14 @@ sweep_kernel_mx(SweepArgs a, DevCtx c, int nsweeps, double A, MxArgs m)
                     if (exB0) cb[0] &= ~top;
                     if constexpr (S > 1) { if (exB1) cb[0] &= ~(top >> 1); }
                 }
-                // ---- exact evaluation of the candidates ------------------------------
+                STAMP(1); // screening
+                // ---- exact evaluation of the candidates, reduction, Metropolis step ------------
                 // every lane fetches its candidates' fp64 positions and decides and evaluates
                 // them exactly as the fp64 kernel does, in ascending slot order per probe
                 Acc8 v = {0, 0, 0, 0, 0, 0, 0, 0};
                 double side[4], tot[8], sOld[4], sNew[4];
-                if (__builtin_amdgcn_ballot_w64(mx_any<S>(ca) || mx_any<S>(cb))) {
-                    int kA = mx_pick<S>(ca), kB = mx_pick<S>(cb);
-                    do {
-                        double XA = 0, YA = 0, ZA = 0, XB = 0, YB = 0, ZB = 0;
-                        if (kA >= 0) mx_fetch<S, T, (WPR > 1)>(Rg, tid, rot, kA, XA, YA, ZA);
-                        if (kB >= 0) mx_fetch<S, T, (WPR > 1)>(Rg, tid, rot, kB, XB, YB, ZB);
-                        if (kA >= 0 && pair_q<true>(g, Qx, Qy, Qz, XA, YA, ZA) < g.cutoff2)
-                            pair_hit(g, Qx, Qy, Qz, XA, YA, ZA, v.a0, v.a1, v.a2, v.a3);
-                        if (kB >= 0 && pair_q<true>(g, Bx, By, Bz, XB, YB, ZB) < g.cutoff2)
-                            pair_hit(g, Bx, By, Bz, XB, YB, ZB, v.b0, v.b1, v.b2, v.b3);
-                        kA = mx_pick<S>(ca); kB = mx_pick<S>(cb);
-                    } while (__builtin_amdgcn_ballot_w64(kA >= 0 || kB >= 0));
-                }
-                if (wave == 0)
-                    special_block(g, sh.roles, lane, role, hasA, hasB, hasA, Px, Py, Pz, Qx, Qy, Qz,
-                                  Bx, By, Bz, v, side);
-                else side[0] = side[1] = side[2] = side[3] = 0.0;
-                combine<WPR>(sh, par, lane, wave, v, side, tot, sOld, sNew);
-
                 bool acc = false;
-                if (hasA) {
+                auto metropolis = [&]() { // SMC acceptance, SMC.c:326-348; needs tot[0..3]
                     const double Un = 4.0 * tot[0], Fnx = tot[1], Fny = tot[2], Fnz = tot[3];
                     const double dX = Fmx * AoT + ddx;
                     const double dY = Fmy * AoT + ddy;
@@ -294,7 +287,29 @@ sweep_kernel_mx(SweepArgs a, DevCtx c, int nsweeps, double A, MxArgs m)
                         Rg[3 * n] = Qx; Rg[3 * n + 1] = Qy; Rg[3 * n + 2] = Qz; // the fp64 state
                     }
                     if (acc) { E = uniform_d(E + (Un - Um)); jacc++; }
+                };
+                if (__builtin_amdgcn_ballot_w64(mx_any<S>(ca) || mx_any<S>(cb))) {
+                    int kA = mx_pick<S>(ca), kB = mx_pick<S>(cb);
+                    do {
+                        double XA = 0, YA = 0, ZA = 0, XB = 0, YB = 0, ZB = 0;
+                        if (kA >= 0) mx_fetch<S, T, (WPR > 1)>(Rg, tid, rot, kA, XA, YA, ZA);
+                        if (kB >= 0) mx_fetch<S, T, (WPR > 1)>(Rg, tid, rot, kB, XB, YB, ZB);
+                        if (kA >= 0 && pair_q<true>(g, Qx, Qy, Qz, XA, YA, ZA) < g.cutoff2)
+                            pair_hit(g, Qx, Qy, Qz, XA, YA, ZA, v.a0, v.a1, v.a2, v.a3);
+                        if (kB >= 0 && pair_q<true>(g, Bx, By, Bz, XB, YB, ZB) < g.cutoff2)
+                            pair_hit(g, Bx, By, Bz, XB, YB, ZB, v.b0, v.b1, v.b2, v.b3);
+                        kA = mx_pick<S>(ca); kB = mx_pick<S>(cb);
+                    } while (__builtin_amdgcn_ballot_w64(kA >= 0 || kB >= 0));
                 }
+                STAMP(2); // candidates
+                if (wave == 0)
+                    special_block(g, sh.roles, lane, role, hasA, hasB, hasA, Px, Py, Pz, Qx, Qy, Qz,
+                                  Bx, By, Bz, v, side);
+                else side[0] = side[1] = side[2] = side[3] = 0.0;
+                STAMP(3); // walls, plane, side pair
+                combine<WPR>(sh, par, lane, wave, v, side, tot, sOld, sNew);
+                if (hasA) metropolis();
+                STAMP(4); // reduction, Metropolis step
 
                 if (hasB) {
                     double s0, s1, s2, s3;
@@ -319,6 +334,7 @@ sweep_kernel_mx(SweepArgs a, DevCtx c, int nsweeps, double A, MxArgs m)
                         tl++;
                     }
                 }
+                STAMP(5); // (probe B: candidates, reduction,) next particle's Um/Fm, slot rotation
             }
         }
         if (tid == 0) {
@@ -326,6 +342,12 @@ sweep_kernel_mx(SweepArgs a, DevCtx c, int nsweeps, double A, MxArgs m)
             a.rec[(size_t)rep * a.chunk + sw] = r;
         }
     }
+#ifdef SMCX_STAMPS
+    if (tid == 0) { // diagnostic: overwrite the head of this replica's (consumed) displacement block
+        double *dbg = const_cast<double *>(a.displ) + (size_t)rep * a.chunk * 3 * N;
+        for (int k = 0; k < 6; k++) dbg[k] = (double)ph[k];
+    }
+#endif
 }
 
 
