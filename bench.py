@@ -156,6 +156,7 @@ def main():
         pe_per_gpu_launchset = nrep * a.steps * 2.0 * N * (N - 1.0)
         value = world * pe_per_gpu_launchset / dt
         S_, W_, _ = eng.geometry
+        kform, kname = eng.kernel_form
         algo_bytes_per_launch = pe_per_gpu_launchset * BYTES_PER_PAIR_EVAL / max(launches, 1)
         launch_s = sweep_ms * 1e-3 / max(launches, 1)
         achieved = algo_bytes_per_launch / launch_s / 1e9
@@ -165,20 +166,18 @@ def main():
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                key = "N%d_R%d_S%d_W%d" % (N, nrep, S_, W_)
+                key = "N%d_R%d_S%d_W%d_K%d" % (N, nrep, S_, W_, kform)
                 if key in tj:
                     traffic = tj[key]["hbm_bytes_per_sweep"] * (a.steps / max(launches, 1))  # per launch
                     if "valu_wave_instr_per_sweep" in tj[key]:
                         wi = tj[key]["valu_wave_instr_per_sweep"]
-                        # what actually binds the kernel: VALU issue (one fp64 wave-instruction per
-                        # ~4.1 clocks per SIMD, 1024 SIMDs), from the committed PMC run
+                        # what actually binds the kernel: VALU issue on the 1024 SIMDs, from the
+                        # committed PMC run of this geometry and kernel form
                         valu = {"wave_instr_per_sweep": wi,
                                 "wave_instr_per_64_pair_evals": wi / (nrep * 2.0 * N * (N - 1.0) / 64.0),
-                                "floor_wave_instr_per_64_pair_evals": 7.0,
-                                "issue_slots_used": wi * 4.1 / (sweep_ms * 1e-3 / a.steps * 1024 * 2.15e9),
-                                "note": "SQ_INSTS_VALU from profiles/r01_pmc_summary.txt; 4.1 clocks per fp64 "
-                                        "wave-instruction and 2.15 GHz under load are measured "
-                                        "(profiles/r01_valu_issue_costs.log)"}
+                                "screen_wave_instr_per_64_pair_evals": tj[key].get("screen_instr_per_pair_eval"),
+                                "simd_clocks_per_wave_instr": (sweep_ms * 1e-3 / a.steps) * 1024 * 2.15e9 / wi,
+                                "note": tj[key].get("_valu_note", "")}
             except Exception:
                 traffic = None
         out = {
@@ -196,13 +195,13 @@ def main():
                                       "observables at the end (%.2f ms)" % (world, "RCCL" if backend == "nccl" else backend, gather_ms)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "smcx::sweep_kernel<S=%d,WPR=%d>" % (S_, W_),
+                         "kernel": kname,
                          "launches": launches, "avg_launch_ms": sweep_ms / max(launches, 1),
                          "ms_per_sweep": sweep_ms / a.steps,
                          "algorithmic_bytes_per_launch": algo_bytes_per_launch,
                          "note": "algorithmic bytes = 24 B x pair-evals (streaming model, SURVEY 8d); "
                                  "positions are register-resident, so frac > 1 is legitimate and the "
-                                 "binding resource is fp64 VALU issue, not HBM"},
+                                 "binding resource is VALU issue, not HBM (see valu)"},
             "valu": valu,
             "device_ms": {"sweep_kernels": sweep_ms, "whole_run": run_ms},
             "observables": {"mean_acceptance": summ["mean_acceptance"], "mean_energy": summ["mean_of_meanE"],

@@ -191,6 +191,10 @@ int smcx_last_kernel_ms(smcx_handle *h, double *ms, int *launches);
 int smcx_last_run_ms(smcx_handle *h, double *ms);
 /* the launch geometry chosen for this handle */
 int smcx_geometry(const smcx_handle *h, int *slots, int *waves_per_replica, int *lds_bytes);
+/* which sweep kernel this handle launches: 1 = fp64 (positions as fp64 in registers), 2 = screened
+ * (int16 x,y + fp32 z copies in registers, fp64 evaluation of the candidates); name, if not NULL,
+ * receives the kernel's name (at most len bytes) */
+int smcx_kernel_form(const smcx_handle *h, int *form, char *name, int len);
 
 /* Teacher-forced evaluator (stateless; tests and debugging): for each of nrep
  * replicas evaluates what SMC.c:300-304 and 319-321 evaluate for particle

@@ -57,7 +57,7 @@ EXPORTS = [
     "smcx_total_energy", "smcx_rng_export", "smcx_rng_import", "smcx_obs_device_bytes",
     "smcx_export_observables_device", "smcx_last_kernel_ms", "smcx_last_run_ms", "smcx_geometry", "smcx_eval_moves",
     "smcx_rng_seed", "smcx_one_particle_moves",
-    "smcx_cluster_counts", "smcx_cluster_update", "smcx_cluster_analysis",
+    "smcx_cluster_counts", "smcx_cluster_update", "smcx_cluster_analysis", "smcx_kernel_form",
 ]
 
 
@@ -100,6 +100,7 @@ def _lib():
         L.smcx_last_kernel_ms.argtypes = [vp, _dp, C.POINTER(C.c_int)]
         L.smcx_last_run_ms.argtypes = [vp, _dp]
         L.smcx_geometry.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.smcx_kernel_form.argtypes = [vp, C.POINTER(C.c_int), C.c_char_p, C.c_int]
         L.smcx_eval_moves.argtypes = [C.POINTER(Params), _dp, _dp, _i32p, _dp, _dp]
         L.smcx_rng_seed.argtypes = [_u32p, C.c_uint32]
         L.smcx_rng_seed.restype = None
@@ -203,6 +204,14 @@ class Engine:
         s, w, l = C.c_int(), C.c_int(), C.c_int()
         self._chk(_lib().smcx_geometry(self._h, C.byref(s), C.byref(w), C.byref(l)), "smcx_geometry")
         return s.value, w.value, l.value
+
+    @property
+    def kernel_form(self):
+        """(form, name): 1 = fp64 sweep kernel, 2 = screened sweep kernel"""
+        f = C.c_int(0)
+        buf = C.create_string_buffer(96)
+        self._chk(_lib().smcx_kernel_form(self._h, C.byref(f), buf, 96), "smcx_kernel_form")
+        return f.value, buf.value.decode()
 
     def upload(self, R0, W, seeds=None):
         R0 = np.ascontiguousarray(R0, dtype=np.float64)

@@ -320,9 +320,9 @@ __device__ __forceinline__ void fused_pass(const Geo &g, const double (&x)[S], c
 // role 3  : pair (new position of n) -> B, kept aside   (lane 31)
 // After the accept/reject decision the matching side term completes B's sums.
 // The per-lane constants live in LDS and are read once per move by wave 0.
-struct RoleTable {
-    double sx[64], sy[64]; // site position i*dw, j*dw (SMC.c:748-750)
-    double ca[64], cb[64]; // W[2m], W[2m+1] or a0, b0 or 1,1
+struct RoleTable {         // lanes l and l+32 stand for the same site (acting on probe A resp. B)
+    double sx[32], sy[32]; // site position i*dw, j*dw (SMC.c:748-750)
+    double ca[32], cb[32]; // W[2m], W[2m+1] or a0, b0 or 1,1
     int role[64];          // -1 = none
     double Lz, invLz, halfLz; // wall geometry, read by the few wall lanes only
 };
@@ -351,7 +351,7 @@ __device__ __forceinline__ void fill_roles(const DevCtx &c, RoleTable &rt, int l
     }
     if (lane == SIDE_LANE_OLD) role = 2;
     if (lane == SIDE_LANE_NEW) role = 3;
-    rt.sx[lane] = sx; rt.sy[lane] = sy; rt.ca[lane] = ca; rt.cb[lane] = cb;
+    if (lane < 32) { rt.sx[lane] = sx; rt.sy[lane] = sy; rt.ca[lane] = ca; rt.cb[lane] = cb; }
     rt.role[lane] = role;
     if (lane == 0) { rt.Lz = c.Lz; rt.invLz = c.invLz; rt.halfLz = c.halfLz; }
 }
@@ -386,7 +386,7 @@ __device__ __forceinline__ void special_block(const Geo &g, const RoleTable &rt,
         const double tx = onA ? Ax : Bx, ty = onA ? Ay : By, tz = onA ? Az : Bz;
         double dx, dy, dz;
         if (wallrole) {
-            dx = tx - rt.sx[lane]; dy = ty - rt.sy[lane];
+            dx = tx - rt.sx[lane & 31]; dy = ty - rt.sy[lane & 31];
             dz = wall_dz(rt, tz);
         } else {
             const bool old = (role == 2);
@@ -399,7 +399,7 @@ __device__ __forceinline__ void special_block(const Geo &g, const RoleTable &rt,
         const double dr2 = dx * dx + dy * dy + dz * dz;
         double e = 0.0, fx = 0.0, fy = 0.0, fz = 0.0;
         if (plane || dr2 < g.cutoff2)
-            lj_acc(dx, dy, dz, dr2, rt.ca[lane], rt.cb[lane], e, fx, fy, fz);
+            lj_acc(dx, dy, dz, dr2, rt.ca[lane & 31], rt.cb[lane & 31], e, fx, fy, fz);
         if (wallrole && onA) { v.a0 += e; v.a1 += fx; v.a2 += fy; v.a3 += fz; }
         else if (wallrole) { v.b0 += e; v.b1 += fx; v.b2 += fy; v.b3 += fz; }
         else { side[0] = e; side[1] = fx; side[2] = fy; side[3] = fz; }

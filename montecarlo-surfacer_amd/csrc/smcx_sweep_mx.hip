@@ -351,6 +351,284 @@ sweep_kernel_mx(SweepArgs a, DevCtx c, int nsweeps, double A, MxArgs m)
 }
 
 
+// ---------------------------------------------------------------------------------
+// Variant with z outside the register file: fp16 in LDS, 2 bytes per particle.  The registers
+// then hold one VGPR per particle (x,y), which lets a third wavefront per SIMD cover the
+// latency-bound sequential part of the other two.  dz of two slots is one v_pk_add_f16, and
+// dz^2 enters the fp32 sum through v_fma_mix_f32.  fp16 keeps |z| < zsafe (a power of two)
+// to within zsafe * 2^-12; the wider margin this needs is part of thr (launch_sweeps_mx).
+// ---------------------------------------------------------------------------------
+typedef _Float16 mz_h2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ unsigned mz_store_zh(double z, float zsafe)
+{
+    const _Float16 h = (_Float16)(float)z;
+    const unsigned short bits = __builtin_bit_cast(unsigned short, h);
+    return (fabs(z) < (double)zsafe) ? (unsigned)bits : 0x7E00u; // NaN: always a candidate
+}
+
+// rotate the slots by one: x,y in registers, z in this wavefront's LDS block
+template <int S>
+__device__ __forceinline__ void mz_rotate(unsigned (&xy)[S], unsigned (&zw)[S / 2][64], int lane)
+{
+    const unsigned t = xy[0];
+#pragma unroll
+    for (int k = 0; k + 1 < S; k++) xy[k] = xy[k + 1];
+    xy[S - 1] = t;
+    const unsigned first = zw[0][lane];
+    unsigned cur = first;
+#pragma unroll
+    for (int j = 0; j + 1 < S / 2; j++) {
+        const unsigned nxt = zw[j + 1][lane];
+        zw[j][lane] = __builtin_amdgcn_alignbit(nxt, cur, 16); // (cur.hi, nxt.lo)
+        cur = nxt;
+    }
+    zw[S / 2 - 1][lane] = __builtin_amdgcn_alignbit(first, cur, 16);
+}
+
+template <int S>
+__device__ __forceinline__ void mz_screen(const unsigned (&xy)[S], const unsigned (&zw)[S / 2][64], int lane,
+                                          unsigned axy, unsigned azz, unsigned bxy, unsigned bzz, float u2,
+                                          float thr, unsigned (&ca)[(S + 31) / 32], unsigned (&cb)[(S + 31) / 32])
+{
+#pragma unroll
+    for (int j = 0; j < S / 2; j++) {
+        const mz_h2 zz = __builtin_bit_cast(mz_h2, zw[j][lane]);
+        const mz_h2 da = __builtin_bit_cast(mz_h2, azz) - zz;
+        const mz_h2 db = __builtin_bit_cast(mz_h2, bzz) - zz;
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const int k = 2 * j + h;
+            const mx_s2 ea = __builtin_bit_cast(mx_s2, axy) - __builtin_bit_cast(mx_s2, xy[k]);
+            const mx_s2 eb = __builtin_bit_cast(mx_s2, bxy) - __builtin_bit_cast(mx_s2, xy[k]);
+            const float fa = u2 * (float)__builtin_amdgcn_sdot2(ea, ea, 0, true);
+            const float fb = u2 * (float)__builtin_amdgcn_sdot2(eb, eb, 0, true);
+            const float za = (float)(h ? da.y : da.x), zb = (float)(h ? db.y : db.x);
+            mx_push(ca[k >> 5], __builtin_fmaf(za, za, fa), thr);
+            mx_push(cb[k >> 5], __builtin_fmaf(zb, zb, fb), thr);
+        }
+    }
+}
+
+template <int S, int WPR, int MINW>
+__global__ void __launch_bounds__(64 * WPR, MINW)
+sweep_kernel_mz(SweepArgs a, DevCtx c, int nsweeps, double A, MxArgs m)
+{
+    constexpr int T = 64 * WPR;
+    constexpr int NW = (S + 31) / 32;
+    __shared__ SweepShared<WPR> sh;
+
+    const int rep = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = uniform(tid >> 6);
+    const int N = a.N;
+    double *Rg = a.R + (size_t)rep * 3 * N;
+
+    // ---- register-resident compact copies: particle l in lane l % T, slot l / T ------
+    // x,y in registers (one VGPR per particle); z as fp16 in LDS, slots 2j and 2j+1 of a lane in
+    // one dword, slot-pair-major so that a wavefront's read of one pair is conflict-free
+    static_assert(S % 2 == 0, "slot pairs");
+    __shared__ unsigned zl[WPR][S / 2][64];
+    unsigned xy[S];
+    unsigned (&zw)[S / 2][64] = zl[wave];
+#pragma unroll
+    for (int j = 0; j < S / 2; j++) {
+        unsigned pair = 0u;
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const int k = 2 * j + h;
+            const int l = k * T + tid;
+            unsigned zh = 0x7C00u; // +inf: a padding slot
+            if (l < N) { xy[k] = mx_pack_xy(Rg[3 * l], Rg[3 * l + 1], m.toFix); zh = mz_store_zh(Rg[3 * l + 2], m.zsafe); }
+            else xy[k] = 0u;
+            pair |= zh << (16 * h);
+        }
+        zw[j][lane] = pair;
+    }
+    int rot = 0; // register slot j holds logical slot (j + rot) % S
+
+    if (wave == 0) fill_roles(c, sh.roles, lane);
+    __syncthreads();
+    const int role = (wave == 0) ? sh.roles.role[lane] : -1;
+
+    Geo g; g.L = a.L; g.invL = a.invL; g.cutoff2 = a.cutoff2;
+    double E = uniform_d(a.obs[rep].Ecur);
+    int par = 0;
+#ifdef SMCX_STAMPS
+    long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long tlast = __builtin_amdgcn_s_memtime();
+#endif
+    const double AoT = A * a.invT;
+    const double Ao4T = A * 0.25 * a.invT;
+
+#pragma unroll 1
+    for (int sw = 0; sw < nsweeps; sw++) {
+        if constexpr (WPR > 1) __syncthreads();
+        const double *displ = a.displ + ((size_t)rep * a.chunk + sw) * 3 * N;
+        const double *uni = a.uni + ((size_t)rep * a.chunk + sw) * N;
+        const int n0 = uniform(a.offs[(size_t)rep * a.chunk + sw]);
+        int jacc = 0;
+#pragma unroll 1
+        for (int run = 0; run < 2; run++) {
+            const int first = run == 0 ? n0 : 0;
+            const int len = run == 0 ? N - n0 : n0;
+            if (len == 0) continue;
+            const int vbase = run == 0 ? 0 : N - n0;
+            const int ks = first / T;
+            while (rot != ks) { mz_rotate<S>(xy, zw, lane); rot = (rot + 1 == S) ? 0 : rot + 1; }
+            int tl = first - ks * T - 1;
+
+            double Px = 0.0, Py = 0.0, Pz = FAR_PROBE;
+            double Um = 0.0, Fmx = 0.0, Fmy = 0.0, Fmz = 0.0;
+            // the next particle's fp64 position comes from memory, one move ahead of its use
+            double nBx = ld_coherent(Rg + 3 * first), nBy = ld_coherent(Rg + 3 * first + 1),
+                   nBz = ld_coherent(Rg + 3 * first + 2);
+            // this move's displacement and log-uniform: wave-uniform, read-only for the whole
+            // kernel -> scalar loads through the constant address space, one move ahead
+            typedef const __attribute__((address_space(4))) double *kptr;
+            const kptr dK = (kptr)(unsigned long long)displ + 3 * (size_t)first;
+            const kptr uK = (kptr)(unsigned long long)uni + vbase;
+            double ndx = dK[0], ndy = dK[1], ndz = dK[2], nlu = uK[0];
+#pragma unroll 1
+            for (int i = -1; i < len; i++) {
+                const int n = first + i;
+                const bool hasA = (i >= 0);
+                const double ddx = ndx, ddy = ndy, ddz = ndz, lu = nlu; // of move i (unused for i = -1)
+                if (i + 1 < len) {
+                    ndx = dK[3 * (i + 1)]; ndy = dK[3 * (i + 1) + 1]; ndz = dK[3 * (i + 1) + 2];
+                    nlu = uK[i + 1];
+                }
+                double Qx = 0.0, Qy = 0.0, Qz = FAR_PROBE; // proposal, SMC.c:307-316
+                if (hasA) {
+                    Qx = Px + (Fmx * AoT + ddx);
+                    Qy = Py + (Fmy * AoT + ddy);
+                    Qz = Pz + (Fmz * AoT + ddz);
+                    Qx = Qx - a.L * __builtin_rint(Qx * a.invL);
+                    Qy = Qy - a.L * __builtin_rint(Qy * a.invL);
+                    Qx = uniform_d(Qx); Qy = uniform_d(Qy); Qz = uniform_d(Qz);
+                }
+                const bool hasB = (i + 1 < len);
+                const bool cross = hasB && (tl == T - 1);
+                double Bx = 0.0, By = 0.0, Bz = FAR_PROBE;
+                if (hasB) { Bx = uniform_d(nBx); By = uniform_d(nBy); Bz = uniform_d(nBz); }
+                if (i + 2 < len) {
+                    nBx = ld_coherent(Rg + 3 * (n + 2)); nBy = ld_coherent(Rg + 3 * (n + 2) + 1);
+                    nBz = ld_coherent(Rg + 3 * (n + 2) + 2);
+                }
+
+                STAMP(0); // proposal, probe fetch
+                // ---- screening ------------------------------------------------------
+                const unsigned axy = (unsigned)uniform((int)mx_pack_xy(Qx, Qy, m.toFix));
+                const unsigned bxy = (unsigned)uniform((int)mx_pack_xy(Bx, By, m.toFix));
+                const unsigned azh = hasA ? mz_store_zh(Qz, m.zsafe) : 0xFC00u; // -inf: a disabled probe
+                const unsigned bzh = hasB ? mz_store_zh(Bz, m.zsafe) : 0xFC00u;
+                const unsigned azz = (unsigned)uniform((int)(azh | (azh << 16)));
+                const unsigned bzz = (unsigned)uniform((int)(bzh | (bzh << 16)));
+                unsigned ca[NW], cb[NW];
+#pragma unroll
+                for (int w = 0; w < NW; w++) { ca[w] = 0u; cb[w] = 0u; }
+                mz_screen<S>(xy, zw, lane, axy, azz, bxy, bzz, m.u2, m.thr, ca, cb);
+                // the moving particle itself and the particle probe B stands for are not neighbours
+                {
+                    constexpr unsigned top = 1u << ((NW == 1 ? S : 32) - 1); // slot 0
+                    const bool exA0 = (tid == tl);
+                    const bool exB0 = (hasA && tid == tl) || (hasB && !cross && tid == tl + 1);
+                    const bool exB1 = cross && (tid == 0);
+                    if (exA0) ca[0] &= ~top;
+                    if (exB0) cb[0] &= ~top;
+                    if constexpr (S > 1) { if (exB1) cb[0] &= ~(top >> 1); }
+                }
+                STAMP(1); // screening
+                // ---- exact evaluation of the candidates, reduction, Metropolis step ------------
+                // every lane fetches its candidates' fp64 positions and decides and evaluates
+                // them exactly as the fp64 kernel does, in ascending slot order per probe
+                Acc8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+                double side[4], tot[8], sOld[4], sNew[4];
+                bool acc = false;
+                auto metropolis = [&]() { // SMC acceptance, SMC.c:326-348; needs tot[0..3]
+                    const double Un = 4.0 * tot[0], Fnx = tot[1], Fny = tot[2], Fnz = tot[3];
+                    const double dX = Fmx * AoT + ddx;
+                    const double dY = Fmy * AoT + ddy;
+                    const double dZ = Fmz * AoT + ddz;
+                    const double gx = Fnx - Fmx, gy = Fny - Fmy, gz = Fnz - Fmz;
+                    const double deltaW = (gx * gx + gy * gy + gz * gz +
+                                           2.0 * (gx * Fmx + gy * Fmy + gz * Fmz)) * Ao4T;
+                    const double arg = Un - Um +
+                                       (dX * (Fnx + Fmx) + dY * (Fny + Fmy) + dZ * (Fnz + Fmz)) * 0.5 + deltaW;
+                    acc = (lu < -arg * a.invT);
+                    acc = (uniform((int)acc) != 0);
+                    const bool upd = acc && (tid == tl);
+                    if (upd) {
+                        xy[0] = axy;
+                        reinterpret_cast<unsigned short *>(&zw[0][lane])[0] = (unsigned short)azh; // slot 0 = low half
+                        Rg[3 * n] = Qx; Rg[3 * n + 1] = Qy; Rg[3 * n + 2] = Qz; // the fp64 state
+                    }
+                    if (acc) { E = uniform_d(E + (Un - Um)); jacc++; }
+                };
+                if (__builtin_amdgcn_ballot_w64(mx_any<S>(ca) || mx_any<S>(cb))) {
+                    int kA = mx_pick<S>(ca), kB = mx_pick<S>(cb);
+                    do {
+                        double XA = 0, YA = 0, ZA = 0, XB = 0, YB = 0, ZB = 0;
+                        if (kA >= 0) mx_fetch<S, T, (WPR > 1)>(Rg, tid, rot, kA, XA, YA, ZA);
+                        if (kB >= 0) mx_fetch<S, T, (WPR > 1)>(Rg, tid, rot, kB, XB, YB, ZB);
+                        if (kA >= 0 && pair_q<true>(g, Qx, Qy, Qz, XA, YA, ZA) < g.cutoff2)
+                            pair_hit(g, Qx, Qy, Qz, XA, YA, ZA, v.a0, v.a1, v.a2, v.a3);
+                        if (kB >= 0 && pair_q<true>(g, Bx, By, Bz, XB, YB, ZB) < g.cutoff2)
+                            pair_hit(g, Bx, By, Bz, XB, YB, ZB, v.b0, v.b1, v.b2, v.b3);
+                        kA = mx_pick<S>(ca); kB = mx_pick<S>(cb);
+                    } while (__builtin_amdgcn_ballot_w64(kA >= 0 || kB >= 0));
+                }
+                STAMP(2); // candidates
+                if (wave == 0)
+                    special_block(g, sh.roles, lane, role, hasA, hasB, hasA, Px, Py, Pz, Qx, Qy, Qz,
+                                  Bx, By, Bz, v, side);
+                else side[0] = side[1] = side[2] = side[3] = 0.0;
+                STAMP(3); // walls, plane, side pair
+                combine<WPR>(sh, par, lane, wave, v, side, tot, sOld, sNew);
+                if (hasA) metropolis();
+                STAMP(4); // reduction, Metropolis step
+
+                if (hasB) {
+                    double s0, s1, s2, s3;
+                    if constexpr (WPR == 1) {
+                        const int src = acc ? SIDE_LANE_NEW : SIDE_LANE_OLD;
+                        s0 = rdlane(sOld[0], src); s1 = rdlane(sOld[1], src);
+                        s2 = rdlane(sOld[2], src); s3 = rdlane(sOld[3], src);
+                    } else {
+                        s0 = acc ? sNew[0] : sOld[0]; s1 = acc ? sNew[1] : sOld[1];
+                        s2 = acc ? sNew[2] : sOld[2]; s3 = acc ? sNew[3] : sOld[3];
+                    }
+                    Um = uniform_d(4.0 * (tot[4] + s0));
+                    Fmx = uniform_d(tot[5] + s1);
+                    Fmy = uniform_d(tot[6] + s2);
+                    Fmz = uniform_d(tot[7] + s3);
+                    Px = Bx; Py = By; Pz = Bz;
+                    if (cross) {
+                        mz_rotate<S>(xy, zw, lane);
+                        rot = (rot + 1 == S) ? 0 : rot + 1;
+                        tl = 0;
+                    } else {
+                        tl++;
+                    }
+                }
+                STAMP(5); // (probe B: candidates, reduction,) next particle's Um/Fm, slot rotation
+            }
+        }
+        if (tid == 0) {
+            SweepRec r; r.E = E; r.accepted = jacc; r.pad = 0;
+            a.rec[(size_t)rep * a.chunk + sw] = r;
+        }
+    }
+#ifdef SMCX_STAMPS
+    if (tid == 0) { // diagnostic: overwrite the head of this replica's (consumed) displacement block
+        double *dbg = const_cast<double *>(a.displ) + (size_t)rep * a.chunk * 3 * N;
+        for (int k = 0; k < 6; k++) dbg[k] = (double)ph[k];
+    }
+#endif
+}
+
+
 typedef void (*sweep_mx_fn)(SweepArgs, DevCtx, int, double, MxArgs);
 
 // 3 VGPRs per particle: twice the slots of the fp64 kernels at the same occupancy
@@ -365,12 +643,34 @@ static sweep_mx_fn lookup_mx(int S, int WPR)
     return nullptr;
 }
 
+// z in LDS: one VGPR per particle
+static sweep_mx_fn lookup_mz(int S, int WPR)
+{
+#define SMCX_MZ(s, w, m) if (S == s && WPR == w) return sweep_kernel_mz<s, w, m>;
+    SMCX_MZ(64, 1, 4) SMCX_MZ(32, 2, 4) SMCX_MZ(64, 4, 3) SMCX_MZ(32, 1, 4) SMCX_MZ(64, 2, 3)
+#undef SMCX_MZ
+    return nullptr;
+}
+
 bool mx_supported(int S, int WPR) { return lookup_mx(S, WPR) != nullptr; }
+
+bool mx_lds_z(int S, int WPR, double Lz)
+{
+    static const char *env_mz = getenv("SMCX_MZ");
+    bool mz = (S == 64 && WPR == 1 && Lz <= 480.0);
+    if (env_mz) mz = (env_mz[0] != '0');
+    return mz && lookup_mz(S, WPR) != nullptr;
+}
 
 hipError_t launch_sweeps_mx(const SweepArgs &a, const DevCtx &c, int S, int WPR, int nsweeps, double A,
                             hipStream_t st)
 {
     sweep_mx_fn fm = lookup_mx(S, WPR);
+    // z as fp16 in LDS (sweep_kernel_mz) where it measured faster: one wavefront per replica with 64
+    // particles per lane, which then fits four waves per SIMD -- unless the box is so tall that fp16
+    // would widen the screen noticeably.  SMCX_MZ=0/1 forces the choice for A/B measurements.
+    const bool mz = mx_lds_z(S, WPR, c.Lz);
+    if (mz) fm = lookup_mz(S, WPR);
     if (!fm) return hipErrorInvalidValue;
     // screening threshold: see the bound in the comment of sweep_kernel_mx
     const double rc = sqrt(c.cutoff2), eps = 5.9604644775390625e-8; // 2^-24
@@ -384,6 +684,15 @@ hipError_t launch_sweeps_mx(const SweepArgs &a, const DevCtx &c, int S, int WPR,
     m.u2 = (float)(u * u);
     m.toFix = 65536.0 / c.L;
     m.zsafe = (float)zsafe;
+    if (mz) { // fp16 z: |z| < zsafe_h (power of two) is kept to zsafe_h * 2^-12, particle and probe
+        double zs = 1.0;
+        while (zs < 0.51 * c.Lz) zs *= 2.0;
+        const double dz = 2.0 * zs / 4096.0 + (rc + 1.0) / 1024.0;
+        const double mzh = 2.0 * rc * dz + dz * dz;
+        const double margin_h = (m_xy + mzh) * 1.01 + 8.0 * eps * (c.cutoff2 + m_xy + mzh) + 1e-6 * c.cutoff2;
+        m.thr = nextafterf((float)(c.cutoff2 + margin_h), INFINITY);
+        m.zsafe = (float)zs;
+    }
     hipLaunchKernelGGL(fm, dim3(c.nrep), dim3(64 * WPR), 0, st, a, c, nsweeps, A, m);
     return hipGetLastError();
 }
