@@ -1,7 +1,6 @@
-// smcx_sweep_mx.hip -- the fp32-screened form of the sweep kernel.  Its own translation
-// unit because it is built with -fno-slp-vectorize: the SLP vectoriser otherwise turns the
-// screening arithmetic into v_pk_*_f32 on shuffled register pairs, moves the probes into
-// VGPRs and spills the positions.
+// smcx_sweep_mx.hip -- the screened form of the sweep kernel.  Its own translation unit because
+// it is built with -fno-slp-vectorize: the SLP vectoriser otherwise repacks the screening
+// arithmetic onto shuffled register pairs, moves the probes into VGPRs and spills the positions.
 #include "smcx_device.hpp"
 #include "smcx_kernels.h"
 
@@ -16,28 +15,31 @@ namespace smcx {
 // Screened form of the same sweep.  The cutoff test -- which 99.96 % of the pair
 // evaluations fail at the benchmark density -- is screened on compact copies of the
 // positions, with a threshold widened by a proven error bound; every candidate is then
-// decided and evaluated EXACTLY as in sweep_kernel, in fp64, from the fp64 positions in
-// memory.  The set of pairs inside the cutoff, the values added and their order are those
-// of the fp64 kernels, so the results are bit-identical to theirs.
+// decided and evaluated in fp64, with the arithmetic of the fp64 kernels, from the fp64
+// positions in memory.  Same pairs inside the cutoff, same values, same order of summation
+// per lane: the results differ from those of the fp64 kernels by rounding only.
 //
-// Compact copy, 2 VGPRs per particle instead of 6:
+// Compact copy of a particle:
 //   x,y  two 16-bit fixed-point numbers in one register, the box [-L/2, L/2) mapped onto the
 //        whole int16 range: the subtraction of two of them (v_pk_sub_i16) wraps modulo 2^16,
 //        which IS the minimum image -- no rint, no branch on where the probe sits;
 //        dx^2 + dy^2 is one v_dot2_i32_i16 (saturating);
-//   z    fp32 (not periodic, unbounded).
-// 64 particles per lane fit beside everything else, so N = 4096 needs ONE wavefront per
-// replica -- no workgroup barrier, no cross-wave reduction -- at two waves per SIMD.
+//   z    (not periodic, unbounded) either fp32 in a second register (ZL = false), or fp16 in
+//        LDS, two bytes per particle (ZL = true): dz of two slots is then one v_pk_add_f16 and
+//        dz^2 enters the fp32 sum through v_fma_mix_f32.
+// With one or two VGPRs per particle 64 particles per lane fit beside everything else, so
+// N = 4096 runs as ONE wavefront per replica -- no workgroup barrier, no cross-wave
+// reduction -- at two (ZL = false) or four (ZL = true) waves per SIMD.
 //
 // Screening bound (host side: launch_sweeps_mx).  With u = L/65536 the stored x differs
 // from the true one by <= u/2, so an integer difference is within 1 unit of the true
 // (minimum-image) one and dxi^2 + dyi^2 <= (true, in units) + 2*sqrt(2)*R + 2 for a pair
-// inside the cutoff R = rc/u.  z: |fl32(z) - z| <= 2^-24 |z| with |z| <= zsafe.  The sum of
-// both, plus the fp32 rounding of the final expression, is `margin`; the test
-// `!(thr <= q)` with thr = rc^2 + margin never rejects a pair the fp64 test accepts.
-// A z outside [-zsafe, zsafe] is stored as NaN, which the (unordered) compare always
-// passes on to the exact evaluation.  Padding slots hold z = +inf, a disabled probe
-// z = -inf: never candidates.
+// inside the cutoff R = rc/u.  z: |fl32(z) - z| <= 2^-24 |z|, resp. |fl16(z) - z| <= zsafe *
+// 2^-12 for |z| < zsafe (a power of two).  The sum of both, plus the rounding of the final
+// expression, is `margin`; the test `!(thr <= q)` with thr = rc^2 + margin never rejects a
+// pair the fp64 test accepts.  A z outside the safe range is stored as NaN, which the
+// (unordered) compare always passes on to the exact evaluation.  Padding slots hold
+// z = +inf, a disabled probe z = -inf: never candidates.
 // ---------------------------------------------------------------------------------
 struct MxArgs {
     float thr;      // screening threshold rc^2 + margin
@@ -47,6 +49,7 @@ struct MxArgs {
 };
 
 typedef short mx_s2 __attribute__((ext_vector_type(2)));
+typedef _Float16 mx_h2 __attribute__((ext_vector_type(2)));
 
 // x,y -> two int16 in one register (x low, y high); x = +L/2 wraps onto -L/2, the same point
 __device__ __forceinline__ unsigned mx_pack_xy(double x, double y, double toFix)
@@ -54,75 +57,145 @@ __device__ __forceinline__ unsigned mx_pack_xy(double x, double y, double toFix)
     const int xi = (int)__builtin_rint(x * toFix), yi = (int)__builtin_rint(y * toFix);
     return ((unsigned)xi & 0xffffu) | ((unsigned)yi << 16);
 }
-__device__ __forceinline__ float mx_store_z(double z, float zsafe)
+__device__ __forceinline__ float mx_z32(double z, float zsafe)
 {
     return (fabs(z) <= (double)zsafe) ? (float)z : __builtin_nanf("");
 }
-
-template <int S>
-__device__ __forceinline__ void rotate1m(unsigned (&xy)[S], float (&z)[S])
+__device__ __forceinline__ unsigned mx_z16(double z, float zsafe) // fp16 bits
 {
-    if constexpr (S > 1) {
-        const unsigned t = xy[0]; const float tz = z[0];
+    const unsigned short bits = __builtin_bit_cast(unsigned short, (_Float16)(float)z);
+    return (fabs(z) < (double)zsafe) ? (unsigned)bits : 0x7E00u; // NaN
+}
+
+// rotate the register-resident slots by one: slot j <- slot j+1
+template <int S, int SZ>
+__device__ __forceinline__ void mx_rotate(unsigned (&xy)[S], float (&z)[SZ])
+{
+    const unsigned t = xy[0];
 #pragma unroll
-        for (int k = 0; k + 1 < S; k++) { xy[k] = xy[k + 1]; z[k] = z[k + 1]; }
-        xy[S - 1] = t; z[S - 1] = tz;
+    for (int k = 0; k + 1 < S; k++) xy[k] = xy[k + 1];
+    xy[S - 1] = t;
+    if constexpr (SZ == S) {
+        const float tz = z[0];
+#pragma unroll
+        for (int k = 0; k + 1 < S; k++) z[k] = z[k + 1];
+        z[S - 1] = tz;
+    }
+}
+// the same for this wavefront's block of fp16 z in LDS (slots 2j, 2j+1 of a lane in one dword)
+template <int S>
+__device__ __forceinline__ void mx_rotate_lds(unsigned (&zw)[S / 2][64], int lane)
+{
+    const unsigned first = zw[0][lane];
+    unsigned cur = first;
+#pragma unroll
+    for (int j = 0; j + 1 < S / 2; j++) {
+        const unsigned nxt = zw[j + 1][lane];
+        zw[j][lane] = __builtin_amdgcn_alignbit(nxt, cur, 16); // (cur.hi, nxt.lo)
+        cur = nxt;
+    }
+    zw[S / 2 - 1][lane] = __builtin_amdgcn_alignbit(first, cur, 16);
+}
+
+// ---- screening: candidate bits, slot k in bit k%32 of word k/32 ------------------------
+// Every compare is shifted into the lane's candidate word through the carry (v_cmp into VCC,
+// v_addc word + word + VCC): two 4-byte instructions per pair and no branch in the whole
+// screen.  Measured against scalar-register masks OR-ed per group of four slots with a branch
+// to a slow path: equal with z in LDS, 4 % faster with z in registers
+// (profiles/r01_screened_kernel.log).  The carry chain builds the word in reverse; the last
+// group turns it round.
+template <int S, int NW>
+__device__ __forceinline__ void mx_flag4(int k0, const float (&qa)[4], const float (&qb)[4], float thr,
+                                         unsigned (&ca)[NW], unsigned (&cb)[NW])
+{
+#pragma unroll
+    for (int j = 0; j < 4; j++) { // !(thr <= q): unordered, NaN is a candidate
+        asm("v_cmp_nle_f32_e32 vcc, %2, %1\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc"
+            : "+v"(ca[(k0 + j) >> 5]) : "v"(qa[j]), "s"(thr) : "vcc");
+        asm("v_cmp_nle_f32_e32 vcc, %2, %1\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc"
+            : "+v"(cb[(k0 + j) >> 5]) : "v"(qb[j]), "s"(thr) : "vcc");
+    }
+    if (k0 + 4 == S) {
+#pragma unroll
+        for (int w = 0; w < NW; w++) {
+            const int width = (w == NW - 1) ? S - 32 * w : 32;
+            ca[w] = __builtin_bitreverse32(ca[w]) >> (32 - width);
+            cb[w] = __builtin_bitreverse32(cb[w]) >> (32 - width);
+        }
     }
 }
 
-// cand = 2*cand + !(thr <= q): compare into VCC, shift the bit in with add-with-carry
-__device__ __forceinline__ void mx_push(unsigned &cand, float q, float thr)
-{
-    asm("v_cmp_nle_f32_e32 vcc, %2, %1\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc"
-        : "+v"(cand) : "v"(q), "s"(thr) : "vcc");
-}
-
-// squared distance for the screen: u2 * (dxi^2 + dyi^2) + dz^2
-__device__ __forceinline__ float mx_q(unsigned pxy, float pz, unsigned xy, float z, float u2)
+// u2 * (dxi^2 + dyi^2) of one particle and one probe
+__device__ __forceinline__ float mx_qxy(unsigned pxy, unsigned xy, float u2)
 {
     const mx_s2 d = __builtin_bit_cast(mx_s2, pxy) - __builtin_bit_cast(mx_s2, xy); // wraps: minimum image
-    const int i2 = __builtin_amdgcn_sdot2(d, d, 0, true);
-    const float dz = pz - z;
-    return fmaf(u2, (float)i2, dz * dz);
+    return u2 * (float)__builtin_amdgcn_sdot2(d, d, 0, true);
 }
 
-// screening of the S register-resident neighbours against probes A and B: candidate
-// bits, slot 32w+j in bit 31-j (or W-1-j for the last, shorter word) of word w
+// z in registers (fp32): az, bz are the probes' z
 template <int S>
-__device__ __forceinline__ void mx_screen(const unsigned (&xy)[S], const float (&z)[S], unsigned axy,
-                                          float az, unsigned bxy, float bz, float u2, float thr,
+__device__ __forceinline__ void mx_screen(const unsigned (&xy)[S], const float (&z)[S], unsigned axy, float az,
+                                          unsigned bxy, float bz, float u2, float thr,
                                           unsigned (&ca)[(S + 31) / 32], unsigned (&cb)[(S + 31) / 32])
 {
+    static_assert(S % 4 == 0, "groups of four slots");
 #pragma unroll
-    for (int k = 0; k < S; k++) {
-        const float qa = mx_q(axy, az, xy[k], z[k], u2);
-        const float qb = mx_q(bxy, bz, xy[k], z[k], u2);
-        mx_push(ca[k >> 5], qa, thr);
-        mx_push(cb[k >> 5], qb, thr);
+    for (int k0 = 0; k0 < S; k0 += 4) {
+        float qa[4], qb[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const float da = az - z[k0 + j], db = bz - z[k0 + j];
+            qa[j] = __builtin_fmaf(da, da, mx_qxy(axy, xy[k0 + j], u2));
+            qb[j] = __builtin_fmaf(db, db, mx_qxy(bxy, xy[k0 + j], u2));
+        }
+        mx_flag4<S, (S + 31) / 32>(k0, qa, qb, thr, ca, cb);
+    }
+}
+// z in LDS (fp16): azz, bzz hold the probes' z twice
+template <int S>
+__device__ __forceinline__ void mx_screen_lds(const unsigned (&xy)[S], const unsigned (&zw)[S / 2][64], int lane,
+                                              unsigned axy, unsigned azz, unsigned bxy, unsigned bzz, float u2,
+                                              float thr, unsigned (&ca)[(S + 31) / 32],
+                                              unsigned (&cb)[(S + 31) / 32])
+{
+    static_assert(S % 4 == 0, "groups of four slots");
+#pragma unroll
+    for (int k0 = 0; k0 < S; k0 += 4) {
+        float qa[4], qb[4];
+#pragma unroll
+        for (int p = 0; p < 2; p++) {
+            const mx_h2 zz = __builtin_bit_cast(mx_h2, zw[k0 / 2 + p][lane]);
+            const mx_h2 da = __builtin_bit_cast(mx_h2, azz) - zz; // two slots at once
+            const mx_h2 db = __builtin_bit_cast(mx_h2, bzz) - zz;
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const int j = 2 * p + h;
+                const float fa = (float)(h ? da.y : da.x), fb = (float)(h ? db.y : db.x);
+                qa[j] = __builtin_fmaf(fa, fa, mx_qxy(axy, xy[k0 + j], u2)); // v_fma_mix_f32
+                qb[j] = __builtin_fmaf(fb, fb, mx_qxy(bxy, xy[k0 + j], u2));
+            }
+        }
+        mx_flag4<S, (S + 31) / 32>(k0, qa, qb, thr, ca, cb);
     }
 }
 
 // take this lane's lowest-slot candidate out of the words: its register slot, or -1
-template <int S>
-__device__ __forceinline__ int mx_pick(unsigned (&cw)[(S + 31) / 32])
+template <int NW>
+__device__ __forceinline__ int mx_pick(unsigned (&cw)[NW])
 {
-    constexpr int NW = (S + 31) / 32;
     int k = -1;
 #pragma unroll
-    for (int w = NW - 1; w >= 0; w--) {
-        const int width = (w == NW - 1) ? S - 32 * w : 32; // bits in use
-        if (cw[w] != 0u) k = 32 * w + width - 32 + __builtin_clz(cw[w]);
-    }
-    if (k >= 0) cw[k >> 5] &= ~(1u << ((((k >> 5) == NW - 1) ? S - 32 * (NW - 1) : 32) - 1 - (k & 31)));
+    for (int w = NW - 1; w >= 0; w--)
+        if (cw[w] != 0u) k = 32 * w + __builtin_ctz(cw[w]);
+    if (k >= 0) cw[k >> 5] &= ~(1u << (k & 31));
     return k;
 }
-
-template <int S>
-__device__ __forceinline__ bool mx_any(const unsigned (&cw)[(S + 31) / 32])
+template <int NW>
+__device__ __forceinline__ bool mx_any(const unsigned (&cw)[NW])
 {
     unsigned u = 0;
 #pragma unroll
-    for (int w = 0; w < (S + 31) / 32; w++) u |= cw[w];
+    for (int w = 0; w < NW; w++) u |= cw[w];
     return u != 0u;
 }
 
@@ -140,19 +213,34 @@ __device__ __forceinline__ void mx_fetch(const double *Rg, int tid, int rot, int
     else { X = q[0]; Y = q[1]; Z = q[2]; }
 }
 
-#ifdef SMCX_STAMPS // diagnostic build only (tools/profile_stamps.sh): cycles per phase of a move
+// the fp64 decision and evaluation of one candidate: pair_hit's arithmetic (signed minimum
+// image, SMC.c:567-578, 601-614), the cutoff test on its dr2
+__device__ __forceinline__ void mx_exact(const Geo &g, double px, double py, double pz, double x, double y,
+                                         double z, double &e, double &fx, double &fy, double &fz)
+{
+    const double dx = px - x, dy = py - y, dz = pz - z;
+    const double sx = dx - g.L * __builtin_rint(dx * g.invL);
+    const double sy = dy - g.L * __builtin_rint(dy * g.invL);
+    const double dr2 = sx * sx + sy * sy + dz * dz;
+    if (dr2 < g.cutoff2) lj_acc(sx, sy, dz, dr2, 1.0, 1.0, e, fx, fy, fz);
+}
+
+#ifdef SMCX_STAMPS // diagnostic build only (tools/phase_stamps.py): cycles per phase of a move
 #define STAMP(k) do { const long long t_ = __builtin_amdgcn_s_memtime(); ph[k] += t_ - tlast; tlast = t_; } while (0)
 #else
 #define STAMP(k) do { } while (0)
 #endif
 
-template <int S, int WPR, int MINW>
+template <int S, int WPR, int MINW, bool ZL>
 __global__ void __launch_bounds__(64 * WPR, MINW)
 sweep_kernel_mx(SweepArgs a, DevCtx c, int nsweeps, double A, MxArgs m)
 {
     constexpr int T = 64 * WPR;
     constexpr int NW = (S + 31) / 32;
+    constexpr int SZ = ZL ? 1 : S; // z slots kept in registers
+    static_assert(S % 4 == 0, "slot groups");
     __shared__ SweepShared<WPR> sh;
+    __shared__ unsigned zl[ZL ? WPR : 1][ZL ? S / 2 : 1][64]; // fp16 z, slot pairs x lanes
 
     const int rep = blockIdx.x;
     const int tid = threadIdx.x;
@@ -161,277 +249,10 @@ sweep_kernel_mx(SweepArgs a, DevCtx c, int nsweeps, double A, MxArgs m)
     const int N = a.N;
     double *Rg = a.R + (size_t)rep * 3 * N;
 
-    // ---- register-resident compact copies: particle l in lane l % T, slot l / T ------
+    // ---- compact copies: particle l in lane l % T, slot l / T --------------------------
     unsigned xy[S];
-    float z[S];
-#pragma unroll
-    for (int k = 0; k < S; k++) {
-        const int l = k * T + tid;
-        if (l < N) { xy[k] = mx_pack_xy(Rg[3 * l], Rg[3 * l + 1], m.toFix); z[k] = mx_store_z(Rg[3 * l + 2], m.zsafe); }
-        else { xy[k] = 0u; z[k] = __builtin_inff(); }
-    }
-    int rot = 0; // register slot j holds logical slot (j + rot) % S
-
-    if (wave == 0) fill_roles(c, sh.roles, lane);
-    __syncthreads();
-    const int role = (wave == 0) ? sh.roles.role[lane] : -1;
-
-    Geo g; g.L = a.L; g.invL = a.invL; g.cutoff2 = a.cutoff2;
-    double E = uniform_d(a.obs[rep].Ecur);
-    int par = 0;
-#ifdef SMCX_STAMPS
-    long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    long long tlast = __builtin_amdgcn_s_memtime();
-#endif
-    const double AoT = A * a.invT;
-    const double Ao4T = A * 0.25 * a.invT;
-
-#pragma unroll 1
-    for (int sw = 0; sw < nsweeps; sw++) {
-        if constexpr (WPR > 1) __syncthreads();
-        const double *displ = a.displ + ((size_t)rep * a.chunk + sw) * 3 * N;
-        const double *uni = a.uni + ((size_t)rep * a.chunk + sw) * N;
-        const int n0 = uniform(a.offs[(size_t)rep * a.chunk + sw]);
-        int jacc = 0;
-#pragma unroll 1
-        for (int run = 0; run < 2; run++) {
-            const int first = run == 0 ? n0 : 0;
-            const int len = run == 0 ? N - n0 : n0;
-            if (len == 0) continue;
-            const int vbase = run == 0 ? 0 : N - n0;
-            const int ks = first / T;
-            while (rot != ks) { rotate1m<S>(xy, z); rot = (rot + 1 == S) ? 0 : rot + 1; }
-            int tl = first - ks * T - 1;
-
-            double Px = 0.0, Py = 0.0, Pz = FAR_PROBE;
-            double Um = 0.0, Fmx = 0.0, Fmy = 0.0, Fmz = 0.0;
-            // the next particle's fp64 position comes from memory, one move ahead of its use
-            double nBx = ld_coherent(Rg + 3 * first), nBy = ld_coherent(Rg + 3 * first + 1),
-                   nBz = ld_coherent(Rg + 3 * first + 2);
-            // this move's displacement and log-uniform: wave-uniform, read-only for the whole
-            // kernel -> scalar loads through the constant address space, one move ahead
-            typedef const __attribute__((address_space(4))) double *kptr;
-            const kptr dK = (kptr)(unsigned long long)displ + 3 * (size_t)first;
-            const kptr uK = (kptr)(unsigned long long)uni + vbase;
-            double ndx = dK[0], ndy = dK[1], ndz = dK[2], nlu = uK[0];
-#pragma unroll 1
-            for (int i = -1; i < len; i++) {
-                const int n = first + i;
-                const bool hasA = (i >= 0);
-                const double ddx = ndx, ddy = ndy, ddz = ndz, lu = nlu; // of move i (unused for i = -1)
-                if (i + 1 < len) {
-                    ndx = dK[3 * (i + 1)]; ndy = dK[3 * (i + 1) + 1]; ndz = dK[3 * (i + 1) + 2];
-                    nlu = uK[i + 1];
-                }
-                double Qx = 0.0, Qy = 0.0, Qz = FAR_PROBE; // proposal, SMC.c:307-316
-                if (hasA) {
-                    Qx = Px + (Fmx * AoT + ddx);
-                    Qy = Py + (Fmy * AoT + ddy);
-                    Qz = Pz + (Fmz * AoT + ddz);
-                    Qx = Qx - a.L * __builtin_rint(Qx * a.invL);
-                    Qy = Qy - a.L * __builtin_rint(Qy * a.invL);
-                    Qx = uniform_d(Qx); Qy = uniform_d(Qy); Qz = uniform_d(Qz);
-                }
-                const bool hasB = (i + 1 < len);
-                const bool cross = hasB && (tl == T - 1);
-                double Bx = 0.0, By = 0.0, Bz = FAR_PROBE;
-                if (hasB) { Bx = uniform_d(nBx); By = uniform_d(nBy); Bz = uniform_d(nBz); }
-                if (i + 2 < len) {
-                    nBx = ld_coherent(Rg + 3 * (n + 2)); nBy = ld_coherent(Rg + 3 * (n + 2) + 1);
-                    nBz = ld_coherent(Rg + 3 * (n + 2) + 2);
-                }
-
-                STAMP(0); // proposal, probe fetch
-                // ---- screening ------------------------------------------------------
-                const float ninf = -__builtin_inff();
-                const unsigned axy = (unsigned)uniform((int)mx_pack_xy(Qx, Qy, m.toFix));
-                const unsigned bxy = (unsigned)uniform((int)mx_pack_xy(Bx, By, m.toFix));
-                const float azf = hasA ? mx_store_z(Qz, m.zsafe) : ninf;
-                const float bzf = hasB ? mx_store_z(Bz, m.zsafe) : ninf;
-                unsigned ca[NW], cb[NW];
-#pragma unroll
-                for (int w = 0; w < NW; w++) { ca[w] = 0u; cb[w] = 0u; }
-                mx_screen<S>(xy, z, axy, azf, bxy, bzf, m.u2, m.thr, ca, cb);
-                // the moving particle itself and the particle probe B stands for are not neighbours
-                {
-                    constexpr unsigned top = 1u << ((NW == 1 ? S : 32) - 1); // slot 0
-                    const bool exA0 = (tid == tl);
-                    const bool exB0 = (hasA && tid == tl) || (hasB && !cross && tid == tl + 1);
-                    const bool exB1 = cross && (tid == 0);
-                    if (exA0) ca[0] &= ~top;
-                    if (exB0) cb[0] &= ~top;
-                    if constexpr (S > 1) { if (exB1) cb[0] &= ~(top >> 1); }
-                }
-                STAMP(1); // screening
-                // ---- exact evaluation of the candidates, reduction, Metropolis step ------------
-                // every lane fetches its candidates' fp64 positions and decides and evaluates
-                // them exactly as the fp64 kernel does, in ascending slot order per probe
-                Acc8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-                double side[4], tot[8], sOld[4], sNew[4];
-                bool acc = false;
-                auto metropolis = [&]() { // SMC acceptance, SMC.c:326-348; needs tot[0..3]
-                    const double Un = 4.0 * tot[0], Fnx = tot[1], Fny = tot[2], Fnz = tot[3];
-                    const double dX = Fmx * AoT + ddx;
-                    const double dY = Fmy * AoT + ddy;
-                    const double dZ = Fmz * AoT + ddz;
-                    const double gx = Fnx - Fmx, gy = Fny - Fmy, gz = Fnz - Fmz;
-                    const double deltaW = (gx * gx + gy * gy + gz * gz +
-                                           2.0 * (gx * Fmx + gy * Fmy + gz * Fmz)) * Ao4T;
-                    const double arg = Un - Um +
-                                       (dX * (Fnx + Fmx) + dY * (Fny + Fmy) + dZ * (Fnz + Fmz)) * 0.5 + deltaW;
-                    acc = (lu < -arg * a.invT);
-                    acc = (uniform((int)acc) != 0);
-                    const bool upd = acc && (tid == tl);
-                    if (upd) {
-                        xy[0] = axy; z[0] = azf;
-                        Rg[3 * n] = Qx; Rg[3 * n + 1] = Qy; Rg[3 * n + 2] = Qz; // the fp64 state
-                    }
-                    if (acc) { E = uniform_d(E + (Un - Um)); jacc++; }
-                };
-                if (__builtin_amdgcn_ballot_w64(mx_any<S>(ca) || mx_any<S>(cb))) {
-                    int kA = mx_pick<S>(ca), kB = mx_pick<S>(cb);
-                    do {
-                        double XA = 0, YA = 0, ZA = 0, XB = 0, YB = 0, ZB = 0;
-                        if (kA >= 0) mx_fetch<S, T, (WPR > 1)>(Rg, tid, rot, kA, XA, YA, ZA);
-                        if (kB >= 0) mx_fetch<S, T, (WPR > 1)>(Rg, tid, rot, kB, XB, YB, ZB);
-                        if (kA >= 0 && pair_q<true>(g, Qx, Qy, Qz, XA, YA, ZA) < g.cutoff2)
-                            pair_hit(g, Qx, Qy, Qz, XA, YA, ZA, v.a0, v.a1, v.a2, v.a3);
-                        if (kB >= 0 && pair_q<true>(g, Bx, By, Bz, XB, YB, ZB) < g.cutoff2)
-                            pair_hit(g, Bx, By, Bz, XB, YB, ZB, v.b0, v.b1, v.b2, v.b3);
-                        kA = mx_pick<S>(ca); kB = mx_pick<S>(cb);
-                    } while (__builtin_amdgcn_ballot_w64(kA >= 0 || kB >= 0));
-                }
-                STAMP(2); // candidates
-                if (wave == 0)
-                    special_block(g, sh.roles, lane, role, hasA, hasB, hasA, Px, Py, Pz, Qx, Qy, Qz,
-                                  Bx, By, Bz, v, side);
-                else side[0] = side[1] = side[2] = side[3] = 0.0;
-                STAMP(3); // walls, plane, side pair
-                combine<WPR>(sh, par, lane, wave, v, side, tot, sOld, sNew);
-                if (hasA) metropolis();
-                STAMP(4); // reduction, Metropolis step
-
-                if (hasB) {
-                    double s0, s1, s2, s3;
-                    if constexpr (WPR == 1) {
-                        const int src = acc ? SIDE_LANE_NEW : SIDE_LANE_OLD;
-                        s0 = rdlane(sOld[0], src); s1 = rdlane(sOld[1], src);
-                        s2 = rdlane(sOld[2], src); s3 = rdlane(sOld[3], src);
-                    } else {
-                        s0 = acc ? sNew[0] : sOld[0]; s1 = acc ? sNew[1] : sOld[1];
-                        s2 = acc ? sNew[2] : sOld[2]; s3 = acc ? sNew[3] : sOld[3];
-                    }
-                    Um = uniform_d(4.0 * (tot[4] + s0));
-                    Fmx = uniform_d(tot[5] + s1);
-                    Fmy = uniform_d(tot[6] + s2);
-                    Fmz = uniform_d(tot[7] + s3);
-                    Px = Bx; Py = By; Pz = Bz;
-                    if (cross) {
-                        rotate1m<S>(xy, z);
-                        rot = (rot + 1 == S) ? 0 : rot + 1;
-                        tl = 0;
-                    } else {
-                        tl++;
-                    }
-                }
-                STAMP(5); // (probe B: candidates, reduction,) next particle's Um/Fm, slot rotation
-            }
-        }
-        if (tid == 0) {
-            SweepRec r; r.E = E; r.accepted = jacc; r.pad = 0;
-            a.rec[(size_t)rep * a.chunk + sw] = r;
-        }
-    }
-#ifdef SMCX_STAMPS
-    if (tid == 0) { // diagnostic: overwrite the head of this replica's (consumed) displacement block
-        double *dbg = const_cast<double *>(a.displ) + (size_t)rep * a.chunk * 3 * N;
-        for (int k = 0; k < 6; k++) dbg[k] = (double)ph[k];
-    }
-#endif
-}
-
-
-// ---------------------------------------------------------------------------------
-// Variant with z outside the register file: fp16 in LDS, 2 bytes per particle.  The registers
-// then hold one VGPR per particle (x,y), which lets a third wavefront per SIMD cover the
-// latency-bound sequential part of the other two.  dz of two slots is one v_pk_add_f16, and
-// dz^2 enters the fp32 sum through v_fma_mix_f32.  fp16 keeps |z| < zsafe (a power of two)
-// to within zsafe * 2^-12; the wider margin this needs is part of thr (launch_sweeps_mx).
-// ---------------------------------------------------------------------------------
-typedef _Float16 mz_h2 __attribute__((ext_vector_type(2)));
-
-__device__ __forceinline__ unsigned mz_store_zh(double z, float zsafe)
-{
-    const _Float16 h = (_Float16)(float)z;
-    const unsigned short bits = __builtin_bit_cast(unsigned short, h);
-    return (fabs(z) < (double)zsafe) ? (unsigned)bits : 0x7E00u; // NaN: always a candidate
-}
-
-// rotate the slots by one: x,y in registers, z in this wavefront's LDS block
-template <int S>
-__device__ __forceinline__ void mz_rotate(unsigned (&xy)[S], unsigned (&zw)[S / 2][64], int lane)
-{
-    const unsigned t = xy[0];
-#pragma unroll
-    for (int k = 0; k + 1 < S; k++) xy[k] = xy[k + 1];
-    xy[S - 1] = t;
-    const unsigned first = zw[0][lane];
-    unsigned cur = first;
-#pragma unroll
-    for (int j = 0; j + 1 < S / 2; j++) {
-        const unsigned nxt = zw[j + 1][lane];
-        zw[j][lane] = __builtin_amdgcn_alignbit(nxt, cur, 16); // (cur.hi, nxt.lo)
-        cur = nxt;
-    }
-    zw[S / 2 - 1][lane] = __builtin_amdgcn_alignbit(first, cur, 16);
-}
-
-template <int S>
-__device__ __forceinline__ void mz_screen(const unsigned (&xy)[S], const unsigned (&zw)[S / 2][64], int lane,
-                                          unsigned axy, unsigned azz, unsigned bxy, unsigned bzz, float u2,
-                                          float thr, unsigned (&ca)[(S + 31) / 32], unsigned (&cb)[(S + 31) / 32])
-{
-#pragma unroll
-    for (int j = 0; j < S / 2; j++) {
-        const mz_h2 zz = __builtin_bit_cast(mz_h2, zw[j][lane]);
-        const mz_h2 da = __builtin_bit_cast(mz_h2, azz) - zz;
-        const mz_h2 db = __builtin_bit_cast(mz_h2, bzz) - zz;
-#pragma unroll
-        for (int h = 0; h < 2; h++) {
-            const int k = 2 * j + h;
-            const mx_s2 ea = __builtin_bit_cast(mx_s2, axy) - __builtin_bit_cast(mx_s2, xy[k]);
-            const mx_s2 eb = __builtin_bit_cast(mx_s2, bxy) - __builtin_bit_cast(mx_s2, xy[k]);
-            const float fa = u2 * (float)__builtin_amdgcn_sdot2(ea, ea, 0, true);
-            const float fb = u2 * (float)__builtin_amdgcn_sdot2(eb, eb, 0, true);
-            const float za = (float)(h ? da.y : da.x), zb = (float)(h ? db.y : db.x);
-            mx_push(ca[k >> 5], __builtin_fmaf(za, za, fa), thr);
-            mx_push(cb[k >> 5], __builtin_fmaf(zb, zb, fb), thr);
-        }
-    }
-}
-
-template <int S, int WPR, int MINW>
-__global__ void __launch_bounds__(64 * WPR, MINW)
-sweep_kernel_mz(SweepArgs a, DevCtx c, int nsweeps, double A, MxArgs m)
-{
-    constexpr int T = 64 * WPR;
-    constexpr int NW = (S + 31) / 32;
-    __shared__ SweepShared<WPR> sh;
-
-    const int rep = blockIdx.x;
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = uniform(tid >> 6);
-    const int N = a.N;
-    double *Rg = a.R + (size_t)rep * 3 * N;
-
-    // ---- register-resident compact copies: particle l in lane l % T, slot l / T ------
-    // x,y in registers (one VGPR per particle); z as fp16 in LDS, slots 2j and 2j+1 of a lane in
-    // one dword, slot-pair-major so that a wavefront's read of one pair is conflict-free
-    static_assert(S % 2 == 0, "slot pairs");
-    __shared__ unsigned zl[WPR][S / 2][64];
-    unsigned xy[S];
-    unsigned (&zw)[S / 2][64] = zl[wave];
+    float z[SZ];
+    unsigned (&zw)[ZL ? S / 2 : 1][64] = zl[ZL ? wave : 0];
 #pragma unroll
     for (int j = 0; j < S / 2; j++) {
         unsigned pair = 0u;
@@ -439,14 +260,19 @@ sweep_kernel_mz(SweepArgs a, DevCtx c, int nsweeps, double A, MxArgs m)
         for (int h = 0; h < 2; h++) {
             const int k = 2 * j + h;
             const int l = k * T + tid;
-            unsigned zh = 0x7C00u; // +inf: a padding slot
-            if (l < N) { xy[k] = mx_pack_xy(Rg[3 * l], Rg[3 * l + 1], m.toFix); zh = mz_store_zh(Rg[3 * l + 2], m.zsafe); }
-            else xy[k] = 0u;
-            pair |= zh << (16 * h);
+            const bool real = (l < N);
+            xy[k] = real ? mx_pack_xy(Rg[3 * l], Rg[3 * l + 1], m.toFix) : 0u;
+            if constexpr (ZL) pair |= (real ? mx_z16(Rg[3 * l + 2], m.zsafe) : 0x7C00u) << (16 * h); // pad: +inf
+            else z[k] = real ? mx_z32(Rg[3 * l + 2], m.zsafe) : __builtin_inff();
         }
-        zw[j][lane] = pair;
+        if constexpr (ZL) zw[j][lane] = pair;
     }
     int rot = 0; // register slot j holds logical slot (j + rot) % S
+    auto rotate = [&]() {
+        mx_rotate<S, SZ>(xy, z);
+        if constexpr (ZL) mx_rotate_lds<S>(zw, lane);
+        rot = (rot + 1 == S) ? 0 : rot + 1;
+    };
 
     if (wave == 0) fill_roles(c, sh.roles, lane);
     __syncthreads();
@@ -459,8 +285,8 @@ sweep_kernel_mz(SweepArgs a, DevCtx c, int nsweeps, double A, MxArgs m)
     long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     long long tlast = __builtin_amdgcn_s_memtime();
 #endif
-    const double AoT = A * a.invT;
-    const double Ao4T = A * 0.25 * a.invT;
+    const double AoT = A * a.invT;         // SMC.c:307-309 (A/T)
+    const double Ao4T = A * 0.25 * a.invT; // SMC.c:327 (A/(4T))
 
 #pragma unroll 1
     for (int sw = 0; sw < nsweeps; sw++) {
@@ -469,6 +295,7 @@ sweep_kernel_mz(SweepArgs a, DevCtx c, int nsweeps, double A, MxArgs m)
         const double *uni = a.uni + ((size_t)rep * a.chunk + sw) * N;
         const int n0 = uniform(a.offs[(size_t)rep * a.chunk + sw]);
         int jacc = 0;
+        // the visiting order n0..N-1, 0..n0-1 (SMC.c:292-294) is two ascending runs
 #pragma unroll 1
         for (int run = 0; run < 2; run++) {
             const int first = run == 0 ? n0 : 0;
@@ -476,8 +303,8 @@ sweep_kernel_mz(SweepArgs a, DevCtx c, int nsweeps, double A, MxArgs m)
             if (len == 0) continue;
             const int vbase = run == 0 ? 0 : N - n0;
             const int ks = first / T;
-            while (rot != ks) { mz_rotate<S>(xy, zw, lane); rot = (rot + 1 == S) ? 0 : rot + 1; }
-            int tl = first - ks * T - 1;
+            while (rot != ks) rotate();
+            int tl = first - ks * T - 1; // owner thread of particle n (slot 0); -1 in the prologue
 
             double Px = 0.0, Py = 0.0, Pz = FAR_PROBE;
             double Um = 0.0, Fmx = 0.0, Fmy = 0.0, Fmz = 0.0;
@@ -491,7 +318,7 @@ sweep_kernel_mz(SweepArgs a, DevCtx c, int nsweeps, double A, MxArgs m)
             const kptr uK = (kptr)(unsigned long long)uni + vbase;
             double ndx = dK[0], ndy = dK[1], ndz = dK[2], nlu = uK[0];
 #pragma unroll 1
-            for (int i = -1; i < len; i++) {
+            for (int i = -1; i < len; i++) { // i = -1: the run's prologue, probe B alone
                 const int n = first + i;
                 const bool hasA = (i >= 0);
                 const double ddx = ndx, ddy = ndy, ddz = ndz, lu = nlu; // of move i (unused for i = -1)
@@ -516,67 +343,52 @@ sweep_kernel_mz(SweepArgs a, DevCtx c, int nsweeps, double A, MxArgs m)
                     nBx = ld_coherent(Rg + 3 * (n + 2)); nBy = ld_coherent(Rg + 3 * (n + 2) + 1);
                     nBz = ld_coherent(Rg + 3 * (n + 2) + 2);
                 }
-
                 STAMP(0); // proposal, probe fetch
+
                 // ---- screening ------------------------------------------------------
                 const unsigned axy = (unsigned)uniform((int)mx_pack_xy(Qx, Qy, m.toFix));
                 const unsigned bxy = (unsigned)uniform((int)mx_pack_xy(Bx, By, m.toFix));
-                const unsigned azh = hasA ? mz_store_zh(Qz, m.zsafe) : 0xFC00u; // -inf: a disabled probe
-                const unsigned bzh = hasB ? mz_store_zh(Bz, m.zsafe) : 0xFC00u;
-                const unsigned azz = (unsigned)uniform((int)(azh | (azh << 16)));
-                const unsigned bzz = (unsigned)uniform((int)(bzh | (bzh << 16)));
                 unsigned ca[NW], cb[NW];
 #pragma unroll
                 for (int w = 0; w < NW; w++) { ca[w] = 0u; cb[w] = 0u; }
-                mz_screen<S>(xy, zw, lane, axy, azz, bxy, bzz, m.u2, m.thr, ca, cb);
+                float azf = 0.f;   // the proposal's z as stored on acceptance
+                unsigned azh = 0u;
+                if constexpr (ZL) {
+                    azh = hasA ? mx_z16(Qz, m.zsafe) : 0xFC00u; // -inf: a disabled probe
+                    const unsigned bzh = hasB ? mx_z16(Bz, m.zsafe) : 0xFC00u;
+                    const unsigned azz = (unsigned)uniform((int)(azh | (azh << 16)));
+                    const unsigned bzz = (unsigned)uniform((int)(bzh | (bzh << 16)));
+                    mx_screen_lds<S>(xy, zw, lane, axy, azz, bxy, bzz, m.u2, m.thr, ca, cb);
+                } else {
+                    azf = hasA ? mx_z32(Qz, m.zsafe) : -__builtin_inff();
+                    const float bzf = hasB ? mx_z32(Bz, m.zsafe) : -__builtin_inff();
+                    mx_screen<S>(xy, z, axy, azf, bxy, bzf, m.u2, m.thr, ca, cb);
+                }
                 // the moving particle itself and the particle probe B stands for are not neighbours
                 {
-                    constexpr unsigned top = 1u << ((NW == 1 ? S : 32) - 1); // slot 0
                     const bool exA0 = (tid == tl);
                     const bool exB0 = (hasA && tid == tl) || (hasB && !cross && tid == tl + 1);
                     const bool exB1 = cross && (tid == 0);
-                    if (exA0) ca[0] &= ~top;
-                    if (exB0) cb[0] &= ~top;
-                    if constexpr (S > 1) { if (exB1) cb[0] &= ~(top >> 1); }
+                    if (exA0) ca[0] &= ~1u;
+                    if (exB0) cb[0] &= ~1u;
+                    if (exB1) cb[0] &= ~2u;
                 }
                 STAMP(1); // screening
-                // ---- exact evaluation of the candidates, reduction, Metropolis step ------------
-                // every lane fetches its candidates' fp64 positions and decides and evaluates
-                // them exactly as the fp64 kernel does, in ascending slot order per probe
+
+                // ---- exact evaluation of the candidates ------------------------------------
+                // every lane fetches its candidates' fp64 positions (one of each probe per round)
+                // and decides and evaluates them in fp64, in ascending slot order per probe
                 Acc8 v = {0, 0, 0, 0, 0, 0, 0, 0};
                 double side[4], tot[8], sOld[4], sNew[4];
-                bool acc = false;
-                auto metropolis = [&]() { // SMC acceptance, SMC.c:326-348; needs tot[0..3]
-                    const double Un = 4.0 * tot[0], Fnx = tot[1], Fny = tot[2], Fnz = tot[3];
-                    const double dX = Fmx * AoT + ddx;
-                    const double dY = Fmy * AoT + ddy;
-                    const double dZ = Fmz * AoT + ddz;
-                    const double gx = Fnx - Fmx, gy = Fny - Fmy, gz = Fnz - Fmz;
-                    const double deltaW = (gx * gx + gy * gy + gz * gz +
-                                           2.0 * (gx * Fmx + gy * Fmy + gz * Fmz)) * Ao4T;
-                    const double arg = Un - Um +
-                                       (dX * (Fnx + Fmx) + dY * (Fny + Fmy) + dZ * (Fnz + Fmz)) * 0.5 + deltaW;
-                    acc = (lu < -arg * a.invT);
-                    acc = (uniform((int)acc) != 0);
-                    const bool upd = acc && (tid == tl);
-                    if (upd) {
-                        xy[0] = axy;
-                        reinterpret_cast<unsigned short *>(&zw[0][lane])[0] = (unsigned short)azh; // slot 0 = low half
-                        Rg[3 * n] = Qx; Rg[3 * n + 1] = Qy; Rg[3 * n + 2] = Qz; // the fp64 state
-                    }
-                    if (acc) { E = uniform_d(E + (Un - Um)); jacc++; }
-                };
-                if (__builtin_amdgcn_ballot_w64(mx_any<S>(ca) || mx_any<S>(cb))) {
-                    int kA = mx_pick<S>(ca), kB = mx_pick<S>(cb);
+                if (__builtin_amdgcn_ballot_w64(mx_any<NW>(ca) || mx_any<NW>(cb))) {
+                    int kA = mx_pick<NW>(ca), kB = mx_pick<NW>(cb);
                     do {
                         double XA = 0, YA = 0, ZA = 0, XB = 0, YB = 0, ZB = 0;
                         if (kA >= 0) mx_fetch<S, T, (WPR > 1)>(Rg, tid, rot, kA, XA, YA, ZA);
                         if (kB >= 0) mx_fetch<S, T, (WPR > 1)>(Rg, tid, rot, kB, XB, YB, ZB);
-                        if (kA >= 0 && pair_q<true>(g, Qx, Qy, Qz, XA, YA, ZA) < g.cutoff2)
-                            pair_hit(g, Qx, Qy, Qz, XA, YA, ZA, v.a0, v.a1, v.a2, v.a3);
-                        if (kB >= 0 && pair_q<true>(g, Bx, By, Bz, XB, YB, ZB) < g.cutoff2)
-                            pair_hit(g, Bx, By, Bz, XB, YB, ZB, v.b0, v.b1, v.b2, v.b3);
-                        kA = mx_pick<S>(ca); kB = mx_pick<S>(cb);
+                        if (kA >= 0) mx_exact(g, Qx, Qy, Qz, XA, YA, ZA, v.a0, v.a1, v.a2, v.a3);
+                        if (kB >= 0) mx_exact(g, Bx, By, Bz, XB, YB, ZB, v.b0, v.b1, v.b2, v.b3);
+                        kA = mx_pick<NW>(ca); kB = mx_pick<NW>(cb);
                     } while (__builtin_amdgcn_ballot_w64(kA >= 0 || kB >= 0));
                 }
                 STAMP(2); // candidates
@@ -586,10 +398,31 @@ sweep_kernel_mz(SweepArgs a, DevCtx c, int nsweeps, double A, MxArgs m)
                 else side[0] = side[1] = side[2] = side[3] = 0.0;
                 STAMP(3); // walls, plane, side pair
                 combine<WPR>(sh, par, lane, wave, v, side, tot, sOld, sNew);
-                if (hasA) metropolis();
+
+                bool acc = false;
+                if (hasA) { // SMC acceptance, SMC.c:326-348
+                    const double Un = 4.0 * tot[0], Fnx = tot[1], Fny = tot[2], Fnz = tot[3];
+                    const double dX = Fmx * AoT + ddx;
+                    const double dY = Fmy * AoT + ddy;
+                    const double dZ = Fmz * AoT + ddz;
+                    const double gx = Fnx - Fmx, gy = Fny - Fmy, gz = Fnz - Fmz;
+                    const double deltaW = (gx * gx + gy * gy + gz * gz +
+                                           2.0 * (gx * Fmx + gy * Fmy + gz * Fmz)) * Ao4T;
+                    const double arg = Un - Um +
+                                       (dX * (Fnx + Fmx) + dY * (Fny + Fmy) + dZ * (Fnz + Fmz)) * 0.5 + deltaW;
+                    acc = (lu < -arg * a.invT); // u < exp(-arg/T); NaN rejects (SMC.c:335)
+                    acc = (uniform((int)acc) != 0);
+                    if (acc && tid == tl) {
+                        xy[0] = axy;
+                        if constexpr (ZL) reinterpret_cast<unsigned short *>(&zw[0][lane])[0] = (unsigned short)azh;
+                        else z[0] = azf;
+                        Rg[3 * n] = Qx; Rg[3 * n + 1] = Qy; Rg[3 * n + 2] = Qz; // the fp64 state
+                    }
+                    if (acc) { E = uniform_d(E + (Un - Um)); jacc++; }
+                }
                 STAMP(4); // reduction, Metropolis step
 
-                if (hasB) {
+                if (hasB) { // next particle's Um,Fm = B sums + the (n, n+1) pair term
                     double s0, s1, s2, s3;
                     if constexpr (WPR == 1) {
                         const int src = acc ? SIDE_LANE_NEW : SIDE_LANE_OLD;
@@ -604,17 +437,13 @@ sweep_kernel_mz(SweepArgs a, DevCtx c, int nsweeps, double A, MxArgs m)
                     Fmy = uniform_d(tot[6] + s2);
                     Fmz = uniform_d(tot[7] + s3);
                     Px = Bx; Py = By; Pz = Bz;
-                    if (cross) {
-                        mz_rotate<S>(xy, zw, lane);
-                        rot = (rot + 1 == S) ? 0 : rot + 1;
-                        tl = 0;
-                    } else {
-                        tl++;
-                    }
+                    if (cross) { rotate(); tl = 0; }
+                    else tl++;
                 }
-                STAMP(5); // (probe B: candidates, reduction,) next particle's Um/Fm, slot rotation
+                STAMP(5); // next particle's Um/Fm, slot rotation
             }
         }
+        // C: hand E[n+1] and jj[n] (SMC.c:194-195) to the bookkeeping kernel
         if (tid == 0) {
             SweepRec r; r.E = E; r.accepted = jacc; r.pad = 0;
             a.rec[(size_t)rep * a.chunk + sw] = r;
@@ -628,13 +457,12 @@ sweep_kernel_mz(SweepArgs a, DevCtx c, int nsweeps, double A, MxArgs m)
 #endif
 }
 
-
 typedef void (*sweep_mx_fn)(SweepArgs, DevCtx, int, double, MxArgs);
 
-// 3 VGPRs per particle: twice the slots of the fp64 kernels at the same occupancy
+// fp32 z in registers: two VGPRs per particle
 static sweep_mx_fn lookup_mx(int S, int WPR)
 {
-#define SMCX_MX(s, w, m) if (S == s && WPR == w) return sweep_kernel_mx<s, w, m>;
+#define SMCX_MX(s, w, m) if (S == s && WPR == w) return sweep_kernel_mx<s, w, m, false>;
     SMCX_MX(16, 1, 3) SMCX_MX(32, 1, 3) SMCX_MX(64, 1, 2)
     SMCX_MX(16, 2, 3) SMCX_MX(32, 2, 3) SMCX_MX(64, 2, 2)
     SMCX_MX(16, 4, 4) SMCX_MX(32, 4, 3) SMCX_MX(64, 4, 2)
@@ -643,11 +471,11 @@ static sweep_mx_fn lookup_mx(int S, int WPR)
     return nullptr;
 }
 
-// z in LDS: one VGPR per particle
+// fp16 z in LDS: one VGPR per particle
 static sweep_mx_fn lookup_mz(int S, int WPR)
 {
-#define SMCX_MZ(s, w, m) if (S == s && WPR == w) return sweep_kernel_mz<s, w, m>;
-    SMCX_MZ(64, 1, 4) SMCX_MZ(32, 2, 4) SMCX_MZ(64, 4, 3) SMCX_MZ(32, 1, 4) SMCX_MZ(64, 2, 3)
+#define SMCX_MZ(s, w, m) if (S == s && WPR == w) return sweep_kernel_mx<s, w, m, true>;
+    SMCX_MZ(64, 1, 4) SMCX_MZ(32, 2, 4) SMCX_MZ(64, 4, 4) SMCX_MZ(32, 1, 4) SMCX_MZ(64, 2, 4)
 #undef SMCX_MZ
     return nullptr;
 }
@@ -666,7 +494,7 @@ hipError_t launch_sweeps_mx(const SweepArgs &a, const DevCtx &c, int S, int WPR,
                             hipStream_t st)
 {
     sweep_mx_fn fm = lookup_mx(S, WPR);
-    // z as fp16 in LDS (sweep_kernel_mz) where it measured faster: one wavefront per replica with 64
+    // z as fp16 in LDS (ZL = true) where it measured faster: one wavefront per replica with 64
     // particles per lane, which then fits four waves per SIMD -- unless the box is so tall that fp16
     // would widen the screen noticeably.  SMCX_MZ=0/1 forces the choice for A/B measurements.
     const bool mz = mx_lds_z(S, WPR, c.Lz);

@@ -9,6 +9,7 @@ import smcx_loader
 S = smcx_loader.load()
 N, Na, Nz, nrep, sweeps, s, w = (int(v) for v in sys.argv[1:8])
 p = S.default_params(N, nrep, tune_slots=s, tune_waves=w, tune_kernel=2)
+print("kernel:", S.Engine(p).kernel_form)
 eng = S.Engine(p)
 eng.upload(S.fcc_init(Na, Nz), S.W_REFERENCE)
 eng.run(0, sweeps, 1000)

@@ -7,7 +7,7 @@
 #define ITER 400
 #define X16(m) m(0) m(1) m(2) m(3) m(4) m(5) m(6) m(7) m(8) m(9) m(10) m(11) m(12) m(13) m(14) m(15)
 
-template <int OP> __global__ void __launch_bounds__(512) k(float *out, float cf, long long *cyc)
+template <int OP> __global__ void __launch_bounds__(1024) k(float *out, float cf, long long *cyc)
 {
     float f[16], g[16]; unsigned u[16];
     typedef float f2 __attribute__((ext_vector_type(2)));
@@ -35,6 +35,9 @@ template <int OP> __global__ void __launch_bounds__(512) k(float *out, float cf,
         if (OP == 0) { X16(SUB) } if (OP == 1) { X16(MUL) } if (OP == 2) { X16(FMAC) } if (OP == 3) { X16(FMA3) }
         if (OP == 4) { X16(CMPADDC) } if (OP == 5) { X16(CMP) } if (OP == 6) { X16(ADDC) } if (OP == 7) { X16(RND) }
         if (OP == 8) { X16(PKFMA) } if (OP == 9) { X16(PKADD) } if (OP == 10) { X16(PKMUL) } if (OP == 11) { X16(DOT2) }
+#define SCREEN(j) asm volatile("v_pk_sub_i16 %0, %3, %1\n\tv_dot2_i32_i16 %0, %0, %0, 0 clamp\n\tv_cvt_f32_i32_e32 %0, %0\n\tv_mul_f32_e32 %0, %3, %0\n\tv_fma_mix_f32 %0, %2, %2, %0 op_sel_hi:[1,1,0]\n\tv_cmp_nle_f32_e64 s[20:21], %3, %0\n\ts_or_b64 s[22:23], s[22:23], s[20:21]" : "=&v"(f[j]) : "v"(u[j]), "v"(g[j]), "s"(cf) : "s20", "s21", "s22", "s23");
+#define SCREENP(j) asm volatile("v_pk_sub_i16 %0, %3, %1\n\tv_dot2_i32_i16 %0, %0, %0, 0 clamp\n\tv_cvt_f32_i32_e32 %0, %0\n\tv_mul_f32_e32 %0, %3, %0\n\tv_fma_mix_f32 %0, %2, %2, %0 op_sel_hi:[1,1,0]\n\tv_cmp_nle_f32_e32 vcc, %3, %0\n\tv_addc_co_u32_e32 %1, vcc, %1, %1, vcc" : "=&v"(f[j]), "+v"(u[j]) : "v"(g[j]), "s"(cf) : "vcc");
+        if (OP == 16) { X16(SCREEN) } if (OP == 17) { X16(SCREENP) }
         if (OP == 12) { X16(PKADDH) } if (OP == 13) { X16(MINABS) } if (OP == 14) { X16(PAIR) } if (OP == 15) { X16(DOT2C) }
     }
     const long long t1 = __builtin_amdgcn_s_memrealtime();
@@ -43,19 +46,20 @@ template <int OP> __global__ void __launch_bounds__(512) k(float *out, float cf,
     if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
 }
 
-template <int OP> void run(const char *name, int per)
+template <int OP> void run(const char *name, int per, int threads = 512)
 {
     const int blocks = 256;
+    const int wps = threads / 256; // waves per SIMD
     float *out; long long *cyc;
-    hipMalloc(&out, sizeof(float) * blocks * 512); hipMalloc(&cyc, sizeof(long long) * blocks);
-    hipLaunchKernelGGL(k<OP>, dim3(blocks), dim3(512), 0, 0, out, 1.0000001f, cyc);
-    hipLaunchKernelGGL(k<OP>, dim3(blocks), dim3(512), 0, 0, out, 1.0000001f, cyc);
+    hipMalloc(&out, sizeof(float) * blocks * 1024); hipMalloc(&cyc, sizeof(long long) * blocks);
+    hipLaunchKernelGGL(k<OP>, dim3(blocks), dim3(threads), 0, 0, out, 1.0000001f, cyc);
+    hipLaunchKernelGGL(k<OP>, dim3(blocks), dim3(threads), 0, 0, out, 1.0000001f, cyc);
     hipDeviceSynchronize();
     std::vector<long long> h(blocks); hipMemcpy(h.data(), cyc, sizeof(long long) * blocks, hipMemcpyDeviceToHost);
     double avr = 0; for (int i = 0; i < blocks; i++) avr += h[i]; avr /= blocks;
     // 2 waves per SIMD share it: SIMD time per wave-instruction = elapsed / (2 * ITER * 16 * per)
-    const double ns = avr * 10.0 / (2.0 * ITER * 16 * per);
-    printf("%-34s %6.3f ns per wave-instr per SIMD  (%.2f cycles at 2.4 GHz, %.2f at 2.1)\n", name, ns, ns * 2.4, ns * 2.1);
+    const double ns = avr * 10.0 / ((double)wps * ITER * 16 * per);
+    printf("%-44s %6.3f ns per wave-instr per SIMD  (%.2f cycles at 2.4 GHz, %.2f at 2.1)\n", name, ns, ns * 2.4, ns * 2.1);
     hipFree(out); hipFree(cyc);
 }
 
@@ -66,5 +70,11 @@ int main()
     run<6>("v_addc_co_u32_e32", 1); run<7>("v_rndne_f32_e32", 1); run<8>("v_pk_fma_f32", 1); run<9>("v_pk_add_f32", 1);
     run<10>("v_pk_mul_f32", 1); run<11>("v_dot2_f32_f16", 1); run<15>("v_dot2c_f32_f16_e32", 1); run<12>("v_pk_add_f16", 1);
     run<13>("v_min_f32_e64 |v|", 1); run<14>("interior pair-eval (6 instr)", 6);
+    for (int t : {256, 512, 1024}) {
+        printf("-- %d wave(s) per SIMD\n", t / 256);
+        run<16>("screen: 6 VALU (cmp_e64 -> sgpr) + s_or", 6, t);
+        run<17>("screen: 7 VALU (cmp_e32 + addc)", 7, t);
+        run<0>("v_sub_f32_e32", 1, t); run<11>("v_dot2_f32_f16", 1, t); run<3>("v_fma_f32", 1, t);
+    }
     return 0;
 }
