@@ -330,12 +330,8 @@ extern "C" int smcx_kernel_form(const smcx_handle *hh, int *form, char *name, in
     const Handle &h = hh->h;
     const bool mx = sweep_uses_mx(h.S, h.WPR, h.p.tune_kernel);
     if (form) *form = mx ? 2 : 1;
-    if (name && len > 0) {
-        const bool lead = !mx && h.S <= 16 && h.WPR >= 4;
-        const char *kn = mx ? (mx_lds_z(h.S, h.WPR, h.p.Lz) ? "sweep_kernel_mz" : "sweep_kernel_mx")
-                            : (lead ? "sweep_kernel_lead" : "sweep_kernel");
-        std::snprintf(name, (size_t)len, "smcx::%s<%d, %d>", kn, h.S, h.WPR);
-    }
+    if (name && len > 0)
+        std::snprintf(name, (size_t)len, "%s", mx ? mx_kernel_name(h.S, h.WPR, h.p.Lz) : fp64_kernel_name(h.S, h.WPR));
     return SMCX_OK;
 }
 

@@ -714,19 +714,42 @@ typedef void (*sweep_fn)(SweepArgs, DevCtx, int, double);
 // MINW (second __launch_bounds__ argument, waves per SIMD) caps the register
 // allocation: 96 VGPRs of positions at S=16 fit 3 waves/SIMD, S=32 fits 2, S=64 one.
 // G = slots per cutoff-test group (more independent chains for the single-wave S=64).
+// (S, MINW, G) for one wavefront per replica; (S, WPR, MINW, G) for several
+#define SMCX_FP64_TABLE1(X) X(1, 4, 1) X(2, 4, 2) X(4, 4, 2) X(8, 4, 2) X(16, 3, 2) X(32, 2, 2) X(64, 1, 2)
+#define SMCX_FP64_TABLE(X) X(8, 2, 4, 2) X(16, 2, 3, 2) X(32, 2, 2, 2) X(4, 4, 4, 2) X(8, 4, 4, 2) X(16, 4, 3, 2) \
+                           X(32, 4, 2, 2) X(8, 8, 4, 2) X(16, 8, 3, 2) X(32, 8, 2, 2) X(16, 16, 4, 2) X(32, 16, 2, 2)
+
 static sweep_fn lookup(int S, int WPR, bool lead = true)
 {
 #define SMCX_CASE1(s, m, gg) if (S == s && WPR == 1) return sweep_kernel<s, 1, m, gg>;
 #define SMCX_CASE(s, w, m, gg) if (S == s && WPR == w) return lead ? sweep_kernel_lead<s, w, m, gg> : sweep_kernel<s, w, m, gg>;
-    SMCX_CASE1(1, 4, 1) SMCX_CASE1(2, 4, 2) SMCX_CASE1(4, 4, 2) SMCX_CASE1(8, 4, 2)
-    SMCX_CASE1(16, 3, 2) SMCX_CASE1(32, 2, 2) SMCX_CASE1(64, 1, 2)
-    SMCX_CASE(8, 2, 4, 2) SMCX_CASE(16, 2, 3, 2) SMCX_CASE(32, 2, 2, 2)
-    SMCX_CASE(4, 4, 4, 2) SMCX_CASE(8, 4, 4, 2) SMCX_CASE(16, 4, 3, 2) SMCX_CASE(32, 4, 2, 2)
-    SMCX_CASE(8, 8, 4, 2) SMCX_CASE(16, 8, 3, 2) SMCX_CASE(32, 8, 2, 2)
-    SMCX_CASE(16, 16, 4, 2) SMCX_CASE(32, 16, 2, 2)
+    SMCX_FP64_TABLE1(SMCX_CASE1)
+    SMCX_FP64_TABLE(SMCX_CASE)
 #undef SMCX_CASE
 #undef SMCX_CASE1
     return nullptr;
+}
+
+// leader/follower form where it measured faster (profiles/r01_leader_follower.log): many
+// waves with few slots each; SMCX_NO_LEAD / SMCX_LEAD force one form for A/B measurements
+static bool use_lead(int S, int WPR)
+{
+    static const bool no_lead = getenv("SMCX_NO_LEAD") != nullptr, force_lead = getenv("SMCX_LEAD") != nullptr;
+    return WPR > 1 && (force_lead || (!no_lead && S <= 16 && WPR >= 4));
+}
+
+// the launched instantiation as rocprofv3 prints it
+const char *fp64_kernel_name(int S, int WPR)
+{
+    const bool lead = use_lead(S, WPR);
+#define SMCX_CASE1(s, m, gg) if (S == s && WPR == 1) return "smcx::sweep_kernel<" #s ", 1, " #m ", " #gg ">";
+#define SMCX_CASE(s, w, m, gg) if (S == s && WPR == w) return lead ? "smcx::sweep_kernel_lead<" #s ", " #w ", " #m ", " #gg ">" \
+                                                                  : "smcx::sweep_kernel<" #s ", " #w ", " #m ", " #gg ">";
+    SMCX_FP64_TABLE1(SMCX_CASE1)
+    SMCX_FP64_TABLE(SMCX_CASE)
+#undef SMCX_CASE
+#undef SMCX_CASE1
+    return "";
 }
 
 bool geometry_supported(int S, int WPR) { return lookup(S, WPR) != nullptr || mx_supported(S, WPR); }
@@ -752,10 +775,7 @@ bool sweep_uses_mx(int S, int WPR, int kernel)
 
 hipError_t launch_sweeps(const DevCtx &c, int S, int WPR, int nsweeps, double A, int kernel, hipStream_t st)
 {
-    // leader/follower form where it measured faster (profiles/r01_leader_follower.log): many
-    // waves with few slots each; SMCX_NO_LEAD / SMCX_LEAD force one form for A/B measurements
-    static const bool no_lead = getenv("SMCX_NO_LEAD") != nullptr, force_lead = getenv("SMCX_LEAD") != nullptr;
-    const bool lead = force_lead || (!no_lead && S <= 16 && WPR >= 4);
+    const bool lead = use_lead(S, WPR);
     sweep_fn f = lookup(S, WPR, lead);
     const bool use_mx = sweep_uses_mx(S, WPR, kernel);
     if (!f && !use_mx) return hipErrorInvalidValue;

@@ -460,13 +460,15 @@ sweep_kernel_mx(SweepArgs a, DevCtx c, int nsweeps, double A, MxArgs m)
 typedef void (*sweep_mx_fn)(SweepArgs, DevCtx, int, double, MxArgs);
 
 // fp32 z in registers: two VGPRs per particle
+// (particles per lane, wavefronts per replica, waves per SIMD the register budget is set for)
+#define SMCX_MX_TABLE(X) X(16, 1, 3) X(32, 1, 3) X(64, 1, 2) X(16, 2, 3) X(32, 2, 3) X(64, 2, 2) \
+                         X(16, 4, 4) X(32, 4, 3) X(64, 4, 2) X(32, 8, 3) X(64, 8, 2)
+#define SMCX_MZ_TABLE(X) X(64, 1, 4) X(32, 2, 4) X(64, 4, 4) X(32, 1, 4) X(64, 2, 4)
+
 static sweep_mx_fn lookup_mx(int S, int WPR)
 {
 #define SMCX_MX(s, w, m) if (S == s && WPR == w) return sweep_kernel_mx<s, w, m, false>;
-    SMCX_MX(16, 1, 3) SMCX_MX(32, 1, 3) SMCX_MX(64, 1, 2)
-    SMCX_MX(16, 2, 3) SMCX_MX(32, 2, 3) SMCX_MX(64, 2, 2)
-    SMCX_MX(16, 4, 4) SMCX_MX(32, 4, 3) SMCX_MX(64, 4, 2)
-    SMCX_MX(32, 8, 3) SMCX_MX(64, 8, 2)
+    SMCX_MX_TABLE(SMCX_MX)
 #undef SMCX_MX
     return nullptr;
 }
@@ -475,12 +477,25 @@ static sweep_mx_fn lookup_mx(int S, int WPR)
 static sweep_mx_fn lookup_mz(int S, int WPR)
 {
 #define SMCX_MZ(s, w, m) if (S == s && WPR == w) return sweep_kernel_mx<s, w, m, true>;
-    SMCX_MZ(64, 1, 4) SMCX_MZ(32, 2, 4) SMCX_MZ(64, 4, 4) SMCX_MZ(32, 1, 4) SMCX_MZ(64, 2, 4)
+    SMCX_MZ_TABLE(SMCX_MZ)
 #undef SMCX_MZ
     return nullptr;
 }
 
 bool mx_supported(int S, int WPR) { return lookup_mx(S, WPR) != nullptr; }
+
+// the launched instantiation as rocprofv3 prints it
+const char *mx_kernel_name(int S, int WPR, double Lz)
+{
+    const bool mz = mx_lds_z(S, WPR, Lz);
+#define SMCX_MX(s, w, m) if (!mz && S == s && WPR == w) return "smcx::sweep_kernel_mx<" #s ", " #w ", " #m ", false>";
+    SMCX_MX_TABLE(SMCX_MX)
+#undef SMCX_MX
+#define SMCX_MZ(s, w, m) if (mz && S == s && WPR == w) return "smcx::sweep_kernel_mx<" #s ", " #w ", " #m ", true>";
+    SMCX_MZ_TABLE(SMCX_MZ)
+#undef SMCX_MZ
+    return "";
+}
 
 bool mx_lds_z(int S, int WPR, double Lz)
 {
