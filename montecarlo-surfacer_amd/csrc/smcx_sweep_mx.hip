@@ -159,12 +159,16 @@ __device__ __forceinline__ void mx_screen_lds(const unsigned (&xy)[S], const uns
                                               unsigned (&cb)[(S + 31) / 32])
 {
     static_assert(S % 4 == 0, "groups of four slots");
+    // the LDS reads run one group ahead of their use
+    unsigned zn[2] = {zw[0][lane], zw[1][lane]};
 #pragma unroll
     for (int k0 = 0; k0 < S; k0 += 4) {
         float qa[4], qb[4];
+        const unsigned zc[2] = {zn[0], zn[1]};
+        if (k0 + 4 < S) { zn[0] = zw[k0 / 2 + 2][lane]; zn[1] = zw[k0 / 2 + 3][lane]; }
 #pragma unroll
         for (int p = 0; p < 2; p++) {
-            const mx_h2 zz = __builtin_bit_cast(mx_h2, zw[k0 / 2 + p][lane]);
+            const mx_h2 zz = __builtin_bit_cast(mx_h2, zc[p]);
             const mx_h2 da = __builtin_bit_cast(mx_h2, azz) - zz; // two slots at once
             const mx_h2 db = __builtin_bit_cast(mx_h2, bzz) - zz;
 #pragma unroll
