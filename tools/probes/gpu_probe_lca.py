@@ -1,7 +1,7 @@
 """ad hoc: time the cluster analysis at benchmark sizes (not a test)"""
 import sys, time
 import numpy as np
-sys.path.insert(0, "tests"); sys.path.insert(0, ".")
+sys.path.insert(0, "tests"); sys.path.insert(0, ".")  # run from the repo root
 import torch  # noqa: F401  (one HIP runtime per process: torch first)
 import oracle_lib as O
 import smcx_loader

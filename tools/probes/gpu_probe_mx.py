@@ -1,7 +1,7 @@
 """ad hoc: where do the screened and the fp64 kernel differ? (not a test)"""
 import sys
 import numpy as np
-sys.path.insert(0, "tests"); sys.path.insert(0, ".")
+sys.path.insert(0, "tests"); sys.path.insert(0, ".")  # run from the repo root
 import torch  # noqa: F401
 import oracle_lib as O
 import smcx_loader
