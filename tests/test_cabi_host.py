@@ -55,7 +55,10 @@ def test_parameter_validation_and_loud_failure_without_gpu(S):
     h = C.c_void_p()
     for kw, want in ((dict(N=107), S.ERR_PARAM), (dict(N=0), S.ERR_PARAM), (dict(nrep=0), S.ERR_PARAM),
                      (dict(L=-1.0), S.ERR_PARAM), (dict(T=0.0), S.ERR_PARAM), (dict(Ncz=300), S.ERR_PARAM),
-                     (dict(M=6), S.ERR_UNSUPPORTED), (dict(M=0), S.ERR_PARAM)):
+                     (dict(M=6), S.ERR_UNSUPPORTED), (dict(M=0), S.ERR_PARAM),
+                     (dict(tune_kernel=3), S.ERR_PARAM), (dict(tune_kernel=-1), S.ERR_PARAM),
+                     (dict(flags=S.FLAGS_REFERENCE | S.FLAG_CLUSTERS, lca_time=0), S.ERR_PARAM),
+                     (dict(flags=S.FLAGS_REFERENCE | S.FLAG_CLUSTERS, lca_cutoff=0.0), S.ERR_PARAM)):
         p = S.default_params(108, 2)
         for k, v in kw.items():
             setattr(p, k, v)
