@@ -36,10 +36,10 @@ namespace smcx {
 // (minimum-image) one and dxi^2 + dyi^2 <= (true, in units) + 2*sqrt(2)*R + 2 for a pair
 // inside the cutoff R = rc/u.  z: |fl32(z) - z| <= 2^-24 |z|, resp. |fl16(z) - z| <= zsafe *
 // 2^-12 for |z| < zsafe (a power of two).  The sum of both, plus the rounding of the final
-// expression, is `margin`; the test `!(thr <= q)` with thr = rc^2 + margin never rejects a
-// pair the fp64 test accepts.  A z outside the safe range is stored as NaN, which the
-// (unordered) compare always passes on to the exact evaluation.  Padding slots hold
-// z = +inf, a disabled probe z = -inf: never candidates.
+// expression, is `margin`; the test q - thr < 0 with thr = rc^2 + margin never rejects a
+// pair the fp64 test accepts.  Particles whose z is outside the safe range are kept in a
+// per-lane mask and are always candidates; a probe outside it makes every slot one.
+// Padding slots hold z = +inf, a disabled probe z = -inf: q = +inf, never candidates.
 // ---------------------------------------------------------------------------------
 struct MxArgs {
     float thr;      // screening threshold rc^2 + margin
@@ -59,12 +59,12 @@ __device__ __forceinline__ unsigned mx_pack_xy(double x, double y, double toFix)
 }
 __device__ __forceinline__ float mx_z32(double z, float zsafe)
 {
-    return (fabs(z) <= (double)zsafe) ? (float)z : __builtin_nanf("");
+    return (fabs(z) < (double)zsafe) ? (float)z : __builtin_nanf(""); // unsafe: see the kernel's mask
 }
 __device__ __forceinline__ unsigned mx_z16(double z, float zsafe) // fp16 bits
 {
     const unsigned short bits = __builtin_bit_cast(unsigned short, (_Float16)(float)z);
-    return (fabs(z) < (double)zsafe) ? (unsigned)bits : 0x7E00u; // NaN
+    return (fabs(z) < (double)zsafe) ? (unsigned)bits : 0x7E00u; // NaN; unsafe: see the kernel's mask
 }
 
 // rotate the register-resident slots by one: slot j <- slot j+1
@@ -98,22 +98,21 @@ __device__ __forceinline__ void mx_rotate_lds(unsigned (&zw)[S / 2][64], int lan
 }
 
 // ---- screening: candidate bits, slot k in bit k%32 of word k/32 ------------------------
-// Every compare is shifted into the lane's candidate word through the carry (v_cmp into VCC,
-// v_addc word + word + VCC): two 4-byte instructions per pair and no branch in the whole
-// screen.  Measured against scalar-register masks OR-ed per group of four slots with a branch
-// to a slow path: equal with z in LDS, 4 % faster with z in registers
-// (profiles/r01_screened_kernel.log).  The carry chain builds the word in reverse; the last
-// group turns it round.
+// The screen computes q - thr; its sign bit is the flag and is shifted into the lane's candidate
+// word with one v_alignbit_b32 ({word, q} >> 31): no compare, no carry through VCC, no branch.
+// Measured (A/B in one session, profiles/r01_screened_kernel.log): 6-9 % faster than
+// v_cmp + v_addc_co through the carry, which in turn beat scalar-register masks OR-ed per group of
+// four slots with a branch to a slow path.  A NaN has no defined sign: particles and probes
+// outside the safe z range are flagged by hand (kernel, `unsafe`).  The shift builds the word in
+// reverse; the last group turns it round.
 template <int S, int NW>
-__device__ __forceinline__ void mx_flag4(int k0, const float (&qa)[4], const float (&qb)[4], float thr,
-                                         unsigned (&ca)[NW], unsigned (&cb)[NW])
+__device__ __forceinline__ void mx_flag4(int k0, const float (&qa)[4], const float (&qb)[4], unsigned (&ca)[NW],
+                                         unsigned (&cb)[NW])
 {
 #pragma unroll
-    for (int j = 0; j < 4; j++) { // !(thr <= q): unordered, NaN is a candidate
-        asm("v_cmp_nle_f32_e32 vcc, %2, %1\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc"
-            : "+v"(ca[(k0 + j) >> 5]) : "v"(qa[j]), "s"(thr) : "vcc");
-        asm("v_cmp_nle_f32_e32 vcc, %2, %1\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc"
-            : "+v"(cb[(k0 + j) >> 5]) : "v"(qb[j]), "s"(thr) : "vcc");
+    for (int j = 0; j < 4; j++) {
+        ca[(k0 + j) >> 5] = __builtin_amdgcn_alignbit(ca[(k0 + j) >> 5], __builtin_bit_cast(unsigned, qa[j]), 31);
+        cb[(k0 + j) >> 5] = __builtin_amdgcn_alignbit(cb[(k0 + j) >> 5], __builtin_bit_cast(unsigned, qb[j]), 31);
     }
     if (k0 + 4 == S) {
 #pragma unroll
@@ -125,11 +124,11 @@ __device__ __forceinline__ void mx_flag4(int k0, const float (&qa)[4], const flo
     }
 }
 
-// u2 * (dxi^2 + dyi^2) of one particle and one probe
-__device__ __forceinline__ float mx_qxy(unsigned pxy, unsigned xy, float u2)
+// u2 * (dxi^2 + dyi^2) - thr of one particle and one probe
+__device__ __forceinline__ float mx_qxy(unsigned pxy, unsigned xy, float u2, float thr)
 {
     const mx_s2 d = __builtin_bit_cast(mx_s2, pxy) - __builtin_bit_cast(mx_s2, xy); // wraps: minimum image
-    return u2 * (float)__builtin_amdgcn_sdot2(d, d, 0, true);
+    return __builtin_fmaf(u2, (float)__builtin_amdgcn_sdot2(d, d, 0, true), -thr);
 }
 
 // z in registers (fp32): az, bz are the probes' z
@@ -145,10 +144,10 @@ __device__ __forceinline__ void mx_screen(const unsigned (&xy)[S], const float (
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const float da = az - z[k0 + j], db = bz - z[k0 + j];
-            qa[j] = __builtin_fmaf(da, da, mx_qxy(axy, xy[k0 + j], u2));
-            qb[j] = __builtin_fmaf(db, db, mx_qxy(bxy, xy[k0 + j], u2));
+            qa[j] = __builtin_fmaf(da, da, mx_qxy(axy, xy[k0 + j], u2, thr));
+            qb[j] = __builtin_fmaf(db, db, mx_qxy(bxy, xy[k0 + j], u2, thr));
         }
-        mx_flag4<S, (S + 31) / 32>(k0, qa, qb, thr, ca, cb);
+        mx_flag4<S, (S + 31) / 32>(k0, qa, qb, ca, cb);
     }
 }
 // z in LDS (fp16): azz, bzz hold the probes' z twice
@@ -175,11 +174,11 @@ __device__ __forceinline__ void mx_screen_lds(const unsigned (&xy)[S], const uns
             for (int h = 0; h < 2; h++) {
                 const int j = 2 * p + h;
                 const float fa = (float)(h ? da.y : da.x), fb = (float)(h ? db.y : db.x);
-                qa[j] = __builtin_fmaf(fa, fa, mx_qxy(axy, xy[k0 + j], u2)); // v_fma_mix_f32
-                qb[j] = __builtin_fmaf(fb, fb, mx_qxy(bxy, xy[k0 + j], u2));
+                qa[j] = __builtin_fmaf(fa, fa, mx_qxy(axy, xy[k0 + j], u2, thr)); // v_fma_mix_f32
+                qb[j] = __builtin_fmaf(fb, fb, mx_qxy(bxy, xy[k0 + j], u2, thr));
             }
         }
-        mx_flag4<S, (S + 31) / 32>(k0, qa, qb, thr, ca, cb);
+        mx_flag4<S, (S + 31) / 32>(k0, qa, qb, ca, cb);
     }
 }
 
@@ -207,12 +206,14 @@ __device__ __forceinline__ bool mx_any(const unsigned (&cw)[NW])
 // wavefront per replica every position is written and read by the same lane, so a plain
 // (L1-cached) load is coherent; several wavefronts need the L1-bypassing load.
 template <int S, int T, bool COHERENT>
-__device__ __forceinline__ void mx_fetch(const double *Rg, int tid, int rot, int k, double &X,
+__device__ __forceinline__ void mx_fetch(const double *Rg, int N, int tid, int rot, int k, double &X,
                                          double &Y, double &Z)
 {
     int ls = k + rot; // register slot -> logical slot
     if (ls >= S) ls -= S;
-    const double *q = Rg + 3 * (ls * T + tid);
+    const int l = ls * T + tid;
+    if (l >= N) { X = 0.0; Y = 0.0; Z = FAR_PAD; return; } // a padding slot (flagged only through an unsafe probe)
+    const double *q = Rg + 3 * l;
     if constexpr (COHERENT) { X = ld_coherent(q); Y = ld_coherent(q + 1); Z = ld_coherent(q + 2); }
     else { X = q[0]; Y = q[1]; Z = q[2]; }
 }
@@ -272,9 +273,17 @@ sweep_kernel_mx(SweepArgs a, DevCtx c, int nsweeps, double A, MxArgs m)
         if constexpr (ZL) zw[j][lane] = pair;
     }
     int rot = 0; // register slot j holds logical slot (j + rot) % S
+    // slots of this lane whose z is outside the safe range (always candidates), bit = register slot
+    unsigned long long unsafe = 0ull;
+#pragma unroll
+    for (int k = 0; k < S; k++) {
+        const int l = k * T + tid;
+        if (l < N && !(fabs(Rg[3 * l + 2]) < (double)m.zsafe)) unsafe |= 1ull << k;
+    }
     auto rotate = [&]() {
         mx_rotate<S, SZ>(xy, z);
         if constexpr (ZL) mx_rotate_lds<S>(zw, lane);
+        unsafe = (unsafe >> 1) | ((unsafe & 1ull) << (S - 1));
         rot = (rot + 1 == S) ? 0 : rot + 1;
     };
 
@@ -368,6 +377,16 @@ sweep_kernel_mx(SweepArgs a, DevCtx c, int nsweeps, double A, MxArgs m)
                     const float bzf = hasB ? mx_z32(Bz, m.zsafe) : -__builtin_inff();
                     mx_screen<S>(xy, z, axy, azf, bxy, bzf, m.u2, m.thr, ca, cb);
                 }
+                {   // the sign-bit screen does not see NaN: unsafe particles and unsafe probes by hand
+                    const bool ua = hasA && !(fabs(Qz) < (double)m.zsafe), ub = hasB && !(fabs(Bz) < (double)m.zsafe);
+#pragma unroll
+                    for (int w = 0; w < NW; w++) {
+                        const unsigned uw = (unsigned)(unsafe >> (32 * w));
+                        const unsigned all = (w == NW - 1 && (S & 31)) ? ((1u << (S & 31)) - 1u) : ~0u;
+                        ca[w] = ua ? all : (ca[w] | uw);
+                        cb[w] = ub ? all : (cb[w] | uw);
+                    }
+                }
                 // the moving particle itself and the particle probe B stands for are not neighbours
                 {
                     const bool exA0 = (tid == tl);
@@ -388,8 +407,8 @@ sweep_kernel_mx(SweepArgs a, DevCtx c, int nsweeps, double A, MxArgs m)
                     int kA = mx_pick<NW>(ca), kB = mx_pick<NW>(cb);
                     do {
                         double XA = 0, YA = 0, ZA = 0, XB = 0, YB = 0, ZB = 0;
-                        if (kA >= 0) mx_fetch<S, T, (WPR > 1)>(Rg, tid, rot, kA, XA, YA, ZA);
-                        if (kB >= 0) mx_fetch<S, T, (WPR > 1)>(Rg, tid, rot, kB, XB, YB, ZB);
+                        if (kA >= 0) mx_fetch<S, T, (WPR > 1)>(Rg, N, tid, rot, kA, XA, YA, ZA);
+                        if (kB >= 0) mx_fetch<S, T, (WPR > 1)>(Rg, N, tid, rot, kB, XB, YB, ZB);
                         if (kA >= 0) mx_exact(g, Qx, Qy, Qz, XA, YA, ZA, v.a0, v.a1, v.a2, v.a3);
                         if (kB >= 0) mx_exact(g, Bx, By, Bz, XB, YB, ZB, v.b0, v.b1, v.b2, v.b3);
                         kA = mx_pick<NW>(ca); kB = mx_pick<NW>(cb);
@@ -418,6 +437,7 @@ sweep_kernel_mx(SweepArgs a, DevCtx c, int nsweeps, double A, MxArgs m)
                     acc = (uniform((int)acc) != 0);
                     if (acc && tid == tl) {
                         xy[0] = axy;
+                        unsafe = (unsafe & ~1ull) | (!(fabs(Qz) < (double)m.zsafe) ? 1ull : 0ull);
                         if constexpr (ZL) reinterpret_cast<unsigned short *>(&zw[0][lane])[0] = (unsigned short)azh;
                         else z[0] = azf;
                         Rg[3 * n] = Qx; Rg[3 * n + 1] = Qy; Rg[3 * n + 2] = Qz; // the fp64 state
