@@ -35,7 +35,6 @@ template <int OP> __global__ void __launch_bounds__(1024) k(float *out, float cf
         if (OP == 0) { X16(SUB) } if (OP == 1) { X16(MUL) } if (OP == 2) { X16(FMAC) } if (OP == 3) { X16(FMA3) }
         if (OP == 4) { X16(CMPADDC) } if (OP == 5) { X16(CMP) } if (OP == 6) { X16(ADDC) } if (OP == 7) { X16(RND) }
         if (OP == 8) { X16(PKFMA) } if (OP == 9) { X16(PKADD) } if (OP == 10) { X16(PKMUL) } if (OP == 11) { X16(DOT2) }
-#define SCREEN(j) asm volatile("v_pk_sub_i16 %0, %3, %1\n\tv_dot2_i32_i16 %0, %0, %0, 0 clamp\n\tv_cvt_f32_i32_e32 %0, %0\n\tv_mul_f32_e32 %0, %3, %0\n\tv_fma_mix_f32 %0, %2, %2, %0 op_sel_hi:[1,1,0]\n\tv_cmp_nle_f32_e64 s[20:21], %3, %0\n\ts_or_b64 s[22:23], s[22:23], s[20:21]" : "=&v"(f[j]) : "v"(u[j]), "v"(g[j]), "s"(cf) : "s20", "s21", "s22", "s23");
 #define SCREENP(j) asm volatile("v_pk_sub_i16 %0, %3, %1\n\tv_dot2_i32_i16 %0, %0, %0, 0 clamp\n\tv_cvt_f32_i32_e32 %0, %0\n\tv_mul_f32_e32 %0, %3, %0\n\tv_fma_mix_f32 %0, %2, %2, %0 op_sel_hi:[1,1,0]\n\tv_cmp_nle_f32_e32 vcc, %3, %0\n\tv_addc_co_u32_e32 %1, vcc, %1, %1, vcc" : "=&v"(f[j]), "+v"(u[j]) : "v"(g[j]), "s"(cf) : "vcc");
 #define PKSUBI(j) asm volatile("v_pk_sub_i16 %0, %1, %0" : "+v"(u[j]) : "v"(u[(j + 1) & 15]));
 #define DOT2I(j) asm volatile("v_dot2_i32_i16 %0, %1, %1, %0 clamp" : "+v"(u[j]) : "v"(u[(j + 1) & 15]));
@@ -44,7 +43,7 @@ template <int OP> __global__ void __launch_bounds__(1024) k(float *out, float cf
 #define SUBU(j) asm volatile("v_sub_u32_e32 %0, %1, %0" : "+v"(u[j]) : "v"(u[(j + 1) & 15]));
 #define MUL24(j) asm volatile("v_mul_i32_i24_e32 %0, %1, %1" : "=v"(u[j]) : "v"(u[(j + 1) & 15]));
 #define ASHR(j) asm volatile("v_ashrrev_i32_e32 %0, 16, %1" : "=v"(u[j]) : "v"(u[(j + 1) & 15]));
-        if (OP == 16) { X16(SCREEN) } if (OP == 17) { X16(SCREENP) }
+        if (OP == 17) { X16(SCREENP) }
         if (OP == 18) { X16(PKSUBI) } if (OP == 19) { X16(DOT2I) } if (OP == 20) { X16(CVTI) } if (OP == 21) { X16(FMAMIX) }
         if (OP == 22) { X16(SUBU) } if (OP == 23) { X16(MUL24) } if (OP == 24) { X16(ASHR) }
         if (OP == 12) { X16(PKADDH) } if (OP == 13) { X16(MINABS) } if (OP == 14) { X16(PAIR) } if (OP == 15) { X16(DOT2C) }
@@ -85,7 +84,6 @@ int main()
     run<12>("v_pk_add_f16", 1); run<11>("v_dot2_f32_f16", 1);
     for (int t : {512}) {
         printf("-- %d wave(s) per SIMD\n", t / 256);
-        run<16>("screen: 6 VALU (cmp_e64 -> sgpr) + s_or", 6, t);
         run<17>("screen: 7 VALU (cmp_e32 + addc)", 7, t);
         run<0>("v_sub_f32_e32", 1, t); run<11>("v_dot2_f32_f16", 1, t); run<3>("v_fma_f32", 1, t);
     }
