@@ -189,7 +189,7 @@ static int choose_geometry(const smcx_params *p, int *S, int *WPR)
     auto pow2_at_least = [](long v) { int r = 1; while (r < v) r *= 2; return r; };
     int s, w;
     const bool fp64_only = (p->tune_kernel == 1);
-    if (!fp64_only && p->N > 512) {
+    if (!fp64_only && (p->N > 512 || p->tune_kernel == 2)) {
         s = pow2_at_least((p->N + 63) / 64); w = 1;
         if (s < 16) s = 16;
         while (s > 64) { s /= 2; w *= 2; }

@@ -462,7 +462,10 @@ def test_energy_autocorrelation(S, O):
     (1024, (8, 4), 33.0, 16, 1, 6, True),
     (1024, (8, 4), 16.0, 16, 1, 3, True),     # box of 5.3 cutoffs: most probes within a cutoff of a periodic edge
     (2000, (8, 8), 33.0, 32, 1, 3, True),     # ragged: N is not a multiple of 64
+    (256, (4, 4), 33.0, 0, 0, 8, True),       # small N: the screened kernel asked for by tune_kernel alone (S=16)
     (1024, (8, 4), 33.0, 16, 1, 3, False),    # no walls, a slab of particles beyond the fp32-safe z range
+    (4000, (8, 16), 33.0, 64, 1, 2, False),   # z as fp16 in LDS, ragged N (padding slots), no walls, part of the
+                                              # system beyond the fp16-safe range: unsafe particles AND unsafe probes
 ])
 def test_screened_kernel_matches_fp64_kernel(S, O, N, lat, L, slots, waves, nsw, walls):
     """the compact-copy (int16 x,y + fp32 z) screen of smcx_sweep_mx.hip only pre-selects pairs:
@@ -476,17 +479,24 @@ def test_screened_kernel_matches_fp64_kernel(S, O, N, lat, L, slots, waves, nsw,
     R0[:, 0] -= L * np.rint(R0[:, 0] / L); R0[:, 1] -= L * np.rint(R0[:, 1] / L)
     R0[:2, 2] = [119.99, -119.999]            # at both walls
     flags = S.FLAGS_REFERENCE | S.FLAG_SERIES
-    if not walls:                              # z beyond zsafe = 2 Lz is stored as NaN: always a candidate
+    if not walls:                              # particles beyond zsafe are always candidates, probes there flag all
         flags = S.FLAG_E0_RESTART | S.FLAG_SERIES
-        R0[R0[:, 2] > 6.0, 2] += 600.0
-        assert (R0[:, 2] > 500).sum() > 100
+        if slots == 64:                        # zsafe = 128 (fp16 z): move the upper part of the film across it
+            R0[R0[:, 2] > 6.0, 2] += 105.0
+            assert (np.abs(R0[:, 2]) > 128).sum() > 100 and (np.abs(R0[:, 2]) < 128).sum() > 100
+        else:                                  # zsafe = 2 Lz (fp32 z)
+            R0[R0[:, 2] > 6.0, 2] += 600.0
+            assert (R0[:, 2] > 500).sum() > 100
     nrep = 3
     out = []
     for kernel in (1, 2):
         fp64_slots, fp64_waves = (slots, waves) if kernel == 2 or S.geometry_supported_fp64(slots, waves) else (0, 0)
+        if slots == 0:
+            fp64_slots, fp64_waves = 0, 0
         p = S.default_params(N, nrep, L=L, tune_slots=fp64_slots, tune_waves=fp64_waves, tune_kernel=kernel,
                              flags=flags)
         eng = S.Engine(p)
+        assert eng.kernel_form[0] == kernel
         eng.upload(R0.ravel(), O.W_FIXTURE)
         eng.run(1, nsw, 1)
         E, jj = eng.series(nsw)
