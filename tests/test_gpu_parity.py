@@ -207,6 +207,26 @@ def test_free_running_chain_observables(S, O, Na, Nz, nsw, kw):
     eng.close()
 
 
+def test_benchmark_kernel_against_oracle_N4096(S, O):
+    """the kernel bench.py measures (N=4096: 64 particles per lane, one wavefront per replica, x,y as
+    int16 and z as fp16 screening copies) against the CPU oracle, 3 sweeps from the benchmark's start"""
+    R0 = O.fcc(8, 16)
+    nsw, nrep = 3, 2
+    eng, p = make_engine(S, O, R0, nrep, flags=S.FLAGS_REFERENCE | S.FLAG_SERIES, tune_slots=64, tune_waves=1)
+    assert eng.kernel_form == (2, "smcx::sweep_kernel_mx<64, 1, 4, true>"), eng.kernel_form
+    eng.run(0, nsw, 1)
+    ob = eng.observables()
+    Es, jj = eng.series(nsw)
+    s = sys_of(O, p)
+    for r in range(nrep):
+        ref = O.chain(s, 12345 + r, R0, O.W_FIXTURE, T, A, 0, nsw, 1)
+        assert np.array_equal(jj[r], ref["jj"])
+        assert np.all(rel(Es[r], ref["E"], scale=1.0) < 1e-9), (Es[r], ref["E"])
+        assert rel(ob["meanE"][r], ref["meanE"]) < 1e-9 and rel(ob["acceptance_ratio"][r], ref["acceptance_ratio"]) < 1e-12
+        assert np.array_equal(ob["zhist"][r], ref["zhist"])
+    eng.close()
+
+
 def test_thermalisation_and_E0_restart(S, O):
     """SMC.c:110-125 (2A thermalisation) and the E[0] restart of the production series (:194)"""
     R0 = O.fcc(4, 4)
