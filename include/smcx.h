@@ -195,6 +195,11 @@ int smcx_geometry(const smcx_handle *h, int *slots, int *waves_per_replica, int 
  * (int16 x,y + fp32 z copies in registers, fp64 evaluation of the candidates); name, if not NULL,
  * receives the kernel's name (at most len bytes) */
 int smcx_kernel_form(const smcx_handle *h, int *form, char *name, int len);
+/* the numbers of the screened kernel's conservative cutoff test for a box (host only, no GPU needed):
+ * thr = cutoff^2 + margin (fp32), u2 = (L/65536)^2, to_fixed = 65536/L, zsafe = |z| up to which the
+ * margin holds; lds_z selects the variant with z as fp16.  tests/test_cabi_host.py checks on the CPU,
+ * with the device's arithmetic emulated, that no pair inside the cutoff escapes the test. */
+int smcx_screen_bound(const smcx_params *p, int lds_z, double *thr, double *u2, double *to_fixed, double *zsafe);
 
 /* Teacher-forced evaluator (stateless; tests and debugging): for each of nrep
  * replicas evaluates what SMC.c:300-304 and 319-321 evaluate for particle

@@ -57,7 +57,7 @@ EXPORTS = [
     "smcx_total_energy", "smcx_rng_export", "smcx_rng_import", "smcx_obs_device_bytes",
     "smcx_export_observables_device", "smcx_last_kernel_ms", "smcx_last_run_ms", "smcx_geometry", "smcx_eval_moves",
     "smcx_rng_seed", "smcx_one_particle_moves",
-    "smcx_cluster_counts", "smcx_cluster_update", "smcx_cluster_analysis", "smcx_kernel_form",
+    "smcx_cluster_counts", "smcx_cluster_update", "smcx_cluster_analysis", "smcx_kernel_form", "smcx_screen_bound",
 ]
 
 
@@ -101,6 +101,7 @@ def _lib():
         L.smcx_last_run_ms.argtypes = [vp, _dp]
         L.smcx_geometry.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.smcx_kernel_form.argtypes = [vp, C.POINTER(C.c_int), C.c_char_p, C.c_int]
+        L.smcx_screen_bound.argtypes = [C.POINTER(Params), C.c_int, _dp, _dp, _dp, _dp]
         L.smcx_eval_moves.argtypes = [C.POINTER(Params), _dp, _dp, _i32p, _dp, _dp]
         L.smcx_rng_seed.argtypes = [_u32p, C.c_uint32]
         L.smcx_rng_seed.restype = None
@@ -133,6 +134,15 @@ def geometry_supported_fp64(slots, waves):
     return (slots, waves) in {(1, 1), (2, 1), (4, 1), (8, 1), (16, 1), (32, 1), (64, 1), (8, 2), (16, 2),
                               (32, 2), (4, 4), (8, 4), (16, 4), (32, 4), (8, 8), (16, 8), (32, 8),
                               (16, 16), (32, 16)}
+
+
+def screen_bound(p, lds_z):
+    """(thr, u2, to_fixed, zsafe) of the screened kernel's cutoff test for the box of p"""
+    v = [C.c_double() for _ in range(4)]
+    rc = _lib().smcx_screen_bound(C.byref(p), int(lds_z), *[C.byref(x) for x in v])
+    if rc != OK:
+        raise SmcxError(rc, "smcx_screen_bound")
+    return tuple(x.value for x in v)
 
 
 def rng_seed(seed):

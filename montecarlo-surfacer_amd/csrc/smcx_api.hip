@@ -324,6 +324,15 @@ extern "C" int smcx_geometry(const smcx_handle *hh, int *slots, int *waves, int 
     return SMCX_OK;
 }
 
+extern "C" int smcx_screen_bound(const smcx_params *p, int lds_z, double *thr, double *u2, double *to_fixed,
+                                 double *zsafe)
+{
+    if (!p || !thr || !u2 || !to_fixed || !zsafe) return SMCX_ERR_PARAM;
+    if (!(p->L > 0) || !(p->Lz > 0) || !(p->cutoff > 0)) return SMCX_ERR_PARAM;
+    mx_bound_values(p->L, p->Lz, p->cutoff * p->cutoff, lds_z != 0, thr, u2, to_fixed, zsafe);
+    return SMCX_OK;
+}
+
 extern "C" int smcx_kernel_form(const smcx_handle *hh, int *form, char *name, int len)
 {
     if (!hh) return SMCX_ERR_PARAM;

@@ -11,6 +11,8 @@ bool fp64_supported(int S, int WPR);
 bool mx_supported(int S, int WPR);
 bool mx_lds_z(int S, int WPR, double Lz); // the variant with z as fp16 in LDS is the one launched
 const char *mx_kernel_name(int S, int WPR, double Lz);
+void mx_bound_values(double L, double Lz, double cutoff2, bool lds_z, double *thr, double *u2, double *toFix,
+                     double *zsafe);
 const char *fp64_kernel_name(int S, int WPR);
 hipError_t launch_sweeps_mx(const SweepArgs &a, const DevCtx &c, int S, int WPR, int nsweeps, double A,
                             hipStream_t st);

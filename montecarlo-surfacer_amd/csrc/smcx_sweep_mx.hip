@@ -529,6 +529,40 @@ bool mx_lds_z(int S, int WPR, double Lz)
     return mz && lookup_mz(S, WPR) != nullptr;
 }
 
+// screening threshold and scales: the bound in the comment of sweep_kernel_mx
+static MxArgs mx_bound(double L, double Lz, double cutoff2, bool mz)
+{
+    const double rc = sqrt(cutoff2), eps = 5.9604644775390625e-8; // 2^-24
+    const double zsafe = 2.0 * Lz; // the walls keep particles within Lz/2; beyond zsafe the screen passes everything on
+    const double u = L / 65536.0, R = rc / u;
+    const double m_xy = (2.0 * sqrt(2.0) * R + 2.0) * u * u;           // fixed-point x,y
+    const double m_z = 2.0 * rc * (3.0 * eps * zsafe) + 1e-9;           // fp32 z of particle and probe
+    const double margin = (m_xy + m_z) * 1.01 + 8.0 * eps * (cutoff2 + m_xy + m_z) + 1e-6 * cutoff2;
+    MxArgs m;
+    m.thr = nextafterf((float)(cutoff2 + margin), INFINITY);
+    m.u2 = (float)(u * u);
+    m.toFix = 65536.0 / L;
+    m.zsafe = (float)zsafe;
+    if (mz) { // fp16 z: |z| < zsafe_h (power of two) is kept to zsafe_h * 2^-12, particle and probe
+        double zs = 1.0;
+        while (zs < 0.51 * Lz) zs *= 2.0;
+        const double dz = 2.0 * zs / 4096.0 + (rc + 1.0) / 1024.0;
+        const double mzh = 2.0 * rc * dz + dz * dz;
+        const double margin_h = (m_xy + mzh) * 1.01 + 8.0 * eps * (cutoff2 + m_xy + mzh) + 1e-6 * cutoff2;
+        m.thr = nextafterf((float)(cutoff2 + margin_h), INFINITY);
+        m.zsafe = (float)zs;
+    }
+    return m;
+}
+
+// host-visible copy of the numbers above (smcx_screen_bound: the CPU test of the bound uses them)
+void mx_bound_values(double L, double Lz, double cutoff2, bool lds_z, double *thr, double *u2, double *toFix,
+                     double *zsafe)
+{
+    const MxArgs m = mx_bound(L, Lz, cutoff2, lds_z);
+    *thr = m.thr; *u2 = m.u2; *toFix = m.toFix; *zsafe = m.zsafe;
+}
+
 hipError_t launch_sweeps_mx(const SweepArgs &a, const DevCtx &c, int S, int WPR, int nsweeps, double A,
                             hipStream_t st)
 {
@@ -539,27 +573,7 @@ hipError_t launch_sweeps_mx(const SweepArgs &a, const DevCtx &c, int S, int WPR,
     const bool mz = mx_lds_z(S, WPR, c.Lz);
     if (mz) fm = lookup_mz(S, WPR);
     if (!fm) return hipErrorInvalidValue;
-    // screening threshold: see the bound in the comment of sweep_kernel_mx
-    const double rc = sqrt(c.cutoff2), eps = 5.9604644775390625e-8; // 2^-24
-    const double zsafe = 2.0 * c.Lz; // the walls keep particles within Lz/2; beyond zsafe the screen passes everything on
-    const double u = c.L / 65536.0, R = rc / u;
-    const double m_xy = (2.0 * sqrt(2.0) * R + 2.0) * u * u;           // fixed-point x,y
-    const double m_z = 2.0 * rc * (3.0 * eps * zsafe) + 1e-9;           // fp32 z of particle and probe
-    const double margin = (m_xy + m_z) * 1.01 + 8.0 * eps * (c.cutoff2 + m_xy + m_z) + 1e-6 * c.cutoff2;
-    MxArgs m;
-    m.thr = nextafterf((float)(c.cutoff2 + margin), INFINITY);
-    m.u2 = (float)(u * u);
-    m.toFix = 65536.0 / c.L;
-    m.zsafe = (float)zsafe;
-    if (mz) { // fp16 z: |z| < zsafe_h (power of two) is kept to zsafe_h * 2^-12, particle and probe
-        double zs = 1.0;
-        while (zs < 0.51 * c.Lz) zs *= 2.0;
-        const double dz = 2.0 * zs / 4096.0 + (rc + 1.0) / 1024.0;
-        const double mzh = 2.0 * rc * dz + dz * dz;
-        const double margin_h = (m_xy + mzh) * 1.01 + 8.0 * eps * (c.cutoff2 + m_xy + mzh) + 1e-6 * c.cutoff2;
-        m.thr = nextafterf((float)(c.cutoff2 + margin_h), INFINITY);
-        m.zsafe = (float)zs;
-    }
+    const MxArgs m = mx_bound(c.L, c.Lz, c.cutoff2, mz);
     hipLaunchKernelGGL(fm, dim3(c.nrep), dim3(64 * WPR), 0, st, a, c, nsweeps, A, m);
     return hipGetLastError();
 }

@@ -76,6 +76,69 @@ def test_parameter_validation_and_loud_failure_without_gpu(S):
     assert lib.smcx_destroy(None) == S.OK
 
 
+def _emulated_screen(S, p, lds_z, P, X):
+    """the screen of csrc/smcx_sweep_mx.hip (mx_qxy, mx_screen / mx_screen_lds) in numpy with the
+    device's roundings: int16 wrap of x,y, saturating dot2, fp32 fma, fp32 or fp16 z.  P: probes
+    [n,3], X: particles [n,3]; returns (candidate flag, exact in-cutoff flag, unsafe flag)"""
+    thr, u2, to_fixed, zsafe = S.screen_bound(p, lds_z)
+    f32 = np.float32
+
+    def pack(v):   # mx_pack_xy: rint, then the low 16 bits as int16
+        return np.rint(v * to_fixed).astype(np.int64).astype(np.uint16).astype(np.int16)
+
+    dxi = (pack(P[:, 0]).astype(np.int32) - pack(X[:, 0]).astype(np.int32)).astype(np.int16).astype(np.int64)  # v_pk_sub_i16 wraps
+    dyi = (pack(P[:, 1]).astype(np.int32) - pack(X[:, 1]).astype(np.int32)).astype(np.int16).astype(np.int64)
+    i2 = np.minimum(dxi * dxi + dyi * dyi, 2 ** 31 - 1)                      # v_dot2_i32_i16 clamp
+    t = (f32(u2).astype(np.float64) * i2.astype(f32).astype(np.float64) - f32(thr).astype(np.float64)).astype(f32)  # v_fma_f32
+    if lds_z:
+        zh, ph = X[:, 2].astype(f32).astype(np.float16), P[:, 2].astype(f32).astype(np.float16)
+        dz = (ph.astype(f32) - zh.astype(f32)).astype(np.float16).astype(np.float64)  # v_pk_add_f16
+    else:
+        dz = (P[:, 2].astype(f32) - X[:, 2].astype(f32)).astype(np.float64)            # v_sub_f32 (exact in double, then f32)
+        dz = dz.astype(f32).astype(np.float64)
+    q = (dz * dz + t.astype(np.float64)).astype(f32)                                   # v_fma(_mix)_f32
+    cand = np.signbit(q)
+    unsafe = ~(np.abs(X[:, 2]) < zsafe) | ~(np.abs(P[:, 2]) < zsafe)
+    d = P - X
+    d[:, 0] -= p.L * np.rint(d[:, 0] / p.L); d[:, 1] -= p.L * np.rint(d[:, 1] / p.L)
+    exact = (d * d).sum(axis=1) < p.cutoff ** 2
+    return cand, exact, unsafe
+
+
+@pytest.mark.parametrize("L,Lz,lds_z", [(33.0, 240.0, 0), (33.0, 240.0, 1), (6.5, 240.0, 1), (100.0, 60.0, 0),
+                                        (100.0, 900.0, 1)])
+def test_screen_never_misses_a_pair_inside_the_cutoff(S, L, Lz, lds_z):
+    """the proof obligation of the screened sweep kernel, checked on the CPU with the
+    product's own threshold (smcx_screen_bound) and the device's arithmetic emulated: pairs placed on
+    both sides of the cutoff sphere, also across the periodic x,y edges and at the edge of the safe
+    z range; every pair inside the cutoff must be a candidate (or sit in the unsafe set, which the
+    kernel always passes on), and the candidates must stay close to the true hits"""
+    p = S.default_params(1024, 1, L=L, Lz=Lz)
+    rs = np.random.RandomState(int(L * 10 + Lz) + lds_z)
+    n = 2_000_000
+    thr, u2, to_fixed, zsafe = S.screen_bound(p, lds_z)
+    assert thr > p.cutoff ** 2 and zsafe >= Lz / 2
+    X = np.empty((n, 3))
+    X[:, 0] = rs.uniform(-L / 2, L / 2, n); X[:, 1] = rs.uniform(-L / 2, L / 2, n)
+    X[:, 2] = rs.uniform(-1.05, 1.05, n) * min(zsafe, 4 * Lz)
+    X[: n // 8, 2] = np.sign(X[: n // 8, 2]) * zsafe * (1 - 10.0 ** rs.uniform(-7, -1, n // 8))   # just inside the safe range
+    r = p.cutoff * (1 + rs.uniform(-1, 1, n) * 10.0 ** rs.uniform(-9, -0.5, n))                # radii around the cutoff
+    r[: n // 16] = rs.uniform(0.3, p.cutoff, n // 16)
+    v = rs.standard_normal((n, 3)); v /= np.linalg.norm(v, axis=1)[:, None]
+    P = X + r[:, None] * v
+    P[:, 0] -= L * np.rint(P[:, 0] / L); P[:, 1] -= L * np.rint(P[:, 1] / L)                 # probes are kept wrapped
+    cand, exact, unsafe = _emulated_screen(S, p, lds_z, P, X)
+    assert exact.sum() > n // 4 and (~exact).sum() > n // 4
+    missed = exact & ~cand & ~unsafe
+    assert not missed.any(), (missed.sum(), P[missed][:3], X[missed][:3])
+    # and it is not vacuous: pairs clearly outside are rejected (the roundings that the margin covers can
+    # also make a pair look closer, so a false candidate is at most about two margins outside)
+    d2 = ((P - X) ** 2).sum(axis=1)  # not minimum image: only used far from the edges below
+    inner = (np.abs(X[:, 0]) < L / 2 - 2 * p.cutoff) & (np.abs(X[:, 1]) < L / 2 - 2 * p.cutoff) & ~unsafe
+    if inner.sum() > 1000:
+        assert not (cand & inner & (d2 > p.cutoff ** 2 + 2.2 * (thr - p.cutoff ** 2) + 0.01)).any()
+
+
 def test_srand_state_agrees_with_oracle_rand(S, O):
     """smcx_rng_seed = srand(): continuing r[i] = r[i-31] + r[i-3] from the exported
     state must give rand()'s outputs."""
