@@ -126,8 +126,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    warm_ms, warm_launches = 0.0, 0
     if a.warmup > 0:
         eng.run(0, a.warmup, gather_lapse)
+        warm_ms, warm_launches = eng.last_kernel_ms()
     barrier()
     t0 = time.perf_counter()
     eng.run(0, a.steps, gather_lapse)                  # exactly K steps; returns after stream sync
@@ -197,6 +199,9 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": kname,
                          "launches": launches, "avg_launch_ms": sweep_ms / max(launches, 1),
+                         # what `rocprofv3 --stats` averages over: the warm-up launches as well
+                         "launches_incl_warmup": launches + warm_launches,
+                         "avg_launch_ms_incl_warmup": (sweep_ms + warm_ms) / max(launches + warm_launches, 1),
                          "ms_per_sweep": sweep_ms / a.steps,
                          "algorithmic_bytes_per_launch": algo_bytes_per_launch,
                          "note": "algorithmic bytes = 24 B x pair-evals (streaming model, SURVEY 8d); "
