@@ -43,7 +43,13 @@ template <int OP> __global__ void __launch_bounds__(1024) k(float *out, float cf
 #define SUBU(j) asm volatile("v_sub_u32_e32 %0, %1, %0" : "+v"(u[j]) : "v"(u[(j + 1) & 15]));
 #define MUL24(j) asm volatile("v_mul_i32_i24_e32 %0, %1, %1" : "=v"(u[j]) : "v"(u[(j + 1) & 15]));
 #define ASHR(j) asm volatile("v_ashrrev_i32_e32 %0, 16, %1" : "=v"(u[j]) : "v"(u[(j + 1) & 15]));
+#define RFL(j) asm volatile("v_readfirstlane_b32 s20, %0\n\tv_add_f32_e32 %0, s20, %0" : "+v"(f[j]) : : "s20");
+#define RFL2(j) asm volatile("v_readfirstlane_b32 s20, %0\n\tv_readfirstlane_b32 s21, %1\n\tv_add_f32_e32 %0, s20, %0\n\tv_add_f32_e32 %1, s21, %1" : "+v"(f[j]), "+v"(g[j]) : : "s20", "s21");
+#define RDL(j) asm volatile("v_readlane_b32 s20, %0, 5\n\tv_add_f32_e32 %0, s20, %0" : "+v"(f[j]) : : "s20");
+#define WRL(j) asm volatile("v_writelane_b32 %0, %1, 7" : "+v"(f[j]) : "s"(cf));
+#define F64ADD(j) asm volatile("v_add_f64 %0, %0, %1" : "+v"(d[j]) : "v"(d[(j + 1) & 15]));
         if (OP == 17) { X16(SCREENP) }
+        if (OP == 25) { X16(RFL) } if (OP == 26) { X16(RFL2) } if (OP == 27) { X16(RDL) } if (OP == 28) { X16(WRL) }
         if (OP == 18) { X16(PKSUBI) } if (OP == 19) { X16(DOT2I) } if (OP == 20) { X16(CVTI) } if (OP == 21) { X16(FMAMIX) }
         if (OP == 22) { X16(SUBU) } if (OP == 23) { X16(MUL24) } if (OP == 24) { X16(ASHR) }
         if (OP == 12) { X16(PKADDH) } if (OP == 13) { X16(MINABS) } if (OP == 14) { X16(PAIR) } if (OP == 15) { X16(DOT2C) }
@@ -82,6 +88,10 @@ int main()
     run<18>("v_pk_sub_i16", 1); run<19>("v_dot2_i32_i16 clamp", 1); run<20>("v_cvt_f32_i32_e32", 1); run<21>("v_fma_mix_f32", 1);
     run<22>("v_sub_u32_e32", 1); run<23>("v_mul_i32_i24_e32", 1); run<24>("v_ashrrev_i32_e32", 1); run<0>("v_sub_f32_e32", 1);
     run<12>("v_pk_add_f16", 1); run<11>("v_dot2_f32_f16", 1);
+    printf("-- lane operations (each followed by a VALU use of the scalar), 2 and 4 waves per SIMD\n");
+    run<25>("v_readfirstlane + v_add using it", 2); run<26>("2 x v_readfirstlane + 2 x v_add", 4); run<27>("v_readlane + v_add using it", 2);
+    run<28>("v_writelane", 1);
+    run<25>("v_readfirstlane + v_add using it", 2, 1024); run<27>("v_readlane + v_add using it", 2, 1024); run<28>("v_writelane", 1, 1024);
     for (int t : {512}) {
         printf("-- %d wave(s) per SIMD\n", t / 256);
         run<17>("screen: 7 VALU (cmp_e32 + addc)", 7, t);
