@@ -42,7 +42,7 @@ void smcx_host_initialize_walls(double x0m, double x0sigma, double ymm, double y
 void smcx_host_box_for_N(int N, double *L, double *Lz);
 
 /* ensemble results of one smcx_host_sMC call (struct Sim, SMC.h:76-88, per replica
- * and averaged over replicas; pressure and ACF come from smcx_pressure_series / smcx_acf) */
+ * and averaged over replicas) */
 typedef struct smcx_sim {
     int nrep, N, Ncz;
     double E, dE;              /* ensemble mean of the replicas' mean energy / of their dE */
@@ -59,6 +59,11 @@ typedef struct smcx_sim {
      * division (0 unless the ratio is 1) added into uninitialised l2[7], l3[7]. */
     double l1, l2[16], l3[16];
     int lca_analyses;
+    /* SMCX_FLAG_PRESSURE: mean and deviation of the total pressure P[k] + rho*T over the reference's
+     * gather_steps entries (P[0] never written, the last gather out of bounds: SMC.c:138-140, 207-208,
+     * 246-247), ensemble mean.  SMCX_FLAG_SERIES: tau = sum(acf) and cv = variance(E)/T^2
+     * (SMC.c:234-235, 249-250), ensemble mean; the ACF itself: smcx_acf. */
+    double P, dP, tau, cv;
     double kernel_ms;          /* device time of the sweep kernels */
     double pair_evals_per_s;   /* nrep*maxsteps*2N(N-1) / kernel time */
 } smcx_sim;

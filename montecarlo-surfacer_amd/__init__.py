@@ -365,6 +365,17 @@ W_REFERENCE = np.array([
     844.42493013196849, 50.331648000000015])
 
 
+class HostSim(C.Structure):
+    """mirror of smcx_sim (include/smcx_host.h)"""
+    _fields_ = [("nrep", C.c_int), ("N", C.c_int), ("Ncz", C.c_int),
+                ("E", C.c_double), ("dE", C.c_double), ("acceptance_ratio", C.c_double),
+                ("therm_acceptance", C.c_double),
+                ("rep_E", _dp), ("rep_dE", _dp), ("rep_acceptance", _dp), ("zprofile", _dp), ("Rfinal", _dp),
+                ("l1", C.c_double), ("l2", C.c_double * 16), ("l3", C.c_double * 16), ("lca_analyses", C.c_int),
+                ("P", C.c_double), ("dP", C.c_double), ("tau", C.c_double), ("cv", C.c_double),
+                ("kernel_ms", C.c_double), ("pair_evals_per_s", C.c_double)]
+
+
 def _host():
     global _HOST
     if _HOST is None:
@@ -378,6 +389,9 @@ def _host():
         H.smcx_host_box_for_N.restype = None
         H.smcx_host_write_csv.argtypes = [C.c_void_p, C.POINTER(Params), C.c_int, C.c_int, C.c_char_p]
         H.smcx_host_read_last_state.argtypes = [C.c_char_p, C.c_int, _dp]
+        H.smcx_host_sMC.argtypes = [C.POINTER(Params), _dp, _dp, C.c_int, C.c_int, C.c_int, C.POINTER(HostSim)]
+        H.smcx_host_sim_free.argtypes = [C.POINTER(HostSim)]
+        H.smcx_host_sim_free.restype = None
         _HOST = H
     return _HOST
 
@@ -409,6 +423,27 @@ def write_csv(engine, maxsteps, gather_lapse, directory):
                                      directory.encode())
     if rc != OK:
         raise SmcxError(rc, "smcx_host_write_csv")
+
+
+def host_sMC(p, W, R0, maxsteps, gather_lapse, eqsteps):
+    """smcx_host_sMC (the C driver mirroring sMC, SMC.c:21-267) -> dict of its results"""
+    sim = HostSim()
+    W = np.ascontiguousarray(W, dtype=np.float64)
+    R0 = np.ascontiguousarray(R0, dtype=np.float64)
+    rc = _host().smcx_host_sMC(C.byref(p), _p(W, C.c_double), _p(R0, C.c_double), maxsteps, gather_lapse,
+                               eqsteps, C.byref(sim))
+    if rc != OK:
+        raise SmcxError(rc, "smcx_host_sMC")
+    n = sim.nrep
+    out = {k: getattr(sim, k) for k in ("E", "dE", "acceptance_ratio", "therm_acceptance", "l1", "lca_analyses",
+                                        "P", "dP", "tau", "cv", "kernel_ms", "pair_evals_per_s")}
+    out["l2"] = np.array(sim.l2[:]); out["l3"] = np.array(sim.l3[:])
+    out["rep_E"] = np.ctypeslib.as_array(sim.rep_E, (n,)).copy()
+    out["rep_acceptance"] = np.ctypeslib.as_array(sim.rep_acceptance, (n,)).copy()
+    out["zprofile"] = np.ctypeslib.as_array(sim.zprofile, (sim.Ncz,)).copy()
+    out["Rfinal"] = np.ctypeslib.as_array(sim.Rfinal, (n, 3 * sim.N)).copy()
+    _host().smcx_host_sim_free(C.byref(sim))
+    return out
 
 
 def read_last_state(path, N):

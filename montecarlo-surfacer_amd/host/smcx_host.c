@@ -198,6 +198,37 @@ int smcx_host_sMC(const smcx_params *p, const double *W, const double *R0, int m
             free(c);
             if (rc != SMCX_OK) break;
         }
+        if (p->flags & SMCX_FLAG_PRESSURE) { /* SMC.c:207-208, 246-247 with the reference's indexing */
+            const int gather_steps = maxsteps / gather_lapse;
+            int ng = 0;
+            double *Ps = (double *)calloc((size_t)nrep * (gather_steps + 1), sizeof(double));
+            if (!Ps) { rc = SMCX_ERR_NOMEM; break; }
+            rc = smcx_pressure_series(h, Ps, &ng);
+            if (rc == SMCX_OK && gather_steps > 0) {
+                const double rho = N / (p->L * p->L * p->Lz);
+                for (int r = 0; r < nrep; r++) {
+                    double sum = 0, sum2 = 0;
+                    for (int k = 0; k < gather_steps; k++) { /* P[0] = 0, P[k] = k-th gather */
+                        const double v = (k >= 1 && k - 1 < ng ? Ps[(size_t)r * ng + (k - 1)] : 0.0) + rho * p->T;
+                        sum += v; sum2 += v * v;
+                    }
+                    const double mean = sum / gather_steps, var = sum2 / gather_steps - mean * mean;
+                    out->P += mean / nrep;
+                    out->dP += sqrt(var > 0 ? var : 0) / nrep;
+                }
+            }
+            free(Ps);
+            if (rc != SMCX_OK) break;
+        }
+        if (p->flags & SMCX_FLAG_SERIES) { /* SMC.c:234-235, 249-250 */
+            double *tc = (double *)calloc(2 * (size_t)nrep, sizeof(double));
+            int keff = 0;
+            if (!tc) { rc = SMCX_ERR_NOMEM; break; }
+            rc = smcx_acf(h, 2500000 /* KMAX, SMC.h:61 */, NULL, &keff, tc, tc + nrep);
+            for (int r = 0; rc == SMCX_OK && r < nrep; r++) { out->tau += tc[r] / nrep; out->cv += tc[nrep + r] / nrep; }
+            free(tc);
+            if (rc != SMCX_OK) break;
+        }
         int launches = 0;
         smcx_last_kernel_ms(h, &out->kernel_ms, &launches);
         if (out->kernel_ms > 0)

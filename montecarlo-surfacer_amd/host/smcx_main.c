@@ -34,7 +34,8 @@ int main(int argc, char **argv)
     smcx_host_box_for_N(N, &p.L, &p.Lz);
     p.T = T;
     p.A = 1.0 * T; /* gamma = 1, main.c:48-51 */
-    p.flags |= SMCX_FLAG_CLUSTERS; /* sMC always runs the cluster analysis (SMC.c:143-155) */
+    /* sMC always evaluates the pressure, the energy autocorrelation and the cluster analysis (SMC.c:140-155, 234) */
+    p.flags |= SMCX_FLAG_CLUSTERS | SMCX_FLAG_PRESSURE | SMCX_FLAG_SERIES;
 
     double W[2 * 3 * 3];
     smcx_host_initialize_walls(1.6, 0.0, 3.0, 0.5, p.M, 0.0, W); /* main.c:74-87 */
@@ -64,6 +65,8 @@ int main(int argc, char **argv)
     }
     printf("\n###  Final results  ###");
     printf("\nMean energy: %f +- %f", sim.E, sim.dE);
+    printf("\nMean pressure: %f +- %f", sim.P, sim.dP);                       /* main.c:128-131 style */
+    printf("\nAverage autocorrelation time: %f, cv: %f", sim.tau, sim.cv);
     printf("\nAverage acceptance ratio: %f (thermalisation %f)", sim.acceptance_ratio, sim.therm_acceptance);
     printf("\nDevice time %0.1f ms, %0.3e pair-evals/s", sim.kernel_ms, sim.pair_evals_per_s);
     if (sim.lca_analyses > 0) { /* SMC.c:227-231 */

@@ -417,6 +417,36 @@ def test_full_density_mobility_and_pressure(S, O):
     eng.close()
 
 
+def test_host_sMC_driver(S, O):
+    """8f.1: smcx_host_sMC, the C driver standing for sMC (SMC.c:21-267): ensemble results against
+    the oracle chain of every replica -- energy, acceptance, pressure with the reference's P[] indexing
+    (SMC.c:138-140, 207-208, 246-247), tau and cv (SMC.c:234-235, 249-250), cluster counts per analysis"""
+    L = 8.0
+    R0 = film_state(O, 4, 4, L, 0.05, 5)
+    nrep, maxsteps, gl, eq = 3, 8, 2, 1
+    flags = S.FLAGS_REFERENCE | S.FLAG_SERIES | S.FLAG_PRESSURE | S.FLAG_CLUSTERS
+    p = S.default_params(256, nrep, L=L, flags=flags, lca_time=2)
+    sim = S.host_sMC(p, O.W_FIXTURE, R0, maxsteps, gl, eq)
+    s = sys_of(O, p)
+    rho = 256 / (L * L * 240.0)
+    E, acc, Pm, dP, tau, cv, l1 = [], [], [], [], [], [], []
+    for r in range(nrep):
+        ref = O.chain(s, 12345 + r, R0, O.W_FIXTURE, T, A, eq, maxsteps, gl, pressure=True, lca_time=2)
+        E.append(ref["meanE"]); acc.append(ref["acceptance_ratio"])
+        gs = maxsteps // gl
+        Pk = np.array([rho * T] + [ref["P"][k - 1] + rho * T for k in range(1, gs)])
+        Pm.append(Pk.mean()); dP.append(np.sqrt(Pk.var()))
+        a = O.fft_acf(ref["E"] + 3 * 256 * T / 2, 2500000)
+        tau.append(a.sum()); cv.append(np.var(ref["E"]) / T ** 2)
+        l1.append(ref["lca"]["n1"] / ref["lca"]["analyses"])
+        assert rel(sim["rep_E"][r], ref["meanE"]) < 1e-9 and rel(sim["rep_acceptance"][r], ref["acceptance_ratio"]) < 1e-12
+        assert np.abs(sim["Rfinal"][r] - ref["R"]).max() < 1e-8
+    assert rel(sim["E"], np.mean(E)) < 1e-9 and rel(sim["acceptance_ratio"], np.mean(acc)) < 1e-12
+    assert rel(sim["P"], np.mean(Pm)) < 1e-9 and rel(sim["dP"], np.mean(dP), scale=1e-12) < 1e-6
+    assert rel(sim["tau"], np.mean(tau)) < 1e-6 and rel(sim["cv"], np.mean(cv)) < 1e-6
+    assert sim["lca_analyses"] == 2 and rel(sim["l1"], np.mean(l1)) < 1e-12 and abs(sim["l2"].sum() - sim["l1"]) < 1e-9
+
+
 def test_csv_outputs_and_restart(S, O, tmp_path):
     """8f.1: data_/local_/last_state_ files in the reference's formats (SMC.c:75-82, 214-225;
     main.c:162-170), and a restart from last_state (main.c:98-108)"""
