@@ -212,6 +212,25 @@ def main():
             "observables": {"mean_acceptance": summ["mean_acceptance"], "mean_energy": summ["mean_of_meanE"],
                             "replicas_gathered": int(len(obs["accepted"]))},
         }
+        out["precision"] = ("every energy, force, acceptance test and position is fp64; the int16 (x,y) and "
+                            "fp16/fp32 (z) copies only pre-select pairs with a conservative, proven threshold "
+                            "(DESIGN 4.1b); every pair inside the cutoff is evaluated in fp64")
+        if world == 1 and kform == 2:
+            # for reference, outside the timed region: the same workload through the all-fp64 sweep kernels
+            try:
+                eng.close()
+                p64 = S.default_params(N, nrep, device=local_rank, first_replica=first, tune_kernel=1)
+                with S.Engine(p64) as e64:
+                    e64.upload(S.fcc_init(*lattice), S.W_REFERENCE)
+                    e64.run(0, 1, gather_lapse)
+                    nk = min(a.steps, 5)
+                    e64.run(0, nk, gather_lapse)
+                    ms64, l64 = e64.last_kernel_ms()
+                    out["fp64_only_kernels"] = {"kernel": e64.kernel_form[1], "sweeps": nk, "ms_per_sweep": ms64 / nk,
+                                                "value": nrep * nk * 2.0 * N * (N - 1.0) / (ms64 * 1e-3),
+                                                "unit": "pair-evals/s (sweep kernels only)"}
+            except Exception as e:
+                out["fp64_only_kernels"] = {"value": None, "note": "failed: %r" % (e,)}
         if world == 1 and not a.no_cpu:
             try:
                 out["cpu_baseline"] = cpu_baseline(N, *lattice)
