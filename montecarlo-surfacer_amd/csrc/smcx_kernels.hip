@@ -5,9 +5,15 @@
 //                         oneParticleMoves call consumes (SMC.c:284, 290, 335), turned
 //                         into the 3N Box-Muller displacements (matematicose.c:183-193),
 //                         the visiting offset and the N acceptance uniforms
-//   sweep_kernel<S,WPR>   the hot path: the trial moves of SMC.c:292-348 for K sweeps,
-//                         positions resident in registers, Metropolis step, incremental
-//                         energy (SMC.c:340-341), histogram (SMC.c:912-927)
+//   sweep_kernel<S,WPR>   the hot path, all-fp64 form: the trial moves of SMC.c:292-348 for K
+//   sweep_kernel_lead     sweeps, positions resident in registers as fp64, Metropolis step,
+//                         incremental energy (SMC.c:340-341); _lead: sequential part of a move
+//                         on one wavefront only.  The default form is the screened kernel of
+//                         smcx_sweep_mx.hip; these run for fewer than 16 particles per lane
+//                         and when smcx_params.tune_kernel asks for them
+//   finalize_kernel       chain bookkeeping of sMC (SMC.c:194-195, 210-211, 244-250)
+//   hist_kernel           localDensityAndMobility (SMC.c:912-927)
+//   pressure_kernel       pressure + wallsPressure of a gather (SMC.c:696-720, 862-895)
 //   total_energy_kernel   energy + wallsEnergy (SMC.c:626-646, 822-859)
 //   eval_moves_kernel     teacher-forced Um,Fm,Un,Fn for one particle per replica
 #include "smcx_device.hpp"
