@@ -87,7 +87,8 @@ def main():
     ap.add_argument("--N", type=int, default=4096, choices=[256, 1024, 4096, 16384])
     ap.add_argument("--slots", type=int, default=0)
     ap.add_argument("--waves", type=int, default=0)
-    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-cpu", action="store_true",
+                    help="skip the reference legs after the timed region (cpu_baseline, all-fp64 kernels): profiling runs")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -215,7 +216,7 @@ def main():
         out["precision"] = ("every energy, force, acceptance test and position is fp64; the int16 (x,y) and "
                             "fp16/fp32 (z) copies only pre-select pairs with a conservative, proven threshold "
                             "(DESIGN 4.1b); every pair inside the cutoff is evaluated in fp64")
-        if world == 1 and kform == 2:
+        if world == 1 and kform == 2 and not a.no_cpu:
             # for reference, outside the timed region: the same workload through the all-fp64 sweep kernels
             try:
                 eng.close()
