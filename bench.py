@@ -91,19 +91,25 @@ def main():
                     help="skip the reference legs after the timed region (cpu_baseline, all-fp64 kernels): profiling runs")
     a = ap.parse_args()
 
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("smcx_dist", os.path.join(ROOT, "montecarlo-surfacer_amd", "dist.py"))
+    D = importlib.util.module_from_spec(spec); spec.loader.exec_module(D)
+
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        # plain `python bench.py --gpus N`: become the launcher.  N fresh ranks (one per GPU) are
+        # started before anything in this process touches the GPU; rank 0 prints the JSON line.
+        sys.exit(D.spawn_ranks(os.path.abspath(__file__), sys.argv[1:], a.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != a.gpus and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
+    if world != a.gpus:   # never run a different rank count than asked for and label it --gpus
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d; launch one rank per GPU "
+                         "(python bench.py --gpus N does it by itself)" % (a.gpus, world))
 
     import numpy as np
     import torch
     import smcx_loader
     S = smcx_loader.load()   # raises if libsmcx.so is missing: no fallback
-    import importlib.util
-    spec = importlib.util.spec_from_file_location("smcx_dist", os.path.join(ROOT, "montecarlo-surfacer_amd", "dist.py"))
-    D = importlib.util.module_from_spec(spec); spec.loader.exec_module(D)
 
     # rehearsal knobs (one-GPU box): SMCX_DIST_BACKEND=gloo, SMCX_FORCE_DEVICE=0
     backend = os.environ.get("SMCX_DIST_BACKEND", "nccl")

@@ -241,6 +241,9 @@ extern "C" int smcx_destroy(smcx_handle *hh)
     hipFree(c.jjseries); hipFree(c.rec); hipFree(h.d_save); hipFree(h.d_tmp);
     hipFree(c.D); hipFree(c.Mu); hipFree(c.Rbin); hipFree(c.Pseries);
     hipFree(h.lca_bits); hipFree(h.lca_counts);
+#ifdef SMCX_CHECK
+    hipFree(c.dbg);
+#endif
     for (hipEvent_t e : h.evs) hipEventDestroy(e);
     if (h.ev0) hipEventDestroy(h.ev0);
     if (h.ev1) hipEventDestroy(h.ev1);
@@ -307,6 +310,10 @@ extern "C" int smcx_create(const smcx_params *p, smcx_handle **out)
         CRT(hipMalloc(&c.Mu, nrep * Nc * sizeof(unsigned long long)));
         CRT(hipMalloc(&c.Rbin, nrep * N * sizeof(int)));
     }
+#ifdef SMCX_CHECK
+    CRT(hipMalloc(&c.dbg, 4 * sizeof(unsigned long long)));
+    CRT(hipMemset(c.dbg, 0, 4 * sizeof(unsigned long long)));
+#endif
     CRT(hipMemset(c.obs, 0, nrep * sizeof(ObsRec)));
     CRT(hipMemset(c.zhist, 0, nrep * p->Ncz * sizeof(unsigned long long)));
     CRT(hipMemset((void *)c.W, 0, (size_t)(2 * c.M2 > 2 ? 2 * c.M2 : 2) * sizeof(double)));
@@ -653,6 +660,20 @@ extern "C" int smcx_series(smcx_handle *hh, double *E_series, int32_t *jj)
                                (size_t)ms * sizeof(int), h.p.nrep, hipMemcpyDeviceToHost));
     return SMCX_OK;
 }
+
+#ifdef SMCX_CHECK
+// diagnostic build only (libsmcx_check.so): what the fp64 test run beside the screen counted since
+// smcx_create -- pairs inside the cutoff, candidates the screen flagged, pairs inside the cutoff
+// that it did NOT flag (must stay 0)
+extern "C" int smcx_debug_check_counts(smcx_handle *hh, uint64_t *out /*[3]*/)
+{
+    if (!hh || !out) return SMCX_ERR_PARAM;
+    Handle &h = hh->h;
+    HIPCHK(&h, hipSetDevice(h.p.device));
+    HIPCHK(&h, hipMemcpy(out, h.c.dbg, 3 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    return SMCX_OK;
+}
+#endif
 
 // for smcx_acf.hip: where the energy series of the last run lives
 #ifdef SMCX_STAMPS

@@ -22,6 +22,9 @@ namespace smcx {
 
 constexpr double FAR_PAD = 1.0e150;    // z of padding particles (never inside any cutoff)
 constexpr double FAR_PROBE = -1.0e150; // z of a disabled probe
+// log-uniform stored for rand() == 0 (SMC.c:335 tests u < exp(-x/T)): exp(-y) > 0 exactly for
+// y < 1075 ln 2 = 745.1332191019412, so "log u < -x/T" with this value accepts the same moves
+constexpr double LOG_U_ZERO = -745.1332191019412;
 
 struct ObsRec {                   // per-replica accumulators, 64 B
     double accepted;              // production accepted moves (exact in fp64 up to 2^53)
@@ -68,6 +71,9 @@ struct DevCtx {
     int *Rbin;                    // [nrep][N] cell of each particle at the previous gather
     double *Pseries;              // [nrep][pstride] pressure + wallsPressure per gather (SMC.c:140)
     int pstride;
+#ifdef SMCX_CHECK
+    unsigned long long *dbg;      // [4] diagnostic build only (see SweepArgs)
+#endif
 };
 
 // cluster analysis (smcx_lca.hip): per-replica counters n1, h2[16], h3[16], dropped stores
@@ -93,6 +99,9 @@ struct SweepArgs {
     const ObsRec *obs;       // [nrep] (Ecur at entry)
     SweepRec *rec;           // [nrep][chunk]
     double edge;             // L/2 - cutoff: probes with |x|,|y| <= edge need no minimum image
+#ifdef SMCX_CHECK
+    unsigned long long *dbg; // diagnostic build: pairs inside the cutoff, candidates, misses of the screen
+#endif
 };
 
 // ---- cross-lane helpers ------------------------------------------------------

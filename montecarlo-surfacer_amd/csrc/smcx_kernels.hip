@@ -65,9 +65,13 @@ rng_prepass_kernel(DevCtx c, int nsweeps, double A)
         }
         // acceptance uniforms u = rand()/RAND_MAX (SMC.c:335), stored as log(u): the test
         // u < exp(-x/T) of SMC.c:329-335 is evaluated as log(u) < -x/T, which keeps the
-        // exponential out of the sequential part of every move (u = 0 -> -inf: always accepted)
-        for (int i = tid; i < N; i += 256)
-            uni[i] = log((double)raw[3 * N + 1 + i] / 2147483647.0);
+        // exponential out of the sequential part of every move.  rand() == 0: the reference tests
+        // 0 < exp(-x/T), true until exp underflows to zero at x/T >= 1075 ln 2; log(0) = -inf would
+        // accept every finite x, so u = 0 is stored as that edge (LOG_U_ZERO)
+        for (int i = tid; i < N; i += 256) {
+            const uint32_t r = raw[3 * N + 1 + i];
+            uni[i] = r ? log((double)r / 2147483647.0) : LOG_U_ZERO;
+        }
         if (tid == 0) // SMC.c:290-294: the sweep starts at particle offset % N
             c.offs[(size_t)rep * c.chunk + s] = (int)(raw[3 * N] % (uint32_t)N);
         __syncthreads();
@@ -790,6 +794,9 @@ hipError_t launch_sweeps(const DevCtx &c, int S, int WPR, int nsweeps, double A,
     a.L = c.L; a.invL = c.invL; a.cutoff2 = c.cutoff2; a.invT = c.invT;
     a.R = c.R; a.displ = c.displ; a.uni = c.uni; a.offs = c.offs; a.obs = c.obs; a.rec = c.rec;
     a.edge = c.L / 2 - sqrt(c.cutoff2); // |x|,|y| up to here: no pair needs the periodic image
+#ifdef SMCX_CHECK
+    a.dbg = c.dbg;
+#endif
     if (use_mx) return launch_sweeps_mx(a, c, S, WPR, nsweeps, A, st);
     hipLaunchKernelGGL(f, dim3(c.nrep), dim3(64 * WPR), 0, st, a, c, nsweeps, A);
     return hipGetLastError();

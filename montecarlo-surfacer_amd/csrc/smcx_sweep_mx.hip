@@ -49,6 +49,7 @@ struct MxArgs {
 };
 
 typedef short mx_s2 __attribute__((ext_vector_type(2)));
+typedef unsigned short mx_u2 __attribute__((ext_vector_type(2)));
 typedef _Float16 mx_h2 __attribute__((ext_vector_type(2)));
 
 // x,y -> two int16 in one register (x low, y high); x = +L/2 wraps onto -L/2, the same point
@@ -127,7 +128,9 @@ __device__ __forceinline__ void mx_flag4(int k0, const float (&qa)[4], const flo
 // u2 * (dxi^2 + dyi^2) - thr of one particle and one probe
 __device__ __forceinline__ float mx_qxy(unsigned pxy, unsigned xy, float u2, float thr)
 {
-    const mx_s2 d = __builtin_bit_cast(mx_s2, pxy) - __builtin_bit_cast(mx_s2, xy); // wraps: minimum image
+    // the difference must wrap modulo 2^16 (that is the minimum image): unsigned lanes, where
+    // wrapping is defined, read back as signed
+    const mx_s2 d = __builtin_bit_cast(mx_s2, __builtin_bit_cast(mx_u2, pxy) - __builtin_bit_cast(mx_u2, xy));
     return __builtin_fmaf(u2, (float)__builtin_amdgcn_sdot2(d, d, 0, true), -thr);
 }
 
@@ -298,6 +301,9 @@ sweep_kernel_mx(SweepArgs a, DevCtx c, int nsweeps, double A, MxArgs m)
     long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     long long tlast = __builtin_amdgcn_s_memtime();
 #endif
+#ifdef SMCX_CHECK // diagnostic build only (libsmcx_check.so): the fp64 test beside the screen, every slot
+    unsigned long long chk_in = 0, chk_cand = 0, chk_miss = 0;
+#endif
     const double AoT = A * a.invT;         // SMC.c:307-309 (A/T)
     const double Ao4T = A * 0.25 * a.invT; // SMC.c:327 (A/(4T))
 
@@ -397,6 +403,33 @@ sweep_kernel_mx(SweepArgs a, DevCtx c, int nsweeps, double A, MxArgs m)
                     if (exB1) cb[0] &= ~2u;
                 }
                 STAMP(1); // screening
+#ifdef SMCX_CHECK
+                {   // every slot of this lane against both probes in fp64 (pair_hit's arithmetic, positions from
+                    // memory): a pair inside the cutoff that the screen did not flag is a miss
+                    unsigned long long fa = ca[0], fb = cb[0];
+                    if constexpr (NW > 1) { fa |= (unsigned long long)ca[1] << 32; fb |= (unsigned long long)cb[1] << 32; }
+                    chk_cand += __builtin_popcountll(fa) + __builtin_popcountll(fb);
+                    const bool exA0 = (tid == tl);
+                    const bool exB0 = (hasA && tid == tl) || (hasB && !cross && tid == tl + 1);
+                    const bool exB1 = cross && (tid == 0);
+#pragma unroll 1
+                    for (int k = 0; k < S; k++) {
+                        double X, Y, Z;
+                        mx_fetch<S, T, true>(Rg, N, tid, rot, k, X, Y, Z);
+                        for (int pr = 0; pr < 2; pr++) {
+                            if (pr == 0 ? !hasA : !hasB) continue;
+                            if (pr == 0 ? (k == 0 && exA0) : ((k == 0 && exB0) || (k == 1 && exB1))) continue;
+                            const double dx = (pr ? Bx : Qx) - X, dy = (pr ? By : Qy) - Y, dz = (pr ? Bz : Qz) - Z;
+                            const double sx = dx - g.L * __builtin_rint(dx * g.invL);
+                            const double sy = dy - g.L * __builtin_rint(dy * g.invL);
+                            if (sx * sx + sy * sy + dz * dz < g.cutoff2) {
+                                chk_in++;
+                                if (!(((pr ? fb : fa) >> k) & 1ull)) chk_miss++;
+                            }
+                        }
+                    }
+                }
+#endif
 
                 // ---- exact evaluation of the candidates ------------------------------------
                 // every lane fetches its candidates' fp64 positions (one of each probe per round)
@@ -473,6 +506,9 @@ sweep_kernel_mx(SweepArgs a, DevCtx c, int nsweeps, double A, MxArgs m)
             a.rec[(size_t)rep * a.chunk + sw] = r;
         }
     }
+#ifdef SMCX_CHECK
+    atomicAdd(&a.dbg[0], chk_in); atomicAdd(&a.dbg[1], chk_cand); atomicAdd(&a.dbg[2], chk_miss);
+#endif
 #ifdef SMCX_STAMPS
     if (tid == 0) { // diagnostic: overwrite the head of this replica's (consumed) displacement block
         double *dbg = const_cast<double *>(a.displ) + (size_t)rep * a.chunk * 3 * N;
@@ -526,6 +562,7 @@ bool mx_lds_z(int S, int WPR, double Lz)
     static const char *env_mz = getenv("SMCX_MZ");
     bool mz = (S == 64 && WPR == 1 && Lz <= 480.0);
     if (env_mz) mz = (env_mz[0] != '0');
+    if (Lz > 32768.0) mz = false; // zsafe (the power of two above Lz/2) must stay a finite fp16
     return mz && lookup_mz(S, WPR) != nullptr;
 }
 

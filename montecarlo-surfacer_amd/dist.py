@@ -71,3 +71,54 @@ def gather_observables(local_packed, nrep_local, Ncz, group=None):
     parts = [unpack(b[:c * width].cpu().numpy(), c, Ncz) for b, c in zip(bufs, counts)]
     out = {k: np.concatenate([p[k] for p in parts], axis=0) for k in parts[0]}
     return out
+
+
+def spawn_ranks(script, argv, n, extra_env=None, timeout=None):
+    """Start `n` ranks of `script` (one process per GPU: RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* set,
+    rendezvous on 127.0.0.1) as FRESH child processes and wait for them.  The caller must not have
+    touched the GPU: a rank initialises its device itself.  Rank 0's stdout is passed through;
+    if any rank fails the others are stopped (by PID) and the first non-zero code is returned."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    import time
+    if n < 1:
+        raise ValueError("need at least one rank")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if extra_env:
+            env.update(extra_env)
+        procs.append(subprocess.Popen([sys.executable, script] + list(argv), env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    t0 = time.time()
+    rc = 0
+    live = list(procs)
+    while live:
+        for p in list(live):
+            code = p.poll()
+            if code is None:
+                continue
+            live.remove(p)
+            if code != 0 and rc == 0:
+                rc = code
+        if rc != 0 or (timeout and time.time() - t0 > timeout):
+            for p in live:   # a rank died or the run overran: stop the rest, they would wait for it forever
+                p.terminate()
+            for p in live:
+                try:
+                    p.wait(20)
+                except subprocess.TimeoutExpired:
+                    p.kill()
+            if rc == 0:
+                rc = 124
+            break
+        time.sleep(0.05)
+    return rc

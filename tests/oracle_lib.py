@@ -159,6 +159,16 @@ class Rng:
         self.g = OrcRng()
         lib().orc_srand(C.byref(self.g), seed)
 
+    @classmethod
+    def from_state(cls, st):
+        """from the engine's exported layout (smcx_rng_export: 31 words oldest first, 0 pending)"""
+        assert int(st[31]) == 0
+        r = cls(1)
+        for i in range(31):
+            r.g.s[i] = int(st[i])
+        r.g.f, r.g.r = 0, 28   # glibc keeps the front pointer three words ahead of the rear one
+        return r
+
     def rand(self):
         return lib().orc_rand(C.byref(self.g))
 

@@ -139,6 +139,38 @@ def test_screen_never_misses_a_pair_inside_the_cutoff(S, L, Lz, lds_z):
         assert not (cand & inner & (d2 > p.cutoff ** 2 + 2.2 * (thr - p.cutoff ** 2) + 0.01)).any()
 
 
+def test_host_c_system_preparation_matches_reference_fixtures(S, O):
+    """host/smcx_host.c against the reference's own outputs and the oracle:
+    initializeWalls (SMC.c:475-501) gives the 18-value wall fixture the real reference printed, bit
+    for bit; the lattices of initializeBox (SMC.c:413-465) and fcc(Na,Nz) equal the oracle's; the
+    sizes the reference's rule cannot place (1024: 16 particles, 4096: 96, 8192: 128 left at the
+    origin, SMC.c:416-431) are reported as such."""
+    W = S.initialize_walls()                                   # M=3, (1.6, 0.0, 3.0, 0.5), uninit = 0.0
+    assert np.array_equal(W, O.W_FIXTURE) and np.array_equal(S.W_REFERENCE, O.W_FIXTURE)
+    assert np.array_equal(W, O.walls())
+    # the ninth site reads uninitialised memory in the reference (SMC.c:481-485): the stand-in value is explicit
+    W7 = S.initialize_walls(uninit=0.25)
+    assert np.array_equal(W7[:16], W[:16]) and not np.array_equal(W7[16:], W[16:])
+    assert np.array_equal(W7, O.walls(uninit=0.25))
+    W2 = S.initialize_walls(M=2)                               # even M*M: every site written
+    assert W2.shape == (8,) and np.array_equal(W2, O.walls(M=2)) and np.all(W2 > 0)
+    for Na, Nz in ((4, 4), (8, 4), (8, 16), (16, 4), (16, 16), (3, 3)):
+        assert np.array_equal(S.fcc_init(Na, Nz), O.fcc(Na, Nz)), (Na, Nz)
+    assert np.array_equal(S.fcc_init(4, 4, L=20.0, Lz=120.0), O.fcc(4, 4, L=20.0, Lz=120.0))
+    for N, L, Lz, unplaced in ((32, 20.0, 120.0, 0), (108, 33.0, 200.0, 0), (256, 33.0, 240.0, 0), (500, 33.0, 240.0, 0),
+                               (864, 33.0, 240.0, 0), (2048, 33.0, 240.0, 0), (4000, 33.0, 240.0, 0),
+                               (16384, 33.0, 240.0, 0), (1024, 33.0, 240.0, 16), (4096, 33.0, 240.0, 96),
+                               (8192, 33.0, 240.0, 128)):
+        X, placed = S.initialize_box(N, L, Lz)
+        Xo, placed_o = O.box_ref(N, L, Lz)
+        assert placed == placed_o == N - unplaced, (N, placed, placed_o)
+        assert np.array_equal(X, Xo), N
+        assert np.abs(X[0::3]).max() <= L / 2 and np.abs(X[2::3]).max() <= 0.95 * Lz / 2 + 1e-12
+    # N=256 with the reference's rule is the fcc(4,4) start of the benchmark configs
+    assert np.array_equal(S.initialize_box(256, 33.0, 240.0)[0], S.fcc_init(4, 4))
+    assert np.array_equal(S.initialize_box(16384, 33.0, 240.0)[0], S.fcc_init(16, 16))
+
+
 def test_srand_state_agrees_with_oracle_rand(S, O):
     """smcx_rng_seed = srand(): continuing r[i] = r[i-31] + r[i-3] from the exported
     state must give rand()'s outputs."""
@@ -220,14 +252,34 @@ print("rank", rank, "ok")
 
 
 def test_two_rank_gloo_gather(tmp_path):
-    """the N>1 path on CPU: replica sharding + the final observable gather, world_size 2"""
+    """the N>1 path on CPU: the rank launcher bench.py uses for `--gpus N` (dist.spawn_ranks: fresh
+    processes, RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* set), replica sharding and the final observable
+    gather, world_size 2 over gloo"""
+    sys.path.insert(0, os.path.join(ROOT, "montecarlo-surfacer_amd"))
+    import importlib
+    D = importlib.import_module("dist")
     w = tmp_path / "worker.py"
     w.write_text(_GLOO_WORKER)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", WORLD_SIZE="2")
-    procs = [subprocess.Popen([sys.executable, str(w), os.path.join(ROOT, "montecarlo-surfacer_amd")],
-                              env=dict(env, RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.PIPE,
-                              text=True) for r in range(2)]
-    for p in procs:
-        out, err = p.communicate(timeout=240)
-        assert p.returncode == 0, err[-2000:]
-        assert "ok" in out
+    assert D.spawn_ranks(str(w), [os.path.join(ROOT, "montecarlo-surfacer_amd")], 2, timeout=240) == 0
+    # a failing rank takes the launch down with its exit code instead of leaving the others waiting
+    bad = tmp_path / "bad.py"
+    bad.write_text("import os, sys, time\nif os.environ['RANK'] == '1': sys.exit(7)\ntime.sleep(600)\n")
+    import time
+    t0 = time.time()
+    assert D.spawn_ranks(str(bad), [], 2, timeout=240) == 7 and time.time() - t0 < 60
+
+
+def test_bench_refuses_rank_count_mismatch():
+    """bench.py never runs a rank count other than --gpus: under a launcher that set WORLD_SIZE
+    differently it exits non-zero before touching the GPU (round 1 silently ran one rank)"""
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env,
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr and "metric" not in r.stdout
+    env.pop("WORLD_SIZE")
+    if __import__("smcx_loader").load().device_count() == 0:
+        # without WORLD_SIZE the script launches the ranks itself; with no GPU both fail loudly
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--N", "256",
+                            "--replicas", "2", "--steps", "1", "--warmup", "0", "--no-cpu"],
+                           env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode != 0 and "metric" not in r.stdout

@@ -1,0 +1,294 @@
+"""GPU tests (-m gpu) of the BASELINE.json configurations at their real sizes, of the screened
+kernel's no-miss property on the device, of ensemble statistics beyond the chaos horizon, and of
+the multi-rank launch path of bench.py.  Everything goes through the C ABI (libsmcx.so); the CPU
+oracle is the checker only.
+
+Tolerances: as in test_gpu_parity.py (fp64 everywhere; 1e-9 relative on energies of
+teacher-equivalent short chains, bit-equal accept counts); statistical comparisons state theirs.
+"""
+import importlib.util
+import json
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+T = A = 1.1
+
+
+def rel(a, b, scale=0.0):
+    return np.abs(np.asarray(a) - np.asarray(b)) / (np.abs(np.asarray(b)) + scale + 1e-300)
+
+
+def sys_of(O, p):
+    return O.make_sys(p.N, M=p.M, L=p.L, Lz=p.Lz, cutoff=p.cutoff, a0=p.a0, b0=p.b0, Ncx=p.Ncx, Ncz=p.Ncz)
+
+
+def oracle_chains(O, s, seeds, R0, eq, nsw, gl, workers=16):
+    """O.chain for many seeds on the host cores (ctypes releases the GIL)"""
+    with ThreadPoolExecutor(min(workers, len(os.sched_getaffinity(0)))) as ex:
+        return list(ex.map(lambda sd: O.chain(s, sd, R0, O.W_FIXTURE, T, A, eq, nsw, gl), seeds))
+
+
+# ------------------------------------------------------------------ BASELINE config 5: N = 16384
+@pytest.mark.parametrize("slots,waves,name", [
+    (64, 4, "smcx::sweep_kernel_mx<64, 4, 2, false>"),   # multi-wavefront tiling: 4 wavefronts x 64 particles per lane
+    (32, 8, "smcx::sweep_kernel_mx<32, 8, 3, false>"),   # what the geometry rule picks at 256 replicas per GPU
+])
+def test_config5_N16384_against_oracle(S, O, slots, waves, name):
+    """BASELINE configs[4]: N=16384 + wall, fcc(16,16) (the reference's own dense lattice),
+    several wavefronts per replica.  2 replicas x 2 sweeps against the oracle chain (SMC.c:278-351
+    with K1-K4 at that N): accept counts per sweep bit-equal, energies 1e-9, positions, z histogram."""
+    R0 = O.fcc(16, 16)
+    nsw, nrep = 2, 2
+    p = S.default_params(16384, nrep, flags=S.FLAGS_REFERENCE | S.FLAG_SERIES, tune_slots=slots, tune_waves=waves)
+    with S.Engine(p) as eng:
+        assert eng.kernel_form == (2, name), eng.kernel_form
+        eng.upload(R0, O.W_FIXTURE)
+        E0 = eng.total_energy()
+        eng.run(0, nsw, 1)
+        ob = eng.observables()
+        Es, jj = eng.series(nsw)
+        Rg = eng.positions()
+    s = sys_of(O, p)
+    refs = oracle_chains(O, s, [12345 + r for r in range(nrep)], R0, 0, nsw, 1)
+    assert rel(E0[0], -41824.76491, 0) < 1e-9          # E0 of the real reference at this lattice
+    for r, ref in enumerate(refs):
+        assert np.array_equal(jj[r], ref["jj"]), (jj[r], ref["jj"])
+        assert np.all(rel(Es[r], ref["E"], scale=1.0) < 1e-9), (Es[r], ref["E"])
+        assert rel(ob["meanE"][r], ref["meanE"]) < 1e-9
+        assert np.abs(Rg[r] - ref["R"]).max() < 1e-8
+        assert np.array_equal(ob["zhist"][r], ref["zhist"])
+
+
+def test_config5_N16384_x256_invariants(S, O):
+    """config 5 per GPU (2048 replicas / 8 GPUs = 256): the geometry rule's own choice, three sweeps:
+    incremental energy = recomputed energy, histograms conserve particles, replica 0 = the oracle's."""
+    R0 = O.fcc(16, 16)
+    nrep = 256
+    p = S.default_params(16384, nrep, flags=S.FLAG_WALLS)
+    with S.Engine(p) as eng:
+        form, name = eng.kernel_form
+        assert form == 2 and eng.geometry[0] * eng.geometry[1] * 64 == 16384, (name, eng.geometry)
+        eng.upload(R0, O.W_FIXTURE)
+        eng.run(1, 2, 1)
+        ob = eng.observables()
+        g, oob = eng.hist_info()
+        Erec = eng.total_energy()
+    assert np.all(rel(ob["E_last"], Erec) < 1e-9)
+    assert np.all(g == 2) and np.all(oob == 0) and np.all(ob["zhist"].sum(axis=1) == 2 * 16384)
+    assert len(np.unique(ob["accepted"])) > 8          # distinct seeds, distinct chains
+    ref = O.chain(sys_of(O, p), 12345, R0, O.W_FIXTURE, T, A, 1, 2, 1, e0_restart=False)
+    assert int(ob["accepted"][0]) == ref["accepted"] and rel(ob["E_last"][0], ref["Efinal"]) < 1e-9
+
+
+# ------------------------------------------------------------------ BASELINE config 2: N = 1024 x 1024
+def test_config2_N1024_x1024(S, O):
+    """BASELINE configs[1] at its real replica count: N=1024 + wall, 1024 replicas on one GPU.
+    Invariants over all replicas, and eight replicas spread over the ensemble against the oracle."""
+    R0 = O.fcc(8, 4)
+    nrep, nsw = 1024, 5
+    p = S.default_params(1024, nrep, flags=S.FLAG_WALLS | S.FLAG_SERIES)
+    with S.Engine(p) as eng:
+        form, name = eng.kernel_form
+        eng.upload(R0, O.W_FIXTURE)
+        eng.run(0, nsw, 1)
+        ob = eng.observables()
+        Es, jj = eng.series(nsw)
+        g, oob = eng.hist_info()
+        Erec = eng.total_energy()
+    assert form == 2, name
+    assert np.all(rel(ob["E_last"], Erec) < 1e-9)
+    assert np.all(g == nsw) and np.all(oob == 0) and np.all(ob["zhist"].sum(axis=1) == nsw * 1024)
+    pick = [0, 1, 127, 128, 511, 640, 1000, 1023]
+    refs = oracle_chains(O, sys_of(O, p), [12345 + r for r in pick], R0, 0, nsw, 1)
+    for r, ref in zip(pick, refs):
+        assert np.array_equal(jj[r], ref["jj"]), r
+        assert np.all(rel(Es[r], ref["E"], scale=1.0) < 1e-9), r
+        assert np.array_equal(ob["zhist"][r], ref["zhist"]), r
+
+
+# ------------------------------------------------------------------ the screen never drops a pair (device)
+def _ab_kernels(S, O, N, lat, nrep, nsw, mx_geom, fp_geom):
+    R0 = O.fcc(*lat)
+    out = []
+    for kernel, (slots, waves) in ((1, fp_geom), (2, mx_geom)):
+        p = S.default_params(N, nrep, tune_kernel=kernel, tune_slots=slots, tune_waves=waves,
+                             flags=S.FLAG_WALLS | S.FLAG_SERIES)
+        with S.Engine(p) as eng:
+            assert eng.kernel_form[0] == kernel
+            eng.upload(R0, O.W_FIXTURE)
+            eng.run(0, nsw, nsw)
+            E, jj = eng.series(nsw)
+            out.append((E.copy(), jj.copy()))
+    return out
+
+
+@pytest.mark.parametrize("N,lat,nrep,nsw,mx_geom,fp_geom", [
+    (4096, (8, 16), 256, 10, (64, 1), (16, 4)),     # the benchmark kernel, 1.0e7 moves
+    (16384, (16, 16), 32, 2, (64, 4), (32, 8)),     # config 5, dense: ~60 pairs inside the cutoff per probe
+])
+def test_screen_ab_against_fp64_kernel_at_scale(S, O, N, lat, nrep, nsw, mx_geom, fp_geom):
+    """screened kernel vs all-fp64 kernel from the same start and seeds.  The two sum in a different
+    order, so they agree to rounding until chaos amplifies 1e-16 into a flipped accept decision; a pair
+    dropped by the screen would instead shift E by >= 4|V(rc)| = 5e-3 at once.  Required: per replica
+    the accept counts are equal sweep by sweep up to a first difference, the energies before it agree
+    to 1e-8, and at most 2 % of the replicas have such a difference at all."""
+    (Ea, ja), (Eb, jb) = _ab_kernels(S, O, N, lat, nrep, nsw, mx_geom, fp_geom)
+    diverged = 0
+    for r in range(nrep):
+        d = np.nonzero(ja[r] != jb[r])[0]
+        upto = nsw if len(d) == 0 else int(d[0])
+        diverged += len(d) > 0
+        assert np.all(np.abs(Ea[r, :upto + 1] - Eb[r, :upto + 1]) <= 1e-8 * (1.0 + np.abs(Ea[r, :upto + 1]))), r
+    assert ja.sum() > 0 and diverged <= max(1, nrep // 50), diverged
+    if N == 4096:   # in practice none at all within ten sweeps
+        assert np.array_equal(ja[:, :5], jb[:, :5])
+
+
+def _load_check_build():
+    path = os.path.join(ROOT, "montecarlo-surfacer_amd", "libsmcx_check.so")
+    if not os.path.exists(path):
+        pytest.fail("libsmcx_check.so is not built (make -C montecarlo-surfacer_amd/csrc CHECK=1; build() does it)")
+    old = os.environ.get("SMCX_LIB")
+    os.environ["SMCX_LIB"] = path
+    try:
+        spec = importlib.util.spec_from_file_location(
+            "montecarlo_surfacer_amd_check", os.path.join(ROOT, "montecarlo-surfacer_amd", "__init__.py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        mod._lib()
+    finally:
+        if old is None:
+            del os.environ["SMCX_LIB"]
+        else:
+            os.environ["SMCX_LIB"] = old
+    return mod
+
+
+@pytest.mark.parametrize("N,lat,nrep,nsw,slots,waves", [
+    (4096, (8, 16), 4096, 2, 0, 0),      # THE bench workload: 4096 replicas, z as fp16 in LDS (3.4e7 moves)
+    (16384, (16, 16), 64, 1, 64, 4),     # config 5, fp32 z, dense
+    (1024, (8, 4), 1024, 4, 0, 0),       # config 2
+])
+def test_screen_miss_counter_is_zero(O, N, lat, nrep, nsw, slots, waves):
+    """diagnostic build (libsmcx_check.so = the product's sources with -DSMCX_CHECK): beside the screen
+    the kernel runs the fp64 cutoff test on EVERY slot and probe from the fp64 positions in memory and
+    counts the pairs inside the cutoff that the screen did not flag.  Must be zero; the counts of true
+    hits and of candidates show the check is not vacuous and how tight the screen is."""
+    import ctypes as C
+    K = _load_check_build()
+    p = K.default_params(N, nrep, tune_slots=slots, tune_waves=waves)
+    with K.Engine(p) as eng:
+        assert eng.kernel_form[0] == 2
+        eng.upload(K.fcc_init(*lat), K.W_REFERENCE)
+        eng.run(0, nsw, nsw)
+        cnt = (C.c_uint64 * 3)()
+        f = K._lib().smcx_debug_check_counts
+        f.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+        assert f(eng._h, cnt) == 0
+        acc = eng.observables()["accepted"].sum()
+    inside, cand, miss = int(cnt[0]), int(cnt[1]), int(cnt[2])
+    moves = nrep * nsw * N
+    print("N=%d: %d moves, %d pairs inside the cutoff, %d candidates (%.2fx), %d missed" %
+          (N, moves, inside, cand, cand / max(inside, 1), miss))
+    assert miss == 0
+    assert inside > moves and cand >= inside and acc > 0
+    assert cand < 3 * inside + 40 * moves      # and the screen still screens
+
+
+# ------------------------------------------------------------------ statistics beyond the chaos horizon
+@pytest.mark.parametrize("N,lat", [(256, (4, 4)), (1024, (8, 4))])
+def test_ensemble_statistics_beyond_chaos_horizon(S, O, N, lat):
+    """256 replicas, 20 thermalisation + 100 production sweeps, GPU vs oracle on the
+    same seeds.  Trajectories separate after 20-60 sweeps (chaos), so realised chains differ; the
+    ensemble mean energy, acceptance ratio and wall-normal profile must agree within 4 standard
+    errors of the difference (from the replica spread of both sides).  A bias from the log-space
+    acceptance test (SMC.c:329-335) or the reciprocal's last ulp would show here."""
+    nrep, eq, nsw, gl = 256, 20, 100, 10
+    R0 = O.fcc(*lat)
+    p = S.default_params(N, nrep)
+    with S.Engine(p) as eng:
+        eng.upload(R0, O.W_FIXTURE)
+        eng.run(eq, nsw, gl)
+        ob = eng.observables()
+        g, _ = eng.hist_info()
+    refs = oracle_chains(O, sys_of(O, p), [12345 + r for r in range(nrep)], R0, eq, nsw, gl)
+
+    def check(name, a, b):
+        a, b = np.asarray(a, float), np.asarray(b, float)
+        se = np.sqrt(a.var(ddof=1) / len(a) + b.var(ddof=1) / len(b))
+        assert abs(a.mean() - b.mean()) <= 4 * se + 1e-12 * abs(b.mean()), (name, a.mean(), b.mean(), se)
+        return abs(a.mean() - b.mean()) / (se + 1e-300)
+
+    zs = [check("meanE", ob["meanE"], [r["meanE"] for r in refs]),
+          check("acceptance", ob["acceptance_ratio"], [r["acceptance_ratio"] for r in refs])]
+    prof_g = ob["zhist"] / g[:, None].astype(float)
+    prof_c = np.array([r["zhist"] / float(r["gathers"]) for r in refs])
+    occupied = 0
+    for k in range(p.Ncz):
+        if prof_c[:, k].sum() + prof_g[:, k].sum() > 0:
+            zs.append(check("z bin %d" % k, prof_g[:, k], prof_c[:, k]))
+            occupied += 1
+    assert occupied >= 2 and np.all(g == nsw // gl)
+    # the chains really are beyond the horizon: most replicas ended on a different trajectory
+    differ = sum(int(ob["accepted"][r]) != refs[r]["accepted"] for r in range(nrep))
+    print("N=%d: %d of %d replicas on a different trajectory; max deviation %.2f standard errors" %
+          (N, differ, nrep, max(zs)))
+    assert differ > nrep // 4
+
+
+# ------------------------------------------------------------------ host side, as a process
+def test_smcx_main_as_child_process(O):
+    """host/smcx_main.c (the main.c:7-176 counterpart) run as its own process:
+    `smcx_main eqsteps maxsteps numdata T N nrep Na Nz` -- its printed ensemble energy, acceptance
+    ratio and z profile against the oracle chains of the same seeds"""
+    exe = os.path.join(ROOT, "montecarlo-surfacer_amd", "smcx_main")
+    r = subprocess.run([exe, "1", "8", "4", "1.1", "256", "3", "4", "4"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = r.stdout
+
+    def after(key):
+        return out.split(key, 1)[1].split("\n", 1)[0]
+    E = float(after("Mean energy: ").split()[0])
+    acc = float(after("Average acceptance ratio: ").split()[0])
+    therm = float(after("(thermalisation ").split(")")[0])
+    prof = np.array([float(v) for v in after("z profile (particles per cell per gather):").split()])
+    s = O.make_sys(256)
+    R0 = O.fcc(4, 4)
+    refs = [O.chain(s, 12345 + k, R0, O.W_FIXTURE, 1.1, 1.1, 1, 8, 2) for k in range(3)]
+    assert abs(E - np.mean([q["meanE"] for q in refs])) < 2e-6 * abs(E) + 1e-6      # printed with %f
+    assert abs(acc - np.mean([q["acceptance_ratio"] for q in refs])) < 1e-6
+    assert abs(therm - np.mean([q["therm_acceptance"] for q in refs])) < 1e-6
+    ref_prof = np.sum([q["zhist"] for q in refs], axis=0) / float(sum(q["gathers"] for q in refs))
+    assert prof.shape == (33,) and np.abs(prof - ref_prof).max() < 1e-3              # %0.3f
+    # argument errors are reported, not crashed on
+    bad = subprocess.run([exe, "1", "8"], capture_output=True, text=True, timeout=60)
+    assert bad.returncode == 2 and "usage" in bad.stderr
+    bad = subprocess.run([exe, "0", "4", "2", "1.1", "1024"], capture_output=True, text=True, timeout=60)
+    assert bad.returncode == 2 and "Can't make the reference's crystal" in bad.stderr  # SMC.c:428
+
+
+# ------------------------------------------------------------------ multi-rank launch path of bench.py
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` without a launcher starts two ranks itself.  Rehearsed on the one
+    GPU of this box: both ranks on device 0 (SMCX_FORCE_DEVICE), gloo instead of RCCL for the gather."""
+    env = dict(os.environ, SMCX_DIST_BACKEND="gloo", SMCX_FORCE_DEVICE="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--N", "1024",
+                        "--replicas", "64", "--steps", "3", "--warmup", "1", "--no-cpu"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(line) == 1                              # rank 0 alone prints
+    out = json.loads(line[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak"
+    assert out["observables"]["replicas_gathered"] == 128 and out["config"]["replicas_total"] == 128
+    assert out["value"] > 0 and out["roofline"]["frac"] > 0

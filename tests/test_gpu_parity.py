@@ -267,6 +267,41 @@ def test_explicit_seeds_and_per_replica_positions(S, O):
     eng.close()
 
 
+def test_zero_uniform_follows_exp_underflow(S, O):
+    """rand() == 0 as the acceptance uniform (SMC.c:335): the reference accepts while exp(-x/T) > 0
+    and rejects once it underflows to zero (x/T >= 1075 ln 2); the kernels compare log u < -x/T, so
+    u = 0 must be stored as that edge, not as log 0 = -inf.  Two particles at the Lennard-Jones
+    minimum, T = A = 1e-3, RNG states crafted so that both acceptance uniforms of the sweep (draws
+    7 and 8 of 4N+1 = 9) are exactly 0; the 256 replicas cover x/T above and just below the edge."""
+    nrep, N = 256, 2
+    R0 = np.array([0.0, 0.0, 0.0, 1.1225, 0.0, 0.0])
+    st = np.stack([S.rng_seed(1000 + r) for r in range(nrep)])
+    for r in range(nrep):   # new[i] = old[i] + old[i-3] + old[i-6] + old[i+22]: make new[7] = new[8] = 0
+        o = [int(v) for v in st[r, :31]]
+        st[r, 7] = (-(o[4] + o[1] + o[29])) & 0xFFFFFFFF
+        st[r, 8] = (-(o[5] + o[2] + o[30])) & 0xFFFFFFFF
+    p = S.default_params(N, nrep, T=1e-3, A=1e-3)
+    eng = S.Engine(p)
+    eng.upload(R0, O.W_FIXTURE)
+    eng.rng_import(st)
+    eng.run(0, 1, 1)
+    ob = eng.observables()
+    Rg = eng.positions()
+    eng.close()
+    s = sys_of(O, p)
+    E0 = O.total_energy(s, R0, O.W_FIXTURE)
+    kinds = {"underflow": 0, "tiny": 0, "plain": 0}
+    for r in range(nrep):
+        R = R0.copy()
+        acc, E1, tr = O.sweep(s, O.Rng.from_state(st[r]), R, O.W_FIXTURE, 1e-3, 1e-3, E=E0, trace=True)
+        assert np.all(tr["u"] == 0.0)
+        for m in tr:
+            kinds["underflow" if m["ap"] == 0.0 else "tiny" if m["ap"] < 1e-200 else "plain"] += 1
+        assert int(ob["accepted"][r]) == acc, (r, tr["ap"], tr["accepted"])
+        assert rel(ob["E_last"][r], E1, 1e-6) < 1e-9 and np.abs(Rg[r] - R).max() < 1e-9
+    assert kinds["underflow"] > 100 and kinds["tiny"] > 10 and kinds["plain"] > 50, kinds
+
+
 # ------------------------------------------------------------------ invariants at any size
 def test_determinism_sharding_and_resume(S, O):
     """bit-identical results for: a repeated run; a replica computed inside a different
