@@ -136,20 +136,20 @@ def _ab_kernels(S, O, N, lat, nrep, nsw, mx_geom, fp_geom):
 ])
 def test_screen_ab_against_fp64_kernel_at_scale(S, O, N, lat, nrep, nsw, mx_geom, fp_geom):
     """screened kernel vs all-fp64 kernel from the same start and seeds.  The two sum in a different
-    order, so they agree to rounding until chaos amplifies 1e-16 into a flipped accept decision; a pair
-    dropped by the screen would instead shift E by >= 4|V(rc)| = 5e-3 at once.  Required: per replica
-    the accept counts are equal sweep by sweep up to a first difference, the energies before it agree
-    to 1e-8, and at most 2 % of the replicas have such a difference at all."""
+    order, so they agree to rounding until chaos amplifies it: measured on MI355X at N=4096 the energy
+    difference grows about tenfold per sweep from 1e-14 relative (2e-13 after five sweeps, 2e-8 after
+    ten) and eventually flips an accept decision.  A pair dropped by the screen would instead shift E
+    by >= 4|V(rc)| = 5e-3 at once.  Required: over the first six sweeps |dE| <= 1e-9 (1 + |E|) for
+    every replica -- seven orders of magnitude below one missed pair -- and equal accept counts; over
+    all sweeps at most 2 % of the replicas with a differing accept count.  (The miss counter of the
+    diagnostic build, below, covers every sweep directly.)"""
     (Ea, ja), (Eb, jb) = _ab_kernels(S, O, N, lat, nrep, nsw, mx_geom, fp_geom)
-    diverged = 0
-    for r in range(nrep):
-        d = np.nonzero(ja[r] != jb[r])[0]
-        upto = nsw if len(d) == 0 else int(d[0])
-        diverged += len(d) > 0
-        assert np.all(np.abs(Ea[r, :upto + 1] - Eb[r, :upto + 1]) <= 1e-8 * (1.0 + np.abs(Ea[r, :upto + 1]))), r
-    assert ja.sum() > 0 and diverged <= max(1, nrep // 50), diverged
-    if N == 4096:   # in practice none at all within ten sweeps
-        assert np.array_equal(ja[:, :5], jb[:, :5])
+    k = min(nsw, 6)
+    assert np.all(np.abs(Ea[:, :k + 1] - Eb[:, :k + 1]) <= 1e-9 * (1.0 + np.abs(Ea[:, :k + 1]))), \
+        np.abs(Ea[:, :k + 1] - Eb[:, :k + 1]).max()
+    assert np.array_equal(ja[:, :k], jb[:, :k]) and ja.sum() > 0
+    diverged = int((ja != jb).any(axis=1).sum())
+    assert diverged <= max(1, nrep // 50), diverged
 
 
 def _load_check_build():
