@@ -192,14 +192,20 @@ int smcx_last_run_ms(smcx_handle *h, double *ms);
 /* the launch geometry chosen for this handle */
 int smcx_geometry(const smcx_handle *h, int *slots, int *waves_per_replica, int *lds_bytes);
 /* which sweep kernel this handle launches: 1 = fp64 (positions as fp64 in registers), 2 = screened
- * (int16 x,y + fp32 z copies in registers, fp64 evaluation of the candidates); name, if not NULL,
- * receives the kernel's name (at most len bytes) */
+ * (compact integer / fp16 / fp32 copies of the positions pre-select pairs, fp64 evaluation of the
+ * candidates: sweep_kernel_mi with one wavefront per replica, sweep_kernel_mx with several); name,
+ * if not NULL, receives the kernel's name (at most len bytes) */
 int smcx_kernel_form(const smcx_handle *h, int *form, char *name, int len);
 /* the numbers of the screened kernel's conservative cutoff test for a box (host only, no GPU needed):
  * thr = cutoff^2 + margin (fp32), u2 = (L/65536)^2, to_fixed = 65536/L, zsafe = |z| up to which the
  * margin holds; lds_z selects the variant with z as fp16.  tests/test_cabi_host.py checks on the CPU,
  * with the device's arithmetic emulated, that no pair inside the cutoff escapes the test. */
 int smcx_screen_bound(const smcx_params *p, int lds_z, double *thr, double *u2, double *to_fixed, double *zsafe);
+/* the same for the integer screen of sweep_kernel_mi (one wavefront per replica): thr = threshold in
+ * length^2, u2 = (L/65536)^2, uz = the z unit 2^zshift L/65536, neg_c = the accumulator start
+ * -(T << 2 zshift) of the x,y dot product; SMCX_ERR_UNSUPPORTED when no built z unit covers the box */
+int smcx_screen_bound_int(const smcx_params *p, double *thr, double *u2, double *to_fixed, double *zsafe,
+                          double *uz, int32_t *neg_c, int32_t *zshift);
 
 /* Teacher-forced evaluator (stateless; tests and debugging): for each of nrep
  * replicas evaluates what SMC.c:300-304 and 319-321 evaluate for particle

@@ -58,6 +58,7 @@ EXPORTS = [
     "smcx_export_observables_device", "smcx_last_kernel_ms", "smcx_last_run_ms", "smcx_geometry", "smcx_eval_moves",
     "smcx_rng_seed", "smcx_one_particle_moves",
     "smcx_cluster_counts", "smcx_cluster_update", "smcx_cluster_analysis", "smcx_kernel_form", "smcx_screen_bound",
+    "smcx_screen_bound_int",
 ]
 
 
@@ -102,6 +103,7 @@ def _lib():
         L.smcx_geometry.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.smcx_kernel_form.argtypes = [vp, C.POINTER(C.c_int), C.c_char_p, C.c_int]
         L.smcx_screen_bound.argtypes = [C.POINTER(Params), C.c_int, _dp, _dp, _dp, _dp]
+        L.smcx_screen_bound_int.argtypes = [C.POINTER(Params), _dp, _dp, _dp, _dp, _dp, _i32p, _i32p]
         L.smcx_eval_moves.argtypes = [C.POINTER(Params), _dp, _dp, _i32p, _dp, _dp]
         L.smcx_rng_seed.argtypes = [_u32p, C.c_uint32]
         L.smcx_rng_seed.restype = None
@@ -143,6 +145,16 @@ def screen_bound(p, lds_z):
     if rc != OK:
         raise SmcxError(rc, "smcx_screen_bound")
     return tuple(x.value for x in v)
+
+
+def screen_bound_int(p):
+    """(thr, u2, to_fixed, zsafe, uz, neg_c, zshift) of the integer screen (sweep_kernel_mi) for the box of p"""
+    v = [C.c_double() for _ in range(5)]
+    nc, zs = C.c_int32(), C.c_int32()
+    rc = _lib().smcx_screen_bound_int(C.byref(p), *[C.byref(x) for x in v], C.byref(nc), C.byref(zs))
+    if rc != OK:
+        raise SmcxError(rc, "smcx_screen_bound_int")
+    return tuple(x.value for x in v) + (nc.value, zs.value)
 
 
 def rng_seed(seed):

@@ -293,7 +293,7 @@ extern "C" int smcx_create(const smcx_params *p, smcx_handle **out)
     CRT(hipEventCreate(&h.ev0));
     CRT(hipEventCreate(&h.ev1));
     CRT(hipMalloc(&c.R, nrep * 3 * N * sizeof(double)));
-    CRT(hipMalloc((void **)&c.W, (size_t)(2 * c.M2 > 2 ? 2 * c.M2 : 2) * sizeof(double)));
+    CRT(hipMalloc((void **)&c.W, (size_t)(2 * c.M2 + 2) * sizeof(double))); // + a0, b0 of the plane (sweep_kernel_mi)
     CRT(hipMalloc(&c.rng, nrep * 32 * sizeof(uint32_t)));
     CRT(hipMalloc(&c.raw, nrep * (size_t)c.rawStride * sizeof(uint32_t)));
     CRT(hipMalloc(&c.displ, nrep * h.chunk * 3 * N * sizeof(double)));
@@ -316,7 +316,11 @@ extern "C" int smcx_create(const smcx_params *p, smcx_handle **out)
 #endif
     CRT(hipMemset(c.obs, 0, nrep * sizeof(ObsRec)));
     CRT(hipMemset(c.zhist, 0, nrep * p->Ncz * sizeof(unsigned long long)));
-    CRT(hipMemset((void *)c.W, 0, (size_t)(2 * c.M2 > 2 ? 2 * c.M2 : 2) * sizeof(double)));
+    CRT(hipMemset((void *)c.W, 0, (size_t)(2 * c.M2 + 2) * sizeof(double)));
+    {
+        const double plane[2] = {p->a0, p->b0};
+        CRT(hipMemcpy((void *)(c.W + 2 * c.M2), plane, sizeof(plane), hipMemcpyHostToDevice));
+    }
 #undef CRT
     *out = hh;
     return SMCX_OK;
@@ -340,14 +344,27 @@ extern "C" int smcx_screen_bound(const smcx_params *p, int lds_z, double *thr, d
     return SMCX_OK;
 }
 
+extern "C" int smcx_screen_bound_int(const smcx_params *p, double *thr, double *u2, double *to_fixed, double *zsafe,
+                                     double *uz, int32_t *neg_c, int32_t *zshift)
+{
+    if (!p || !thr || !u2 || !to_fixed || !zsafe || !uz || !neg_c || !zshift) return SMCX_ERR_PARAM;
+    if (!(p->L > 0) || !(p->Lz > 0) || !(p->cutoff > 0)) return SMCX_ERR_PARAM;
+    int nc = 0, zs = 0;
+    mi_bound_values(p->L, p->Lz, p->cutoff * p->cutoff, thr, u2, to_fixed, zsafe, uz, &nc, &zs);
+    *neg_c = nc; *zshift = zs;
+    return zs ? SMCX_OK : SMCX_ERR_UNSUPPORTED;
+}
+
 extern "C" int smcx_kernel_form(const smcx_handle *hh, int *form, char *name, int len)
 {
     if (!hh) return SMCX_ERR_PARAM;
     const Handle &h = hh->h;
     const bool mx = sweep_uses_mx(h.S, h.WPR, h.p.tune_kernel);
     if (form) *form = mx ? 2 : 1;
+    const bool mi = mx && mi_supported(h.S, h.WPR, h.p.L, h.p.Lz, h.p.cutoff * h.p.cutoff);
     if (name && len > 0)
-        std::snprintf(name, (size_t)len, "%s", mx ? mx_kernel_name(h.S, h.WPR, h.p.Lz) : fp64_kernel_name(h.S, h.WPR));
+        std::snprintf(name, (size_t)len, "%s", mi ? mi_kernel_name(h.S, h.p.L, h.p.Lz)
+                                                  : mx ? mx_kernel_name(h.S, h.WPR, h.p.Lz) : fp64_kernel_name(h.S, h.WPR));
     return SMCX_OK;
 }
 

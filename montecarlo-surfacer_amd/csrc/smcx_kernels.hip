@@ -797,6 +797,7 @@ hipError_t launch_sweeps(const DevCtx &c, int S, int WPR, int nsweeps, double A,
 #ifdef SMCX_CHECK
     a.dbg = c.dbg;
 #endif
+    if (use_mx && mi_supported(S, WPR, c.L, c.Lz, c.cutoff2)) return launch_sweeps_mi(a, c, S, nsweeps, A, st);
     if (use_mx) return launch_sweeps_mx(a, c, S, WPR, nsweeps, A, st);
     hipLaunchKernelGGL(f, dim3(c.nrep), dim3(64 * WPR), 0, st, a, c, nsweeps, A);
     return hipGetLastError();

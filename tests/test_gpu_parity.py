@@ -209,11 +209,11 @@ def test_free_running_chain_observables(S, O, Na, Nz, nsw, kw):
 
 def test_benchmark_kernel_against_oracle_N4096(S, O):
     """the kernel bench.py measures (N=4096: 64 particles per lane, one wavefront per replica, x,y as
-    int16 and z as fp16 screening copies) against the CPU oracle, 3 sweeps from the benchmark's start"""
+    int16 and z as int16 screening copies) against the CPU oracle, 3 sweeps from the benchmark's start"""
     R0 = O.fcc(8, 16)
     nsw, nrep = 3, 2
     eng, p = make_engine(S, O, R0, nrep, flags=S.FLAGS_REFERENCE | S.FLAG_SERIES, tune_slots=64, tune_waves=1)
-    assert eng.kernel_form == (2, "smcx::sweep_kernel_mx<64, 1, 4, true>"), eng.kernel_form
+    assert eng.kernel_form == (2, "smcx::sweep_kernel_mi<64, 4, 4>"), eng.kernel_form
     eng.run(0, nsw, 1)
     ob = eng.observables()
     Es, jj = eng.series(nsw)
