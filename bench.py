@@ -23,6 +23,48 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 BYTES_PER_PAIR_EVAL = 24  # one neighbour position = 3 fp64 per pair-eval
+N_SIMD = 256 * 4          # MI355X_MICROARCH.md: 256 CUs x 4 SIMD-32
+# issue cost of one wave64 VALU instruction on a SIMD-32, MI355X_MICROARCH.md ("v_fma_f32 (wave64) 2 cyc",
+# fp64 at half rate: 4, transcendental 8 -> fp64 transcendental 16)
+GUIDE_COST = {"b32": 2.0, "f64": 4.0, "trans_f64": 16.0}
+# the same from this repo's own measurement at four waves per SIMD (profiles/r02_issue_costs.txt):
+# fast 32-bit forms 1.92, packed / 3-operand integer / converting / SGPR-source forms 3.42, fp64 3.43, v_rcp_f64 8.0
+MEASURED_COST = {"b32": 3.0, "f64": 3.43, "trans_f64": 8.0}
+
+
+def issue_roofline(kname, sweep_ms_per_sweep, nrep, N, clock_ghz):
+    """VALU-issue roofline of the sweep kernel: SIMD cycles the executed wave-instructions need at the
+    guide's issue costs, over the SIMD cycles that passed (1024 SIMDs x in-kernel clock x time).
+    Instruction counts per wave-move by class come from the committed PMC run of this kernel
+    (profiles/kernel_counters.json, tools/profile_valu.sh + tools/pmc_to_json.py)."""
+    path = os.path.join(ROOT, "profiles", "kernel_counters.json")
+    if not os.path.exists(path) or not clock_ghz:
+        return None
+    kc = json.load(open(path)).get(kname)
+    if not kc:
+        return None
+    m = kc["per_wave_move"]
+    f64 = m.get("SQ_INSTS_VALU_ADD_F64", 0) + m.get("SQ_INSTS_VALU_MUL_F64", 0) + m.get("SQ_INSTS_VALU_FMA_F64", 0)
+    tr = m.get("SQ_INSTS_VALU_TRANS_F64", 0)
+    b32 = m["SQ_INSTS_VALU"] - f64 - tr
+    moves_per_s = nrep * N / (sweep_ms_per_sweep * 1e-3)          # wave-moves per second (one wavefront per replica)
+    if kc["workload"]["replicas"] * kc["workload"]["N"] != nrep * N:
+        return None                                                  # counters are of another workload
+    waves_per_replica = kc.get("waves_per_replica", 1)
+    need = b32 * GUIDE_COST["b32"] + f64 * GUIDE_COST["f64"] + tr * GUIDE_COST["trans_f64"]
+    need_m = b32 * MEASURED_COST["b32"] + f64 * MEASURED_COST["f64"] + tr * MEASURED_COST["trans_f64"]
+    peak = N_SIMD * clock_ghz                                        # G SIMD-cycles per second
+    achieved = need * moves_per_s / 1e9
+    return {"bound": "valu_issue", "achieved": achieved, "peak": peak, "unit": "G SIMD-cycles/s of VALU issue",
+            "frac": achieved / peak,
+            "frac_at_measured_costs": need_m * moves_per_s / 1e9 / peak,
+            "clock_ghz": clock_ghz, "clock_source": "s_memtime / s_memrealtime inside the timed sweep launch, median over wavefronts",
+            "valu_wave_instr_per_move": m["SQ_INSTS_VALU"], "of_which_fp64": f64, "fp64_transcendental": tr,
+            "salu_per_move": m.get("SQ_INSTS_SALU"), "lds_per_move": m.get("SQ_INSTS_LDS"),
+            "vmem_rd_per_move": m.get("SQ_INSTS_VMEM_RD"), "guide_issue_cycles_per_move": need,
+            "simd_cycles_per_move": peak * 1e9 / moves_per_s / waves_per_replica,
+            "counters": "profiles/kernel_counters.json (rocprofv3 --pmc, %d-sweep launch)" % kc["workload"]["sweeps_in_launch"],
+            "hbm_bytes_per_sweep_pmc": kc.get("hbm_bytes_per_sweep")}
 
 
 def cpu_baseline(N, Na, Nz, seconds_target=12.0):
@@ -144,6 +186,10 @@ def main():
     dt = time.perf_counter() - t0
     sweep_ms, launches = eng.last_kernel_ms()          # HIP events around the sweep launches
     run_ms = eng.last_run_ms()
+    try:
+        clock_ghz, wave_cycles = eng.last_clock()      # measured inside the last sweep launch of the timed run
+    except Exception:
+        clock_ghz, wave_cycles = None, None
 
     # the one exchange step: all-gather of the per-replica observables
     nbytes = eng.obs_device_bytes()
@@ -169,26 +215,7 @@ def main():
         algo_bytes_per_launch = pe_per_gpu_launchset * BYTES_PER_PAIR_EVAL / max(launches, 1)
         launch_s = sweep_ms * 1e-3 / max(launches, 1)
         achieved = algo_bytes_per_launch / launch_s / 1e9
-        traffic = None
-        valu = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
-            try:
-                tj = json.load(open(tpath))
-                key = "N%d_R%d_S%d_W%d_K%d" % (N, nrep, S_, W_, kform)
-                if key in tj:
-                    traffic = tj[key]["hbm_bytes_per_sweep"] * (a.steps / max(launches, 1))  # per launch
-                    if "valu_wave_instr_per_sweep" in tj[key]:
-                        wi = tj[key]["valu_wave_instr_per_sweep"]
-                        # what actually binds the kernel: VALU issue on the 1024 SIMDs, from the
-                        # committed PMC run of this geometry and kernel form
-                        valu = {"wave_instr_per_sweep": wi,
-                                "wave_instr_per_64_pair_evals": wi / (nrep * 2.0 * N * (N - 1.0) / 64.0),
-                                "screen_wave_instr_per_64_pair_evals": tj[key].get("screen_instr_per_pair_eval"),
-                                "simd_clocks_per_wave_instr": (sweep_ms * 1e-3 / a.steps) * 1024 * 2.15e9 / wi,
-                                "note": tj[key].get("_valu_note", "")}
-            except Exception:
-                traffic = None
+        traffic = None   # HBM bytes per launch from the committed PMC run of this kernel (set below)
         out = {
             "metric": "pair-evals/s (MC sweeps/s x replicas x 2N(N-1)) at N=%d" % N,
             "value": value, "unit": "pair-evals/s", "n_gpus": world, "steps": a.steps,
@@ -202,23 +229,30 @@ def main():
                        "geometry": "S=%d particles/lane, %d wavefront(s)/replica" % (S_, W_),
                        "parallelism": "replica-sharded x%d, no data-path collective; %s all-gather of "
                                       "observables at the end (%.2f ms)" % (world, "RCCL" if backend == "nccl" else backend, gather_ms)},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": kname,
-                         "launches": launches, "avg_launch_ms": sweep_ms / max(launches, 1),
-                         # what `rocprofv3 --stats` averages over: the warm-up launches as well
-                         "launches_incl_warmup": launches + warm_launches,
-                         "avg_launch_ms_incl_warmup": (sweep_ms + warm_ms) / max(launches + warm_launches, 1),
-                         "ms_per_sweep": sweep_ms / a.steps,
-                         "algorithmic_bytes_per_launch": algo_bytes_per_launch,
-                         "note": "algorithmic bytes = 24 B x pair-evals (streaming model, SURVEY 8d); "
-                                 "positions are register-resident, so frac > 1 is legitimate and the "
-                                 "binding resource is VALU issue, not HBM (see valu)"},
-            "valu": valu,
+            "roofline": None,
+            "roofline_hbm_model": {"bound": "hbm (streaming model: NOT the binding bound)", "achieved": achieved,
+                                   "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                                   "algorithmic_bytes_per_launch": algo_bytes_per_launch,
+                                   "note": "SURVEY 8d: 24 B x pair-evals; positions are register/LDS-resident, so this "
+                                           "exceeds the HBM peak and bounds nothing; measured HBM traffic is in roofline.traffic"},
             "device_ms": {"sweep_kernels": sweep_ms, "whole_run": run_ms},
             "observables": {"mean_acceptance": summ["mean_acceptance"], "mean_energy": summ["mean_of_meanE"],
                             "replicas_gathered": int(len(obs["accepted"]))},
         }
+        rl = issue_roofline(kname, sweep_ms / a.steps, nrep, N, clock_ghz)
+        base = {"kernel": kname, "launches": launches, "avg_launch_ms": sweep_ms / max(launches, 1),
+                # what `rocprofv3 --stats` averages over: the warm-up launches as well
+                "launches_incl_warmup": launches + warm_launches,
+                "avg_launch_ms_incl_warmup": (sweep_ms + warm_ms) / max(launches + warm_launches, 1),
+                "ms_per_sweep": sweep_ms / a.steps, "traffic": traffic}
+        if rl is None:   # no committed counters for this kernel / workload: the clock and the time are still live
+            rl = {"bound": "valu_issue", "achieved": None, "peak": N_SIMD * clock_ghz if clock_ghz else None,
+                  "unit": "G SIMD-cycles/s of VALU issue", "frac": None, "clock_ghz": clock_ghz,
+                  "note": "no PMC instruction counts committed for this kernel and workload (profiles/kernel_counters.json)"}
+        elif rl.get("hbm_bytes_per_sweep_pmc"):
+            base["traffic"] = rl["hbm_bytes_per_sweep_pmc"]["fetch_x2_plus_write"] * (a.steps / max(launches, 1))
+        rl.update(base)
+        out["roofline"] = rl
         out["precision"] = ("every energy, force, acceptance test and position is fp64; the int16 (x,y) and "
                             "fp16/fp32 (z) copies only pre-select pairs with a conservative, proven threshold "
                             "(DESIGN 4.1b); every pair inside the cutoff is evaluated in fp64")

@@ -187,6 +187,9 @@ int smcx_export_observables_device(smcx_handle *h, void *dst_device, size_t byte
 /* timing of the sweep kernel launches of the last smcx_run (HIP events around each
  * launch, on the launch stream): their summed milliseconds and their number */
 int smcx_last_kernel_ms(smcx_handle *h, double *ms, int *launches);
+/* the shader clock the LAST sweep kernel launch ran at, measured in the kernel (s_memtime over
+ * s_memrealtime, median over the replicas' wavefronts), and a wavefront's lifetime in shader cycles */
+int smcx_last_clock(smcx_handle *h, double *ghz, double *wave_cycles);
 /* device time of the whole last smcx_run (RNG pre-pass and bookkeeping kernels included) */
 int smcx_last_run_ms(smcx_handle *h, double *ms);
 /* the launch geometry chosen for this handle */

@@ -58,7 +58,7 @@ EXPORTS = [
     "smcx_export_observables_device", "smcx_last_kernel_ms", "smcx_last_run_ms", "smcx_geometry", "smcx_eval_moves",
     "smcx_rng_seed", "smcx_one_particle_moves",
     "smcx_cluster_counts", "smcx_cluster_update", "smcx_cluster_analysis", "smcx_kernel_form", "smcx_screen_bound",
-    "smcx_screen_bound_int",
+    "smcx_screen_bound_int", "smcx_last_clock",
 ]
 
 
@@ -100,6 +100,7 @@ def _lib():
         L.smcx_export_observables_device.argtypes = [vp, vp, C.c_size_t]
         L.smcx_last_kernel_ms.argtypes = [vp, _dp, C.POINTER(C.c_int)]
         L.smcx_last_run_ms.argtypes = [vp, _dp]
+        L.smcx_last_clock.argtypes = [vp, _dp, _dp]
         L.smcx_geometry.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.smcx_kernel_form.argtypes = [vp, C.POINTER(C.c_int), C.c_char_p, C.c_int]
         L.smcx_screen_bound.argtypes = [C.POINTER(Params), C.c_int, _dp, _dp, _dp, _dp]
@@ -356,6 +357,12 @@ class Engine:
         ms = C.c_double()
         self._chk(_lib().smcx_last_run_ms(self._h, C.byref(ms)), "smcx_last_run_ms")
         return ms.value
+
+    def last_clock(self):
+        """(GHz, wavefront lifetime in cycles) of the last sweep launch, measured in the kernel"""
+        g, c = C.c_double(), C.c_double()
+        self._chk(_lib().smcx_last_clock(self._h, C.byref(g), C.byref(c)), "smcx_last_clock")
+        return g.value, c.value
 
     def last_kernel_ms(self):
         ms, n = C.c_double(), C.c_int()

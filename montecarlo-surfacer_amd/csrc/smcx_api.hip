@@ -11,6 +11,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <algorithm>
 #include <vector>
 
 using namespace smcx;
@@ -240,7 +241,7 @@ extern "C" int smcx_destroy(smcx_handle *hh)
     hipFree(c.uni); hipFree(c.offs); hipFree(c.obs); hipFree(c.zhist); hipFree(c.Eseries);
     hipFree(c.jjseries); hipFree(c.rec); hipFree(h.d_save); hipFree(h.d_tmp);
     hipFree(c.D); hipFree(c.Mu); hipFree(c.Rbin); hipFree(c.Pseries);
-    hipFree(h.lca_bits); hipFree(h.lca_counts);
+    hipFree(h.lca_bits); hipFree(h.lca_counts); hipFree(c.clk);
 #ifdef SMCX_CHECK
     hipFree(c.dbg);
 #endif
@@ -302,6 +303,8 @@ extern "C" int smcx_create(const smcx_params *p, smcx_handle **out)
     CRT(hipMalloc(&c.obs, nrep * sizeof(ObsRec)));
     CRT(hipMalloc(&c.rec, nrep * h.chunk * sizeof(SweepRec)));
     CRT(hipMalloc(&c.zhist, nrep * p->Ncz * sizeof(unsigned long long)));
+    CRT(hipMalloc(&c.clk, nrep * 4 * sizeof(unsigned long long)));
+    CRT(hipMemset(c.clk, 0, nrep * 4 * sizeof(unsigned long long)));
     CRT(hipMalloc(&h.d_save, nrep * sizeof(double)));
     CRT(hipMalloc(&h.d_tmp, nrep * sizeof(double)));
     if (p->flags & SMCX_FLAG_FULL_HIST) {
@@ -593,6 +596,27 @@ extern "C" int smcx_last_kernel_ms(smcx_handle *hh, double *ms, int *launches)
     return SMCX_OK;
 }
 
+extern "C" int smcx_last_clock(smcx_handle *hh, double *ghz, double *wave_cycles)
+{
+    if (!hh) return SMCX_ERR_PARAM;
+    Handle &h = hh->h;
+    if (!h.c.clk) return SMCX_ERR_STATE;
+    HIPCHK(&h, hipSetDevice(h.p.device));
+    std::vector<unsigned long long> st((size_t)h.p.nrep * 4);
+    HIPCHK(&h, hipMemcpy(st.data(), h.c.clk, st.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    std::vector<double> f, cyc;
+    for (int r = 0; r < h.p.nrep; r++) {
+        const double dc = (double)(st[4 * r + 2] - st[4 * r]), dr = (double)(st[4 * r + 3] - st[4 * r + 1]);
+        if (st[4 * r + 3] > st[4 * r + 1] && st[4 * r + 2] > st[4 * r]) { f.push_back(dc / dr * 0.1); cyc.push_back(dc); }
+    }
+    if (f.empty()) return SMCX_ERR_STATE; // no sweep kernel has stamped yet
+    std::nth_element(f.begin(), f.begin() + f.size() / 2, f.end());
+    std::nth_element(cyc.begin(), cyc.begin() + cyc.size() / 2, cyc.end());
+    if (ghz) *ghz = f[f.size() / 2];
+    if (wave_cycles) *wave_cycles = cyc[cyc.size() / 2];
+    return SMCX_OK;
+}
+
 extern "C" int smcx_last_run_ms(smcx_handle *hh, double *ms)
 {
     if (!hh || !ms) return SMCX_ERR_PARAM;
@@ -696,12 +720,12 @@ extern "C" int smcx_debug_check_counts(smcx_handle *hh, uint64_t *out /*[3]*/)
 #ifdef SMCX_STAMPS
 // diagnostic build only: per-phase cycle counts the instrumented sweep kernel left at the head of
 // each replica's displacement block (tools/phase_stamps.py)
-extern "C" int smcx_debug_stamps(smcx_handle *hh, double *out /*[nrep][6]*/)
+extern "C" int smcx_debug_stamps(smcx_handle *hh, double *out /*[nrep][8]*/)
 {
     Handle &h = hh->h;
     const size_t stride = (size_t)h.chunk * 3 * h.p.N;
     for (int r = 0; r < h.p.nrep; r++)
-        HIPCHK(&h, hipMemcpy(out + 6 * (size_t)r, h.c.displ + r * stride, 6 * sizeof(double), hipMemcpyDeviceToHost));
+        HIPCHK(&h, hipMemcpy(out + 8 * (size_t)r, h.c.displ + r * stride, 8 * sizeof(double), hipMemcpyDeviceToHost));
     return SMCX_OK;
 }
 #endif

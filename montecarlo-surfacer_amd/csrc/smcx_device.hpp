@@ -71,6 +71,7 @@ struct DevCtx {
     int *Rbin;                    // [nrep][N] cell of each particle at the previous gather
     double *Pseries;              // [nrep][pstride] pressure + wallsPressure per gather (SMC.c:140)
     int pstride;
+    unsigned long long *clk;      // [nrep][4] shader-clock and 100 MHz stamps of the last sweep launch (see SweepArgs)
 #ifdef SMCX_CHECK
     unsigned long long *dbg;      // [4] diagnostic build only (see SweepArgs)
 #endif
@@ -99,10 +100,22 @@ struct SweepArgs {
     const ObsRec *obs;       // [nrep] (Ecur at entry)
     SweepRec *rec;           // [nrep][chunk]
     double edge;             // L/2 - cutoff: probes with |x|,|y| <= edge need no minimum image
+    unsigned long long *clk; // [nrep][4] s_memtime, s_memrealtime at the start and at the end of the launch
 #ifdef SMCX_CHECK
     unsigned long long *dbg; // diagnostic build: pairs inside the cutoff, candidates, misses of the screen
 #endif
 };
+
+// start / end stamps of a sweep launch: shader clock (s_memtime) and the constant 100 MHz counter
+// (s_memrealtime); their ratio is the clock the kernel actually ran at (smcx_last_clock).  Two scalar
+// instructions and one store per launch, outside the move loop.
+__device__ __forceinline__ void clock_stamp(unsigned long long *clk, int rep, int end)
+{
+    if (clk && threadIdx.x == 0) {
+        clk[4 * (size_t)rep + 2 * end] = (unsigned long long)__builtin_amdgcn_s_memtime();
+        clk[4 * (size_t)rep + 2 * end + 1] = (unsigned long long)__builtin_amdgcn_s_memrealtime();
+    }
+}
 
 // ---- cross-lane helpers ------------------------------------------------------
 __device__ __forceinline__ double rdlane(double v, int lane)

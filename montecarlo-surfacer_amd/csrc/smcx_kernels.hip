@@ -107,6 +107,7 @@ sweep_kernel(SweepArgs a, DevCtx c, int nsweeps, double A)
     const int N = a.N;
 
     double *Rg = a.R + (size_t)rep * 3 * N;
+    clock_stamp(a.clk, rep, 0);
 
     // ---- register-resident positions: particle l in lane l % T, slot l / T ------
     double x[S], y[S], z[S];
@@ -278,6 +279,7 @@ sweep_kernel(SweepArgs a, DevCtx c, int nsweeps, double A)
         }
     }
 
+    clock_stamp(a.clk, rep, 1);
     // ---- positions back to memory (with several waves they were written through) ----
     if constexpr (WPR == 1) {
 #pragma unroll
@@ -794,6 +796,7 @@ hipError_t launch_sweeps(const DevCtx &c, int S, int WPR, int nsweeps, double A,
     a.L = c.L; a.invL = c.invL; a.cutoff2 = c.cutoff2; a.invT = c.invT;
     a.R = c.R; a.displ = c.displ; a.uni = c.uni; a.offs = c.offs; a.obs = c.obs; a.rec = c.rec;
     a.edge = c.L / 2 - sqrt(c.cutoff2); // |x|,|y| up to here: no pair needs the periodic image
+    a.clk = c.clk;
 #ifdef SMCX_CHECK
     a.dbg = c.dbg;
 #endif

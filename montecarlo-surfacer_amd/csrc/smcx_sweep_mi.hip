@@ -215,6 +215,13 @@ __device__ __forceinline__ void mi_probe(const Geo &g, const MiWalls &wl, const 
     E4 = rdlane(r, 0); Fx = rdlane(r, 16); Fy = rdlane(r, 32); Fz = rdlane(r, 48);
 }
 
+#ifdef SMCX_STAMPS // diagnostic build only (tools/phase_stamps.py): cycles per phase of a move, summed in LDS by lane 0
+#define MI_STAMP(k) do { const long long t_ = __builtin_amdgcn_s_memtime(); \
+                         if (lane == 0) phs[k] += (unsigned long long)(t_ - tlast); tlast = t_; } while (0)
+#else
+#define MI_STAMP(k) do { } while (0)
+#endif
+
 template <int S, int ZS, int MINW>
 __global__ void __launch_bounds__(64, MINW)
 sweep_kernel_mi(SweepArgs a, MiWalls wl, int nsweeps, double A, MiArgs m)
@@ -223,11 +230,17 @@ sweep_kernel_mi(SweepArgs a, MiWalls wl, int nsweeps, double A, MiArgs m)
     typedef unsigned long long u64;
     __shared__ unsigned zw[S / 2][64]; // int16 z, slot pairs x lanes
     __shared__ double p0[64][3];       // fp64 position of every lane's slot-0 particle (the next probes B)
+#ifdef SMCX_STAMPS
+    __shared__ unsigned long long phs[8];
+    if (threadIdx.x < 8) phs[threadIdx.x] = 0ull;
+    long long tlast = __builtin_amdgcn_s_memtime();
+#endif
 
     const int rep = blockIdx.x;
     const int lane = threadIdx.x;
     const int N = a.N;
     double *Rg = a.R + (size_t)rep * 3 * N;
+    clock_stamp(a.clk, rep, 0);
 
     // ---- compact copies: particle l in lane l % 64, slot l / 64 --------------------------
     unsigned xy[S];
@@ -313,6 +326,7 @@ sweep_kernel_mi(SweepArgs a, MiWalls wl, int nsweeps, double A, MiArgs m)
                     ndx = dK[3 * (i + 1)]; ndy = dK[3 * (i + 1) + 1]; ndz = dK[3 * (i + 1) + 2];
                     nlu = uK[i + 1];
                 }
+                MI_STAMP(0); // loop control, scalar loads
                 // ---- probe B = current position of particle n+1: the compact copy its owner lane holds ----
                 unsigned bxy = 0u, bzz = 0u;
                 bool ub = false;
@@ -336,11 +350,13 @@ sweep_kernel_mi(SweepArgs a, MiWalls wl, int nsweeps, double A, MiArgs m)
                 asm("v_mov_b32 %0, %1" : "=v"(axyv) : "s"(axy));
                 asm("v_mov_b32 %0, %1" : "=v"(bxyv) : "s"(bxy));
 
+                MI_STAMP(1); // probe B's compact copy
                 // ---- screening ------------------------------------------------------
                 unsigned ca[NW], cb[NW];
 #pragma unroll
                 for (int w = 0; w < NW; w++) { ca[w] = 0u; cb[w] = 0u; }
                 mi_screen<S, ZS>(xy, zw, lane, axyv, azz, bxyv, bzz, m.negC, ca, cb);
+                MI_STAMP(2); // screen
                 u64 wa = ca[0], wb = cb[0];
                 if constexpr (NW > 1) { wa |= (u64)ca[1] << 32; wb |= (u64)cb[1] << 32; }
                 {   // particles outside the safe z range are always candidates, a probe outside it flags
@@ -385,11 +401,13 @@ sweep_kernel_mi(SweepArgs a, MiWalls wl, int nsweeps, double A, MiArgs m)
                 }
 #endif
 
+                MI_STAMP(3); // unsafe / exclusion bits
                 // ---- the proposal of particle n: Un, Fn, the Metropolis step (SMC.c:319-348) --------
                 bool acc = false;
                 if (hasA) {
                     double Un, Fnx, Fny, Fnz;
                     mi_probe<S>(g, wl, Rg, N, lane, rot, site, Qx, Qy, Qz, wa, false, 0.0, 0.0, 0.0, Un, Fnx, Fny, Fnz);
+                    MI_STAMP(4); // probe A: walls, candidates, reduction
                     Un *= 4.0;
                     const double dX = Fmx * AoT + ddx;
                     const double dY = Fmy * AoT + ddy;
@@ -413,6 +431,7 @@ sweep_kernel_mi(SweepArgs a, MiWalls wl, int nsweeps, double A, MiArgs m)
                         Px = Qx; Py = Qy; Pz = Qz; // where the move leaves particle n
                     }
                 }
+                MI_STAMP(5); // Metropolis step, update
                 // ---- particle n+1 at its current position: its Um, Fm (SMC.c:300-304), then its proposal ----
                 if (hasB) {
                     double Bx, By, Bz;
@@ -425,6 +444,7 @@ sweep_kernel_mi(SweepArgs a, MiWalls wl, int nsweeps, double A, MiArgs m)
                     double e4;
                     mi_probe<S>(g, wl, Rg, N, lane, rot, site, Bx, By, Bz, wb, hasA, Px, Py, Pz, e4, Fmx, Fmy, Fmz);
                     Um = 4.0 * e4;
+                    MI_STAMP(6); // probe B: walls, side pair, candidates, reduction
                     Px = Bx; Py = By; Pz = Bz;
                     ddx = ndx; ddy = ndy; ddz = ndz; lu = nlu;
                     {   // proposal of particle n+1 (SMC.c:307-316); its compact copy from the vector registers
@@ -442,6 +462,7 @@ sweep_kernel_mi(SweepArgs a, MiWalls wl, int nsweeps, double A, MiArgs m)
                     if (cross) { rotate(); tl = 0; }
                     else tl++;
                 }
+                MI_STAMP(7); // next proposal, slot rotation
             }
         }
         // C: hand E[n+1] and jj[n] (SMC.c:194-195) to the bookkeeping kernel
@@ -450,8 +471,15 @@ sweep_kernel_mi(SweepArgs a, MiWalls wl, int nsweeps, double A, MiArgs m)
             a.rec[(size_t)rep * a.chunk + sw] = r;
         }
     }
+    clock_stamp(a.clk, rep, 1);
 #ifdef SMCX_CHECK
     atomicAdd(&a.dbg[0], chk_in); atomicAdd(&a.dbg[1], chk_cand); atomicAdd(&a.dbg[2], chk_miss);
+#endif
+#ifdef SMCX_STAMPS
+    if (lane < 8) { // diagnostic: overwrite the head of this replica's (consumed) displacement block
+        double *dbg = const_cast<double *>(a.displ) + (size_t)rep * a.chunk * 3 * N;
+        dbg[lane] = (double)phs[lane];
+    }
 #endif
 }
 

@@ -256,6 +256,7 @@ sweep_kernel_mx(SweepArgs a, DevCtx c, int nsweeps, double A, MxArgs m)
     const int wave = uniform(tid >> 6);
     const int N = a.N;
     double *Rg = a.R + (size_t)rep * 3 * N;
+    clock_stamp(a.clk, rep, 0);
 
     // ---- compact copies: particle l in lane l % T, slot l / T --------------------------
     unsigned xy[S];
@@ -506,6 +507,7 @@ sweep_kernel_mx(SweepArgs a, DevCtx c, int nsweeps, double A, MxArgs m)
             a.rec[(size_t)rep * a.chunk + sw] = r;
         }
     }
+    clock_stamp(a.clk, rep, 1);
 #ifdef SMCX_CHECK
     atomicAdd(&a.dbg[0], chk_in); atomicAdd(&a.dbg[1], chk_cand); atomicAdd(&a.dbg[2], chk_miss);
 #endif

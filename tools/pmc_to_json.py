@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""pmc_to_json.py PROF_DIR OUT_JSON [N nrep sweeps] -- turn the rocprofv3 --pmc csv files of
+tools/profile_valu.sh into per-kernel counters of the LARGEST launch of every sweep kernel (the
+9-sweep launch of the default profile command) and per-wave-move figures.  bench.py reads the JSON
+(profiles/kernel_counters.json) for the instruction mix behind its roofline line."""
+import csv, glob, json, os, sys
+
+d, out = sys.argv[1], sys.argv[2]
+N, nrep, sweeps = (int(v) for v in sys.argv[3:6]) if len(sys.argv) > 5 else (4096, 4096, 9)
+res = {}
+for f in glob.glob(os.path.join(d, "*", "*", "*_counter_collection.csv")):
+    best = {}
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"]
+        if "sweep_kernel" not in k:
+            continue
+        name = k.split("(")[0].replace("void ", "").strip()
+        key = (name, r["Counter_Name"])
+        v = float(r["Counter_Value"])
+        if v >= best.get(key, (-1,))[0]:
+            best[key] = (v, int(r["VGPR_Count"]), int(r["SGPR_Count"]), int(r["Scratch_Size"]), int(r["LDS_Block_Size"]),
+                         int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    for (name, cnt), (v, vg, sg, scr, lds, ns) in best.items():
+        e = res.setdefault(name, {"counters": {}, "launch_ns": {}})
+        e["counters"][cnt] = v
+        e["vgpr"], e["sgpr"], e["scratch_bytes"], e["lds_bytes"] = vg, sg, scr, lds
+        e["launch_ns"][cnt] = ns
+for name, e in res.items():
+    c = e["counters"]
+    moves = float(nrep) * sweeps * N
+    e["workload"] = {"N": N, "replicas": nrep, "sweeps_in_launch": sweeps, "wave_moves": moves}
+    e["per_wave_move"] = {k: v / moves for k, v in c.items() if k.startswith("SQ_INSTS")}
+    if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+        # gfx950: FETCH_SIZE counts 64 B per 128-B request of wide coalesced reads (guide, section HBM); these
+        # are 8/16-byte scattered and scalar reads, for which the factor is uncalibrated: both readings kept
+        e["hbm_bytes_per_sweep"] = {"fetch_x2_plus_write": (2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024 / sweeps,
+                                    "fetch_x1_plus_write": (c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024 / sweeps}
+    e["launch_ms"] = sorted(set(round(v / 1e6, 3) for v in e.pop("launch_ns").values()))
+json.dump(res, open(out, "w"), indent=1, sort_keys=True)
+for name, e in res.items():
+    print(name, "VGPR", e["vgpr"], "SGPR", e["sgpr"], "scratch", e["scratch_bytes"], "LDS", e["lds_bytes"], "launch ms", e["launch_ms"])
+    for k, v in sorted(e["per_wave_move"].items()):
+        print("   %-28s %10.2f per wave-move" % (k, v))
+    for k in ("SQ_BUSY_CYCLES", "SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES", "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY", "FETCH_SIZE", "WRITE_SIZE"):
+        if k in e["counters"]:
+            print("   %-28s %12.5g" % (k, e["counters"][k]))
