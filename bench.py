@@ -120,6 +120,26 @@ def cpu_baseline(N, Na, Nz, seconds_target=12.0):
                       "oracle/smc_oracle.c built %s, %.1f s wall" % (cores, sweeps, N, Na, Nz, flags, wall)}
 
 
+def side_config(S, label, N, nrep, lattice, sweeps, device):
+    """one of the other BASELINE configurations, run briefly AFTER the timed region (not the headline)"""
+    p = S.default_params(N, nrep, device=device)
+    with S.Engine(p) as e:
+        e.upload(S.fcc_init(*lattice), S.W_REFERENCE)
+        e.run(0, 1, 10)
+        e.run(0, sweeps, 10)
+        ms, _ = e.last_kernel_ms()
+        run_ms = e.last_run_ms()
+        try:
+            ghz, _ = e.last_clock()
+        except Exception:
+            ghz = None
+        s_, w_, _ = e.geometry
+        pe = nrep * sweeps * 2.0 * N * (N - 1.0)
+        return {"workload": label, "N": N, "replicas": nrep, "sweeps": sweeps, "value": pe / (run_ms * 1e-3),
+                "unit": "pair-evals/s (device time of the whole run)", "ms_per_sweep": ms / sweeps,
+                "kernel": e.kernel_form[1], "geometry": "S=%d x %d wavefront(s)" % (s_, w_), "clock_ghz": ghz}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -272,6 +292,16 @@ def main():
                                                 "unit": "pair-evals/s (sweep kernels only)"}
             except Exception as e:
                 out["fp64_only_kernels"] = {"value": None, "note": "failed: %r" % (e,)}
+        if world == 1 and not a.no_cpu and N == 4096:
+            # the other single-GPU BASELINE configurations, briefly, after the timed region
+            out["other_configs"] = []
+            for label, n_, r_, lat_, sw_ in (("BASELINE config 2: N=1024 + wall, 1024 replicas, fcc(8,4)", 1024, 1024, (8, 4), 40),
+                                             ("BASELINE config 5 per GPU: N=16384 + wall, 256 of 2048 replicas, fcc(16,16)", 16384, 256, (16, 16), 4)):
+                try:
+                    eng.close()
+                    out["other_configs"].append(side_config(S, label, n_, r_, lat_, sw_, local_rank))
+                except Exception as e:
+                    out["other_configs"].append({"workload": label, "value": None, "note": "failed: %r" % (e,)})
         if world == 1 and not a.no_cpu:
             try:
                 out["cpu_baseline"] = cpu_baseline(N, *lattice)

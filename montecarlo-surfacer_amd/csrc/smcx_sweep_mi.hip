@@ -93,8 +93,50 @@ __device__ __forceinline__ unsigned mi_flag(unsigned word, int q)
     return r;
 }
 
-// the screen: candidate bits of probes A and B, slot k in bit k % 32 of word k / 32.  Slots are
-// taken in descending order, so the shifted-in sign bits land in place without a reversal.
+// One group of the screen: four slots (k0 .. k0+3, positions xy0..xy3, z pairs z01 = slots k0, k0+1 and
+// z23) against both probes, as ONE statement of 44 instructions.  The eight chains are interleaved so
+// that every result is consumed at least seven instructions after it was issued: no wait states are
+// needed anywhere (a v_dot2 result wants three before a dependent VALU read, which hipcc cannot see
+// inside a statement and therefore cannot pad), and no instruction waits on its predecessor.
+// Slots are taken in descending order, so the shifted-in sign bits land in place without a reversal.
+template <int ZS>
+__device__ __forceinline__ void mi_screen4(unsigned xy0, unsigned xy1, unsigned xy2, unsigned xy3, unsigned z01,
+                                           unsigned z23, unsigned axy, unsigned azz, unsigned bxy, unsigned bzz,
+                                           int negC, unsigned &wa, unsigned &wb)
+{
+    unsigned a0, a1, a2, a3, b0, b1, b2, b3, za1, zb1, za0, zb0;
+    asm("v_sub_u32 %2, %14, %21\n\t"  "v_sub_u32 %6, %16, %21\n\t"
+        "v_sub_u32 %3, %14, %20\n\t"  "v_sub_u32 %7, %16, %20\n\t"
+        "v_sub_u32 %4, %14, %19\n\t"  "v_sub_u32 %8, %16, %19\n\t"
+        "v_sub_u32 %5, %14, %18\n\t"  "v_sub_u32 %9, %16, %18\n\t"
+        "v_dot2_i32_i16 %2, %2, %2, %24\n\t"  "v_dot2_i32_i16 %6, %6, %6, %24\n\t"
+        "v_dot2_i32_i16 %3, %3, %3, %24\n\t"  "v_dot2_i32_i16 %7, %7, %7, %24\n\t"
+        "v_dot2_i32_i16 %4, %4, %4, %24\n\t"  "v_dot2_i32_i16 %8, %8, %8, %24\n\t"
+        "v_dot2_i32_i16 %5, %5, %5, %24\n\t"  "v_dot2_i32_i16 %9, %9, %9, %24\n\t"
+        "v_pk_sub_i16 %10, %15, %23 clamp\n\t"  "v_pk_sub_i16 %11, %17, %23 clamp\n\t"
+        "v_pk_sub_i16 %12, %15, %22 clamp\n\t"  "v_pk_sub_i16 %13, %17, %22 clamp\n\t"
+        "v_ashrrev_i32 %2, %25, %2\n\t"  "v_ashrrev_i32 %6, %25, %6\n\t"
+        "v_ashrrev_i32 %3, %25, %3\n\t"  "v_ashrrev_i32 %7, %25, %7\n\t"
+        "v_ashrrev_i32 %4, %25, %4\n\t"  "v_ashrrev_i32 %8, %25, %8\n\t"
+        "v_ashrrev_i32 %5, %25, %5\n\t"  "v_ashrrev_i32 %9, %25, %9\n\t"
+        "v_mad_i32_i16 %2, %10, %10, %2 op_sel:[1,1,0,0]\n\t"  "v_mad_i32_i16 %6, %11, %11, %6 op_sel:[1,1,0,0]\n\t"
+        "v_mad_i32_i16 %3, %10, %10, %3\n\t"                   "v_mad_i32_i16 %7, %11, %11, %7\n\t"
+        "v_mad_i32_i16 %4, %12, %12, %4 op_sel:[1,1,0,0]\n\t"  "v_mad_i32_i16 %8, %13, %13, %8 op_sel:[1,1,0,0]\n\t"
+        "v_mad_i32_i16 %5, %12, %12, %5\n\t"                   "v_mad_i32_i16 %9, %13, %13, %9\n\t"
+        "v_alignbit_b32 %0, %0, %2, 31\n\t"  "v_alignbit_b32 %1, %1, %6, 31\n\t"
+        "v_alignbit_b32 %0, %0, %3, 31\n\t"  "v_alignbit_b32 %1, %1, %7, 31\n\t"
+        "v_alignbit_b32 %0, %0, %4, 31\n\t"  "v_alignbit_b32 %1, %1, %8, 31\n\t"
+        "v_alignbit_b32 %0, %0, %5, 31\n\t"  "v_alignbit_b32 %1, %1, %9, 31"
+        : "+v"(wa), "+v"(wb),                                               // 0, 1
+          "=&v"(a3), "=&v"(a2), "=&v"(a1), "=&v"(a0),                       // 2..5: probe A, slots k0+3 .. k0
+          "=&v"(b3), "=&v"(b2), "=&v"(b1), "=&v"(b0),                       // 6..9: probe B
+          "=&v"(za1), "=&v"(zb1), "=&v"(za0), "=&v"(zb0)                    // 10..13: dz of (k0+2, k0+3), (k0, k0+1)
+        : "v"(axy), "s"(azz), "v"(bxy), "s"(bzz),                           // 14..17
+          "v"(xy0), "v"(xy1), "v"(xy2), "v"(xy3), "v"(z01), "v"(z23),       // 18..23
+          "s"(negC), "n"(2 * ZS));                                          // 24, 25
+}
+
+// the screen: candidate bits of probes A and B, slot k in bit k % 32 of word k / 32
 template <int S, int ZS>
 __device__ __forceinline__ void mi_screen(const unsigned (&xy)[S], const unsigned (&zw)[S / 2][64], int lane,
                                           unsigned axy, unsigned azz, unsigned bxy, unsigned bzz, int negC,
@@ -106,22 +148,8 @@ __device__ __forceinline__ void mi_screen(const unsigned (&xy)[S], const unsigne
     for (int k0 = S - 4; k0 >= 0; k0 -= 4) {
         const unsigned zc[2] = {zn[0], zn[1]};
         if (k0 >= 4) { zn[0] = zw[k0 / 2 - 2][lane]; zn[1] = zw[k0 / 2 - 1][lane]; }
-#pragma unroll
-        for (int p = 1; p >= 0; p--) {
-            const mi_s2 zz = __builtin_bit_cast(mi_s2, zc[p]);
-            const unsigned dza = __builtin_bit_cast(unsigned, __builtin_elementwise_sub_sat(__builtin_bit_cast(mi_s2, azz), zz));
-            const unsigned dzb = __builtin_bit_cast(unsigned, __builtin_elementwise_sub_sat(__builtin_bit_cast(mi_s2, bzz), zz));
-#pragma unroll
-            for (int h = 1; h >= 0; h--) {
-                const int k = k0 + 2 * p + h;
-                const int ia = mi_dot2(axy - xy[k], negC) >> (2 * ZS);
-                const int ib = mi_dot2(bxy - xy[k], negC) >> (2 * ZS);
-                const int qa = h ? mi_mad16<true>(dza, ia) : mi_mad16<false>(dza, ia);
-                const int qb = h ? mi_mad16<true>(dzb, ib) : mi_mad16<false>(dzb, ib);
-                ca[k >> 5] = mi_flag(ca[k >> 5], qa);
-                cb[k >> 5] = mi_flag(cb[k >> 5], qb);
-            }
-        }
+        mi_screen4<ZS>(xy[k0], xy[k0 + 1], xy[k0 + 2], xy[k0 + 3], zc[0], zc[1], axy, azz, bxy, bzz, negC,
+                       ca[k0 >> 5], cb[k0 >> 5]);
     }
 }
 
@@ -162,26 +190,45 @@ struct MiWalls {
 
 constexpr int MI_SIDE_LANE = 30; // the lane that evaluates the pair (particle n, probe B)
 
+// take this lane's lowest candidate out of `w` and start the load of its fp64 position
+template <int S>
+__device__ __forceinline__ void mi_fetch(const double *Rg, int N, int lane, int rot, bool skip, unsigned long long &w,
+                                         double &X, double &Y, double &Z, bool &have)
+{
+    have = false; X = 0.0; Y = 0.0; Z = 0.0;
+    if (!skip && w != 0ull) {
+        int ls = __builtin_ctzll(w) + rot; if (ls >= S) ls -= S;
+        w &= w - 1ull;
+        const int l = ls * 64 + lane;
+        if (l < N) { // a padding slot is flagged only through an unsafe probe
+            const double *q = Rg + 3 * l;
+            X = q[0]; Y = q[1]; Z = q[2];
+            have = true;
+        }
+    }
+}
+
 // One probe against everything it interacts with (K1-K4 for one configuration, SMC.c:300-304 or
 // 319-321): the wall sites and the plane on lanes 0..M2 (round 0), optionally the pair with one
-// given position on lane 30 (round 0), and this lane's candidates `w` from the screen, one per
-// round, their fp64 positions fetched from memory.  ONE body of the fp64 arithmetic (signed minimum
-// image, cutoff test, lj_acc's sequence) serves all of them; the items differ only in where dx, dy,
-// dz and the two coefficients come from.  Returns e, fx, fy, fz summed over the wavefront.
+// given position on lane 30 (round 0), and this lane's candidates from the screen, one per round,
+// their fp64 positions fetched from memory (the first one by the caller, ahead of time: X, Y, Z,
+// have).  ONE body of the fp64 arithmetic (signed minimum image, cutoff test, lj_acc's sequence)
+// serves all of them; the items differ only in where dx, dy, dz and the two coefficients come
+// from.  Returns e, fx, fy, fz summed over the wavefront.
 template <int S>
 __device__ __forceinline__ void mi_probe(const Geo &g, const MiWalls &wl, const double *Rg, int N, int lane, int rot,
                                          int site, double px, double py, double pz, unsigned long long w,
+                                         double X, double Y, double Z, bool have,
                                          bool withSide, double sx, double sy, double sz,
                                          double &E4, double &Fx, double &Fy, double &Fz)
 {
     double e = 0.0, fx = 0.0, fy = 0.0, fz = 0.0;
     bool first = true;
-    do {
+    for (;;) {
         const bool wall = first && wl.on && lane <= wl.M2;
         const bool plane = wall && lane == wl.M2;
         const bool side = first && withSide && lane == MI_SIDE_LANE;
         double dx = 0.0, dy = 0.0, dz = 0.0, ca = 1.0, cb = 1.0;
-        bool have = false;
         if (wall) {   // K3/K4: site (i dw, j dw) or the featureless plane, distance to the nearer wall
             const double2 cc = *reinterpret_cast<const double2 *>(wl.Wx + 2 * lane);
             ca = cc.x; cb = cc.y;
@@ -192,15 +239,8 @@ __device__ __forceinline__ void mi_probe(const Geo &g, const MiWalls &wl, const 
         } else if (side) {
             dx = px - sx; dy = py - sy; dz = pz - sz;
             have = true;
-        } else if (w != 0ull) {
-            int ls = __builtin_ctzll(w) + rot; if (ls >= S) ls -= S;
-            w &= w - 1ull;
-            const int l = ls * 64 + lane;
-            if (l < N) { // a padding slot is flagged only through an unsafe probe
-                const double *q = Rg + 3 * l;
-                dx = px - q[0]; dy = py - q[1]; dz = pz - q[2];
-                have = true;
-            }
+        } else if (have) {
+            dx = px - X; dy = py - Y; dz = pz - Z;
         }
         if (have) {
             double mx = dx - g.L * __builtin_rint(dx * g.invL); // SMC.c:571-572, 605-606, 751-752
@@ -209,8 +249,10 @@ __device__ __forceinline__ void mi_probe(const Geo &g, const MiWalls &wl, const 
             const double dr2 = mx * mx + my * my + dz * dz;
             if (plane || dr2 < g.cutoff2) lj_acc(mx, my, dz, dr2, ca, cb, e, fx, fy, fz);
         }
+        if (!__builtin_amdgcn_ballot_w64(w != 0ull)) break;
         first = false;
-    } while (__builtin_amdgcn_ballot_w64(w != 0ull));
+        mi_fetch<S>(Rg, N, lane, rot, false, w, X, Y, Z, have);
+    }
     const double r = reduce4(e, fx, fy, fz);
     E4 = rdlane(r, 0); Fx = rdlane(r, 16); Fy = rdlane(r, 32); Fz = rdlane(r, 48);
 }
@@ -229,7 +271,8 @@ sweep_kernel_mi(SweepArgs a, MiWalls wl, int nsweeps, double A, MiArgs m)
     constexpr int NW = (S + 31) / 32;
     typedef unsigned long long u64;
     __shared__ unsigned zw[S / 2][64]; // int16 z, slot pairs x lanes
-    __shared__ double p0[64][3];       // fp64 position of every lane's slot-0 particle (the next probes B)
+    __shared__ double p0[65][3];       // fp64 position of every lane's slot-0 particle (the next probes B);
+                                       // row 64: lane 0's slot-1 particle, probe B when the order crosses slots
 #ifdef SMCX_STAMPS
     __shared__ unsigned long long phs[8];
     if (threadIdx.x < 8) phs[threadIdx.x] = 0ull;
@@ -261,9 +304,11 @@ sweep_kernel_mi(SweepArgs a, MiWalls wl, int nsweeps, double A, MiArgs m)
         zw[j][lane] = pair;
     }
     int rot = 0; // register slot j holds logical slot (j + rot) % S
-    auto fill_p0 = [&]() { // the fp64 positions of the particles now in slot 0
+    auto fill_p0 = [&]() { // the fp64 positions of the particles now in slot 0, and of the first one of slot 1
         const int l = rot * 64 + lane;
         if (l < N) { p0[lane][0] = Rg[3 * l]; p0[lane][1] = Rg[3 * l + 1]; p0[lane][2] = Rg[3 * l + 2]; }
+        const int l1 = (rot + 1) * 64; // no move order crosses from the last slot to the first
+        if (lane == 0 && l1 < N) { p0[64][0] = Rg[3 * l1]; p0[64][1] = Rg[3 * l1 + 1]; p0[64][2] = Rg[3 * l1 + 2]; }
     };
     auto rotate = [&]() {
         const unsigned t = xy[0];
@@ -321,18 +366,18 @@ sweep_kernel_mi(SweepArgs a, MiWalls wl, int nsweeps, double A, MiArgs m)
                 const bool hasA = (i >= 0);
                 const bool hasB = (i + 1 < len);
                 const bool cross = hasB && (tl == 63);
-                double ndx = 0.0, ndy = 0.0, ndz = 0.0, nlu = 0.0; // of move i + 1: loaded now, used at the end
-                if (hasB) {
-                    ndx = dK[3 * (i + 1)]; ndy = dK[3 * (i + 1) + 1]; ndz = dK[3 * (i + 1) + 2];
-                    nlu = uK[i + 1];
-                }
                 MI_STAMP(0); // loop control, scalar loads
                 // ---- probe B = current position of particle n+1: the compact copy its owner lane holds ----
                 unsigned bxy = 0u, bzz = 0u;
                 bool ub = false;
+                double Bxv = 0.0, Byv = 0.0, Bzv = FAR_PROBE; // its fp64 position: asked for here, used after probe A
                 if (hasB) {
                     const unsigned zp0 = zw[0][lane]; // slots 0 and 1 of every lane
                     unsigned bz16;
+                    {
+                        const int row = cross ? 64 : tl + 1;
+                        Bxv = p0[row][0]; Byv = p0[row][1]; Bzv = p0[row][2];
+                    }
                     if (cross) {
                         bxy = (unsigned)__builtin_amdgcn_readlane((int)xy[S > 1 ? 1 : 0], 0);
                         bz16 = (unsigned)__builtin_amdgcn_readlane((int)zp0, 0) >> 16;
@@ -356,7 +401,26 @@ sweep_kernel_mi(SweepArgs a, MiWalls wl, int nsweeps, double A, MiArgs m)
 #pragma unroll
                 for (int w = 0; w < NW; w++) { ca[w] = 0u; cb[w] = 0u; }
                 mi_screen<S, ZS>(xy, zw, lane, axyv, azz, bxyv, bzz, m.negC, ca, cb);
+#ifdef SMCX_SCREEN_TWICE // timing experiment only: the screen's cost in place = the time this build adds
+                {
+                    unsigned ca2[NW], cb2[NW];
+#pragma unroll
+                    for (int w = 0; w < NW; w++) { ca2[w] = 0u; cb2[w] = 0u; }
+                    asm volatile("" : "+v"(axyv), "+v"(bxyv));
+                    mi_screen<S, ZS>(xy, zw, lane, axyv, azz, bxyv, bzz, m.negC, ca2, cb2);
+#pragma unroll
+                    for (int w = 0; w < NW; w++) { ca[w] |= ca2[w]; cb[w] |= cb2[w]; }
+                }
+#endif
                 MI_STAMP(2); // screen
+                // displacement and log-uniform of move i + 1: scalar loads, asked for now and used at the end of
+                // the move.  NOT before the screen: a scalar load in flight shares the LDS counter and returns
+                // out of order, which turns every counted wait of the screen's LDS read-ahead into a full drain
+                double ndx = 0.0, ndy = 0.0, ndz = 0.0, nlu = 0.0;
+                if (hasB) {
+                    ndx = dK[3 * (i + 1)]; ndy = dK[3 * (i + 1) + 1]; ndz = dK[3 * (i + 1) + 2];
+                    nlu = uK[i + 1];
+                }
                 u64 wa = ca[0], wb = cb[0];
                 if constexpr (NW > 1) { wa |= (u64)ca[1] << 32; wb |= (u64)cb[1] << 32; }
                 {   // particles outside the safe z range are always candidates, a probe outside it flags
@@ -401,12 +465,23 @@ sweep_kernel_mi(SweepArgs a, MiWalls wl, int nsweeps, double A, MiArgs m)
                 }
 #endif
 
-                MI_STAMP(3); // unsafe / exclusion bits
+                // the first candidate of either probe: both loads are in flight while probe A is evaluated;
+                // the lanes that stand for a wall site, the plane or the side pair take theirs a round later
+                double XA, YA, ZA, XB, YB, ZB;
+                bool gotA, gotB;
+                const bool wallLane = wl.on && lane <= wl.M2;
+                mi_fetch<S>(Rg, N, lane, rot, wallLane, wa, XA, YA, ZA, gotA);
+#ifndef SMCX_MI_LATE_B
+                mi_fetch<S>(Rg, N, lane, rot, wallLane || (hasA && lane == MI_SIDE_LANE), wb, XB, YB, ZB, gotB);
+#endif
+                __builtin_amdgcn_sched_barrier(0);
+                MI_STAMP(3); // unsafe / exclusion bits, first fetches
                 // ---- the proposal of particle n: Un, Fn, the Metropolis step (SMC.c:319-348) --------
                 bool acc = false;
                 if (hasA) {
                     double Un, Fnx, Fny, Fnz;
-                    mi_probe<S>(g, wl, Rg, N, lane, rot, site, Qx, Qy, Qz, wa, false, 0.0, 0.0, 0.0, Un, Fnx, Fny, Fnz);
+                    mi_probe<S>(g, wl, Rg, N, lane, rot, site, Qx, Qy, Qz, wa, XA, YA, ZA, gotA, false, 0.0, 0.0, 0.0,
+                                Un, Fnx, Fny, Fnz);
                     MI_STAMP(4); // probe A: walls, candidates, reduction
                     Un *= 4.0;
                     const double dX = Fmx * AoT + ddx;
@@ -434,15 +509,13 @@ sweep_kernel_mi(SweepArgs a, MiWalls wl, int nsweeps, double A, MiArgs m)
                 MI_STAMP(5); // Metropolis step, update
                 // ---- particle n+1 at its current position: its Um, Fm (SMC.c:300-304), then its proposal ----
                 if (hasB) {
-                    double Bx, By, Bz;
-                    if (cross) { // its owner is lane 0, slot 1: not in the slot-0 cache
-                        const double *q = Rg + 3 * (n + 1);
-                        Bx = uniform_d(q[0]); By = uniform_d(q[1]); Bz = uniform_d(q[2]);
-                    } else {
-                        Bx = uniform_d(p0[tl + 1][0]); By = uniform_d(p0[tl + 1][1]); Bz = uniform_d(p0[tl + 1][2]);
-                    }
+                    const double Bx = uniform_d(Bxv), By = uniform_d(Byv), Bz = uniform_d(Bzv);
+#ifdef SMCX_MI_LATE_B
+                    mi_fetch<S>(Rg, N, lane, rot, wallLane || (hasA && lane == MI_SIDE_LANE), wb, XB, YB, ZB, gotB);
+#endif
                     double e4;
-                    mi_probe<S>(g, wl, Rg, N, lane, rot, site, Bx, By, Bz, wb, hasA, Px, Py, Pz, e4, Fmx, Fmy, Fmz);
+                    mi_probe<S>(g, wl, Rg, N, lane, rot, site, Bx, By, Bz, wb, XB, YB, ZB, gotB, hasA, Px, Py, Pz,
+                                e4, Fmx, Fmy, Fmz);
                     Um = 4.0 * e4;
                     MI_STAMP(6); // probe B: walls, side pair, candidates, reduction
                     Px = Bx; Py = By; Pz = Bz;

@@ -291,4 +291,4 @@ def test_bench_launches_its_own_ranks():
     out = json.loads(line[0])
     assert out["n_gpus"] == 2 and out["scaling"] == "weak"
     assert out["observables"]["replicas_gathered"] == 128 and out["config"]["replicas_total"] == 128
-    assert out["value"] > 0 and out["roofline"]["frac"] > 0
+    assert out["value"] > 0 and out["roofline"]["bound"] == "valu_issue" and out["roofline"]["clock_ghz"] > 1.0
