@@ -114,7 +114,15 @@ def cpu_baseline(N, Na, Nz, seconds_target=12.0):
         list(ex.map(one, [(12345 + i, sweeps) for i in range(cores)]))
     wall = time.perf_counter() - t0
     pe = cores * sweeps * 2.0 * N * (N - 1.0)
-    return {"value": pe / wall, "unit": "pair-evals/s", "cores": cores, "kind": "port",
+    model = "unknown"
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                model = ln.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return {"value": pe / wall, "unit": "pair-evals/s", "cores": cores, "kind": "port", "cpu_model": model,
             "per_core": pe / wall / cores,
             "sample": "%d independent chains (one per core) x %d sweeps of N=%d, fcc(%d,%d) start, "
                       "oracle/smc_oracle.c built %s, %.1f s wall" % (cores, sweeps, N, Na, Nz, flags, wall)}

@@ -171,6 +171,86 @@ def test_host_c_system_preparation_matches_reference_fixtures(S, O):
     assert np.array_equal(S.initialize_box(16384, 33.0, 240.0)[0], S.fcc_init(16, 16))
 
 
+def _emulated_int_screen(S, p, P, X):
+    """the integer screen of csrc/smcx_sweep_mi.hip (mi_screen4) in numpy with the device's arithmetic:
+    int16 wrap of the packed x,y difference INCLUDING the borrow of the 32-bit subtraction into y,
+    v_dot2_i32_i16 with the accumulator -C, arithmetic shift, saturating int16 z difference,
+    v_mad_i32_i16, sign bit.  Returns (candidate flag, exact in-cutoff flag, unsafe flag)"""
+    thr, u2, to_fixed, zsafe, uz, neg_c, zs = S.screen_bound_int(p)
+
+    def pack(v):   # mi_pack_xy: rint, then the low 16 bits
+        return np.rint(v * to_fixed).astype(np.int64) & 0xffff
+
+    def word(A):
+        return (pack(A[:, 0]) | (pack(A[:, 1]) << 16)).astype(np.uint64)
+
+    def z16(z):    # mi_z16: rint, clamp to +-32767 (v_cvt_i32_f64 saturates), low 16 bits as int16
+        return np.clip(np.rint(z / uz), -32767, 32767).astype(np.int64)
+
+    d = (word(P) - word(X)) & np.uint64(0xffffffff)                       # v_sub_u32: the borrow reaches the y field
+    dx = (d & np.uint64(0xffff)).astype(np.int64); dx = np.where(dx >= 32768, dx - 65536, dx)
+    dy = (d >> np.uint64(16)).astype(np.int64); dy = np.where(dy >= 32768, dy - 65536, dy)
+    I = dx * dx + dy * dy + neg_c                                           # v_dot2_i32_i16, no clamp: must fit int32
+    assert I.max() < 2 ** 31 and I.min() >= -2 ** 31
+    I = I >> (2 * zs)                                                       # v_ashrrev_i32
+    dz = np.clip(z16(P[:, 2]) - z16(X[:, 2]), -32768, 32767)               # v_pk_sub_i16 clamp
+    q = dz * dz + I                                                         # v_mad_i32_i16
+    assert q.max() < 2 ** 31
+    cand = q < 0
+    unsafe = ~(np.abs(X[:, 2]) < zsafe) | ~(np.abs(P[:, 2]) < zsafe)
+    dd = P - X
+    dd[:, 0] -= p.L * np.rint(dd[:, 0] / p.L); dd[:, 1] -= p.L * np.rint(dd[:, 1] / p.L)
+    exact = (dd * dd).sum(axis=1) < p.cutoff ** 2
+    return cand, exact, unsafe, thr
+
+
+@pytest.mark.parametrize("L,Lz", [(33.0, 240.0), (33.0, 200.0), (6.5, 240.0), (100.0, 60.0), (100.0, 900.0), (16.0, 240.0)])
+def test_integer_screen_never_misses_a_pair_inside_the_cutoff(S, L, Lz):
+    """the proof obligation of sweep_kernel_mi's all-integer screen, checked on the CPU with the product's
+    own numbers (smcx_screen_bound_int): 2e6 pairs per box placed within 1e-9 .. 0.3 of the cutoff sphere,
+    across the periodic x,y edges and up to the edge of the safe z range.  Every pair inside the cutoff must
+    be flagged (or sit in the unsafe set, which the kernel always passes on); no intermediate leaves int32;
+    and the screen stays tight: nothing further out than the threshold plus its own margin is flagged."""
+    p = S.default_params(1024, 1, L=L, Lz=Lz)
+    rs = np.random.RandomState(int(L * 10 + Lz))
+    n = 2_000_000
+    thr, u2, to_fixed, zsafe, uz, neg_c, zs = S.screen_bound_int(p)
+    assert thr > p.cutoff ** 2 and thr < 1.02 * p.cutoff ** 2 + 40 * uz and zsafe >= 0.55 * Lz and zs in (4, 6)
+    X = np.empty((n, 3))
+    X[:, 0] = rs.uniform(-L / 2, L / 2, n); X[:, 1] = rs.uniform(-L / 2, L / 2, n)
+    X[:, 2] = rs.uniform(-1.05, 1.05, n) * zsafe
+    X[: n // 8, 2] = np.sign(X[: n // 8, 2]) * zsafe * (1 - 10.0 ** rs.uniform(-7, -1, n // 8))   # just inside the safe range
+    r = p.cutoff * (1 + rs.uniform(-1, 1, n) * 10.0 ** rs.uniform(-9, -0.5, n))                # radii around the cutoff
+    r[: n // 16] = rs.uniform(0.3, p.cutoff, n // 16)
+    v = rs.standard_normal((n, 3)); v /= np.linalg.norm(v, axis=1)[:, None]
+    v[n // 2: n // 2 + n // 8, 2] *= 0.02; v /= np.linalg.norm(v, axis=1)[:, None]               # nearly in-plane pairs
+    Pp = X + r[:, None] * v
+    Pp[:, 0] -= L * np.rint(Pp[:, 0] / L); Pp[:, 1] -= L * np.rint(Pp[:, 1] / L)                 # probes are kept wrapped
+    cand, exact, unsafe, thr = _emulated_int_screen(S, p, Pp, X)
+    assert exact.sum() > n // 4 and (~exact).sum() > n // 4
+    missed = exact & ~cand & ~unsafe
+    assert not missed.any(), (missed.sum(), Pp[missed][:3], X[missed][:3])
+    d2 = ((Pp - X) ** 2).sum(axis=1)  # not minimum image: only used far from the edges below
+    inner = (np.abs(X[:, 0]) < L / 2 - 2 * p.cutoff) & (np.abs(X[:, 1]) < L / 2 - 2 * p.cutoff) & ~unsafe
+    if inner.sum() > 1000:
+        assert not (cand & inner & (d2 > p.cutoff ** 2 + 2.2 * (thr - p.cutoff ** 2) + 0.01)).any()
+    # far pairs, also further apart in z than the int16 range spans: never flagged by wrap-around
+    far = rs.uniform(-1, 1, (200000, 3)) * [L / 2, L / 2, 0.999 * zsafe]
+    far2 = rs.uniform(-1, 1, (200000, 3)) * [L / 2, L / 2, 0.999 * zsafe]
+    c2, e2, u2_, _ = _emulated_int_screen(S, p, far, far2)
+    assert not (e2 & ~c2).any() and (c2 & ~e2).sum() <= 0.02 * max(e2.sum(), 50) + 20
+
+
+def test_integer_screen_unsupported_boxes_fall_back(S):
+    """no built z unit covers a very tall box, and a box narrower than ~2 cutoffs overflows the int32 sum:
+    smcx_screen_bound_int says so (the engine then launches the older screened kernel)"""
+    for kw in (dict(L=33.0, Lz=5000.0), dict(L=5.0, Lz=240.0, cutoff=3.0)):
+        p = S.default_params(1024, 1, **kw)
+        with pytest.raises(S.SmcxError) as e:
+            S.screen_bound_int(p)
+        assert e.value.status == S.ERR_UNSUPPORTED
+
+
 def test_srand_state_agrees_with_oracle_rand(S, O):
     """smcx_rng_seed = srand(): continuing r[i] = r[i-31] + r[i-3] from the exported
     state must give rand()'s outputs."""

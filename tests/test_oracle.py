@@ -173,6 +173,71 @@ def test_nowall_pins(O):
     assert abs(j.value / (500 * N) - pin["acceptance_500"]) < 6e-4
 
 
+def test_nowall_ten_sweep_trace(O):
+    """BASELINE config 1 (SMC_noMPI_noWall.c path, CPU plumbing): a 10-sweep chain at N=256, rho=0.1,
+    T=0.4, A=4e-8.  The reference holds no vector for it, so the trace is checked
+    through what must hold: the run is deterministic; every move's bookkeeping is self-consistent
+    (proposal = position + delta, accepted <=> u < ap, ap = exp(-(...)/T) from the traced Um, Un, Fm,
+    Fn, SMC_noMPI_noWall.c:296-306); the energy change summed over accepted moves equals the change of
+    orc_nw_energy (energy(), :573-591) between the first and the last configuration; the fixed visiting
+    order 0..N-1 (:278) and the 4N draws per sweep (3N normals + N uniforms, no offset draw)."""
+    N, T_, A_ = 256, 0.4, 4e-8
+    L = np.cbrt(N / 0.1)
+    dp = C.POINTER(C.c_double)
+
+    def pair0(a, b):   # the pair term of energySingle (:606-616): minimum image in x, y and z, cutoff L/2
+        d = a - b
+        d = d - L * np.rint(d / L)
+        r2 = float(d @ d)
+        return 4.0 * (1.0 / r2 ** 6 - 1.0 / r2 ** 3) if r2 < L * L / 4 else 0.0
+
+    def run():
+        X = np.zeros(3 * N)
+        assert O.lib().orc_nw_fcc_init(N, L, X.ctypes.data_as(dp)) == N
+        rng = O.Rng(12345)
+        Rn = np.zeros(3 * N)
+        j = C.c_int(0)
+        traces, dE = [], 0.0
+        E0 = O.lib().orc_nw_energy(N, X.ctypes.data_as(dp), L)
+        for _ in range(10):
+            tr = np.zeros(N, dtype=O.TRACE_DTYPE)
+            before = X.copy()
+            O.lib().orc_nw_one_particle_moves(N, C.byref(rng.g), X.ctypes.data_as(dp), Rn.ctypes.data_as(dp),
+                                              L, A_, T_, C.byref(j), tr.ctypes.data_as(C.POINTER(O.OrcMoveTrace)))
+            assert np.array_equal(tr["n"], np.arange(N))
+            pos = before.reshape(-1, 3)
+            for m in tr:   # each move starts from the positions left by the moves before it
+                n = m["n"]
+                assert np.allclose(m["prop"], pos[n] + m["delta"], rtol=0, atol=1e-15)
+                arg = m["Un"] - m["Um"] + 0.5 * np.dot(m["delta"], m["Fn"] + m["Fm"]) + \
+                    (np.dot(m["Fn"] - m["Fm"], m["Fn"] - m["Fm"]) + 2 * np.dot(m["Fn"] - m["Fm"], m["Fm"])) * A_ / (4 * T_)
+                assert abs(m["ap"] - np.exp(-arg / T_)) <= 1e-12 * max(1.0, m["ap"])
+                assert bool(m["accepted"]) == (m["u"] < m["ap"])
+                if m["accepted"]:
+                    w = m["prop"] - L * np.rint(m["prop"] / L)   # shiftSystem wraps Rn before it is copied back
+                    dE += m["Un"] - m["Um"]
+                    if n != 0:   # energySingle never counts particle 0 as a neighbour (:603): add what it leaves out
+                        dE += pair0(m["prop"], pos[0]) - pair0(pos[n], pos[0])
+                    pos[n] = w
+            assert np.allclose(pos.ravel(), X, rtol=0, atol=1e-15)
+            traces.append(tr)
+        E1 = O.lib().orc_nw_energy(N, X.ctypes.data_as(dp), L)
+        return X, j.value, traces, E0, E1, dE, rng.rand()
+
+    X1, j1, t1, E0, E1, dE, nxt1 = run()
+    X2, j2, t2, _, _, _, nxt2 = run()
+    assert np.array_equal(X1, X2) and j1 == j2 and nxt1 == nxt2
+    assert all(np.array_equal(a, b) for a, b in zip(t1, t2))
+    assert abs(E0 - PINS["nowall_N256"]["E0"]) < 5e-13
+    assert 0.95 * 10 * N < j1 <= 10 * N
+    # energySingle leaves particle 0 out of every neighbour loop (:603), energy() does not: with the (n, 0) pair
+    # terms added back (pair0 above) the per-move differences sum to the change of energy()
+    assert abs((E1 - E0) - dE) < 1e-9, (E1 - E0, dE)
+    ref = O.Rng(12345)
+    ref.draws(10 * 4 * N)
+    assert nxt1 == ref.rand()
+
+
 # ---------------------------------------------------------------- properties / edge cases
 def test_incremental_energy_tracks_recomputed(O):
     X = O.fcc(4, 4)
