@@ -1,0 +1,931 @@
+#!/usr/bin/env python3
+"""gen_sweep_ma.py -- writes smcx_sweep_ma_body.inc: the body of sweep_kernel_ma, the hand-scheduled
+gfx950 form of the screened sweep kernel for ONE wavefront per replica with 64 particles per lane
+(2048 < N <= 4096, the benchmark geometry).  Same algorithm and the same arithmetic per pair as
+sweep_kernel_mi (smcx_sweep_mi.hip: integer screen, fp64 decision and evaluation of every candidate,
+SMC.c:278-351); what changes is that every instruction, register and wait is chosen here instead of
+by hipcc, whose output for that kernel issues ~1600 instructions per move (SGPR spills to VGPR
+lanes, mask bookkeeping, copies around the one-SGPR-per-instruction limit) where ~1100 do the work --
+and on this chip a wavefront's time is its instruction count (four waves per SIMD issue
+one instruction per ~3.7 cycles whatever its kind).
+
+A move (iteration i of a run; particle n = first + i sits in register slot 0 of lane tl):
+  B-COPY  probe B = current position of particle n+1: compact copy by v_readlane from its owner lane
+  SCREEN  16 groups of 4 slots x 2 probes, 44 instructions each, z words read two groups ahead
+  FIX     unsafe / exclusion bits; the first candidate of either probe picked, its fp64 position asked for
+  PROBE A wall sites + plane (lanes 0..M2; position and coefficients from a 32-byte table row per lane),
+          candidates; ONE fp64 body; reduce4 leaves e, fx, fy, fz in the four 16-lane rows of one register
+  MET     Metropolis step in "row layout": row 0 carries the energies, rows 1-3 the x, y, z components, so
+          g = Fn - Fm, h = Fn + Fm and dX = Fm A/T + displ are one instruction each and
+          arg = sum over rows of  h (dX/2 + A/(4T) g)   [= dX.(Fn+Fm)/2 + deltaW: g.g + 2 g.Fm = g.h]
+                plus 4 (eA - eB) from row 0            [= Un - Um, exactly]
+  PROBE B the same body + the pair with particle n where the move left it (LDS cache p0[tl]) on lane 30;
+          its result vector FmV stays in a register for the next move
+  NEXT    proposal of particle n+1 in row layout: q = p0[.] + (FmV A/T + displ) per row, wrap of rows 1-2,
+          fixed-point copies by one v_mul / v_rndne / v_cvt for all three coordinates
+Registers: v64..v127 = the 64 packed x,y of this lane; everything else v0..v63; s0..s95 named below;
+the inline-asm operands (lane id, kernarg pointer, block id) live in v0 and s96+.
+Hazards are padded by the rules hipcc applies on gfx950 (read off its output): 2 wait states between a
+VALU write of an SGPR/VCC and a VALU read of it, 1 before v_readlane / v_readfirstlane of a fresh VGPR,
+2 before DPP or v_permlane*_swap of a fresh VGPR, 1 after v_rcp_f64, 3 after v_dot2 (met by the interleave).
+"""
+import sys
+
+out = []
+
+
+def E(txt=""):
+    for ln in txt.strip("\n").split("\n"):
+        ln = ln.strip()
+        if ln and not ln.startswith("//"):
+            out.append(ln)
+
+
+# ---------------------------------------------------------------------------------------------- registers
+LANE, KARG, REP = "%0", "%1", "%2"
+
+V = dict(zaddr=1, uns0=2, uns1=3, wa0=4, wa1=5, wb0=6, wb1=7, axy=8, bxy=9,
+         zA=10, zB=12,            # z words of the screen: two pairs
+         t=14,                    # v14..v25: screen temporaries; afterwards XA (v14-19) and XB (v20-25)
+         XA=14, XB=20, C=26, D=30, M=36, dr2=40, ir2=42, T=44, S6=46, F=48,
+         acc=50,                  # e, fx, fy, fz: v50..v57
+         wdz=58, FmV=60, DdV=62)
+XY0 = 64
+
+
+def v(name, i=0): return "v%d" % (V[name] + i)
+def vp(name, i=0): return "v[%d:%d]" % (V[name] + 2 * i, V[name] + 2 * i + 1)
+def xy(k): return "v%d" % (XY0 + k)
+
+
+S = dict(Rg=0, displ=2, uni=4, dK=6, uK=8, wtab=10, rec=12, clk=14,
+         L=16, invL=18, cut2=20, invT=22, AoT=24, Ao4T=26, toFix=28, zFix=30, zsafe=32, halfLz=34, Lz=36, invLz=38,
+         neg24=40,
+         N=42, negC=43, M2=44, nsw=45, sw=46, run=47, n0=48, first=49, len=50, i=51, tl=52, rot=53, jacc=54,
+         hasA=55, hasB=56, cross=57, lb=58, azz=59, az16=60, ua=61, bzz=62, ub=63, cbase=64, vbase=65,
+         Q=66, lu=72, nlu=74, E=76, haveA=78, wallM=80, haveB=82, planeM=84, sideM=86, t=88)   # s88..s95 scratch
+
+
+def s(name, i=0): return "s%d" % (S[name] + i)
+def sp(name, i=0): return "s[%d:%d]" % (S[name] + 2 * i, S[name] + 2 * i + 1)
+def st(i): return "s%d" % (S["t"] + i)
+def stp(i): return "s[%d:%d]" % (S["t"] + i, S["t"] + i + 1)
+def st4(i): return "s[%d:%d]" % (S["t"] + i, S["t"] + i + 3)
+
+
+ZS = 4
+LDS_P0 = 8192
+ONE_HI = "0x3ff00000"
+
+# kernarg layout (struct MaArgs in smcx_sweep_ma.hip)
+K_R, K_DISPL, K_UNI, K_OFFS, K_OBS, K_REC, K_WTAB, K_CLK = 0x0, 0x8, 0x10, 0x18, 0x20, 0x28, 0x30, 0x38
+K_CONST16, K_CONST8, K_INTS, K_M2 = 0x40, 0x80, 0xa0, 0xb0
+
+# ---------------------------------------------------------------------------------------------- prologue
+E(f"""
+s_load_dwordx2 {sp('Rg')}, {KARG}, {K_R}
+s_load_dwordx4 {st4(0)}, {KARG}, {K_OBS}
+s_load_dwordx4 {st4(4)}, {KARG}, {K_WTAB}
+s_load_dwordx16 s[16:31], {KARG}, {K_CONST16}
+s_load_dwordx8 s[32:39], {KARG}, {K_CONST8}
+s_waitcnt lgkmcnt(0)
+// stp(0) obs, stp(2) rec, stp(4) wtab, stp(6) clk
+s_mov_b64 {sp('rec')}, {stp(2)}
+s_mov_b64 {sp('wtab')}, {stp(4)}
+s_mov_b64 {sp('clk')}, {stp(6)}
+s_lshl_b32 {st(2)}, {REP}, 6
+s_add_u32 {st(0)}, {st(0)}, {st(2)}
+s_addc_u32 {st(1)}, {st(1)}, 0
+s_load_dwordx2 {sp('E')}, {stp(0)}, 0x20
+s_load_dwordx4 {st4(4)}, {KARG}, {K_INTS}
+s_load_dword {s('M2')}, {KARG}, {K_M2}
+s_waitcnt lgkmcnt(0)
+// stp(4..7) = N, chunk, nsweeps, negC
+s_mov_b32 {s('N')}, {st(4)}
+s_mov_b32 {s('nsw')}, {st(6)}
+s_mov_b32 {s('negC')}, {st(7)}
+s_mul_i32 {s('cbase')}, {REP}, {st(5)}
+s_mov_b32 {s('neg24')}, 0
+s_mov_b32 {s('neg24',1)}, 0xc0380000
+// Rg = R + rep * N * 24 ; rec += rep * chunk * 16 ; clk += rep * 32
+s_mul_i32 {st(0)}, {s('N')}, 24
+s_mul_hi_u32 {st(1)}, {st(0)}, {REP}
+s_mul_i32 {st(0)}, {st(0)}, {REP}
+s_add_u32 {s('Rg')}, {s('Rg')}, {st(0)}
+s_addc_u32 {s('Rg',1)}, {s('Rg',1)}, {st(1)}
+s_lshl_b32 {st(0)}, {s('cbase')}, 4
+s_add_u32 {s('rec')}, {s('rec')}, {st(0)}
+s_addc_u32 {s('rec',1)}, {s('rec',1)}, 0
+s_lshl_b32 {st(0)}, {REP}, 5
+s_add_u32 {s('clk')}, {s('clk')}, {st(0)}
+s_addc_u32 {s('clk',1)}, {s('clk',1)}, 0
+// start stamp: clk[rep][0..1] = s_memtime, s_memrealtime
+s_memtime {stp(4)}
+s_memrealtime {stp(6)}
+s_waitcnt lgkmcnt(0)
+v_mov_b32 v14, 0
+v_mov_b32 v16, {st(4)}
+v_mov_b32 v17, {st(5)}
+v_mov_b32 v18, {st(6)}
+v_mov_b32 v19, {st(7)}
+s_mov_b64 exec, 1
+global_store_dwordx4 v14, v[16:19], {sp('clk')}
+s_mov_b64 exec, -1
+// masks of the special lanes: wall sites + plane = lanes 0..M2 (none if M2 < 0), plane = lane M2, side pair = lane 30
+s_mov_b64 {sp('wallM')}, 0
+s_mov_b64 {sp('planeM')}, 0
+s_cmp_lt_i32 {s('M2')}, 0
+s_cbranch_scc1 L_nowalls
+s_add_u32 {st(2)}, {s('M2')}, 1
+s_lshl_b64 {sp('wallM')}, 1, {st(2)}
+s_sub_u32 {s('wallM')}, {s('wallM')}, 1
+s_lshl_b64 {sp('planeM')}, 1, {s('M2')}
+L_nowalls:
+s_mov_b32 {s('sideM')}, 0x40000000
+s_mov_b32 {s('sideM',1)}, 0
+v_lshlrev_b32 {v('zaddr')}, 2, {LANE}
+v_mov_b32 {v('uns0')}, 0
+v_mov_b32 {v('uns1')}, 0
+s_mov_b32 {s('rot')}, 0
+""")
+
+# ---- compact copies: 64 passes, each loads logical slot k of this lane, packs it, and shifts it in at the
+# top of the register file (xy[j] <- xy[j+1], xy[63] <- new): after 64 passes slot k sits in xy[k]
+E(f"""
+s_mov_b32 {st(0)}, 0
+L_init:
+v_lshl_or_b32 v14, {st(0)}, 6, {LANE}
+v_cmp_gt_u32 vcc, {s('N')}, v14
+v_mul_u32_u24 v15, 24, v14
+v_mov_b32 v16, 0
+v_mov_b32 v17, 0
+v_mov_b32 v18, 0
+v_mov_b32 v19, 0
+v_mov_b32 v20, 0
+v_mov_b32 v21, 0
+s_and_saveexec_b64 {stp(2)}, vcc
+global_load_dwordx4 v[16:19], v15, {sp('Rg')}
+global_load_dwordx2 v[20:21], v15, {sp('Rg')} offset:16
+s_waitcnt vmcnt(0)
+s_mov_b64 exec, -1
+v_mul_f64 v[22:23], v[16:17], {sp('toFix')}
+v_mul_f64 v[24:25], v[18:19], {sp('toFix')}
+v_rndne_f64 v[22:23], v[22:23]
+v_rndne_f64 v[24:25], v[24:25]
+v_cvt_i32_f64 v22, v[22:23]
+v_cvt_i32_f64 v24, v[24:25]
+v_and_b32 v22, 0xffff, v22
+v_lshl_or_b32 v22, v24, 16, v22
+// z -> int16 in units uz, clamped to +-32767; padding slots hold 0x7fff ; unsafe = real && !(|z| < zsafe)
+v_mul_f64 v[24:25], v[20:21], {sp('zFix')}
+v_rndne_f64 v[24:25], v[24:25]
+v_cvt_i32_f64 v24, v[24:25]
+v_mov_b32 v25, 0x7fff
+v_mov_b32 v27, 0xffff8001
+v_med3_i32 v24, v24, v25, v27
+v_cmp_nlt_f64 {stp(4)}, |v[20:21]|, {sp('zsafe')}
+s_and_b64 {stp(4)}, {stp(4)}, vcc
+v_cndmask_b32 v22, 0, v22, vcc
+v_cndmask_b32 v24, v25, v24, vcc
+s_lshr_b32 {st(6)}, {st(0)}, 1
+s_lshl_b32 {st(6)}, {st(6)}, 8
+s_and_b32 {st(7)}, {st(0)}, 1
+s_lshl_b32 {st(7)}, {st(7)}, 1
+s_add_u32 {st(6)}, {st(6)}, {st(7)}
+v_add_u32 v26, {st(6)}, {v('zaddr')}
+ds_write_b16 v26, v24
+v_lshrrev_b64 v[{V['uns0']}:{V['uns1']}], 1, v[{V['uns0']}:{V['uns1']}]
+v_cndmask_b32 v27, 0, 1, {stp(4)}
+v_lshl_or_b32 {v('uns1')}, v27, 31, {v('uns1')}
+""")
+for k in range(63):
+    E(f"v_mov_b32 {xy(k)}, {xy(k+1)}")
+E(f"""
+v_mov_b32 {xy(63)}, v22
+s_add_u32 {st(0)}, {st(0)}, 1
+s_cmp_lt_u32 {st(0)}, 64
+s_cbranch_scc1 L_init
+s_waitcnt lgkmcnt(0)
+""")
+
+
+def fill_p0(tag):
+    """p0[lane] = fp64 position of this lane's slot-0 particle, p0[64] = lane 0's slot-1 particle"""
+    E(f"""
+    s_lshl_b32 {st(0)}, {s('rot')}, 6
+    v_or_b32 v14, {st(0)}, {LANE}
+    v_cmp_gt_u32 vcc, {s('N')}, v14
+    v_mul_u32_u24 v15, 24, v14
+    v_mul_u32_u24 v22, 24, {LANE}
+    s_and_saveexec_b64 {stp(2)}, vcc
+    global_load_dwordx4 v[16:19], v15, {sp('Rg')}
+    global_load_dwordx2 v[20:21], v15, {sp('Rg')} offset:16
+    s_waitcnt vmcnt(0)
+    ds_write_b64 v22, v[16:17] offset:{LDS_P0}
+    ds_write_b64 v22, v[18:19] offset:{LDS_P0 + 8}
+    ds_write_b64 v22, v[20:21] offset:{LDS_P0 + 16}
+    s_mov_b64 exec, 1
+    s_add_u32 {st(0)}, {st(0)}, 64
+    s_cmp_lt_u32 {st(0)}, {s('N')}
+    s_cbranch_scc0 L_p0done_{tag}
+    s_mul_i32 {st(1)}, {st(0)}, 24
+    v_mov_b32 v15, {st(1)}
+    s_nop 1
+    global_load_dwordx4 v[16:19], v15, {sp('Rg')}
+    global_load_dwordx2 v[20:21], v15, {sp('Rg')} offset:16
+    v_mov_b32 v22, {LDS_P0 + 64 * 24}
+    s_waitcnt vmcnt(0)
+    ds_write_b64 v22, v[16:17]
+    ds_write_b64 v22, v[18:19] offset:8
+    ds_write_b64 v22, v[20:21] offset:16
+    L_p0done_{tag}:
+    s_mov_b64 exec, -1
+    s_waitcnt lgkmcnt(0)
+    """)
+
+
+def rotate(tag):
+    """slot j <- slot j+1 for the packed x,y, the int16 z in LDS and the unsafe bits; then the p0 cache"""
+    E(f"v_mov_b32 v14, {xy(0)}")
+    for k in range(63):
+        E(f"v_mov_b32 {xy(k)}, {xy(k+1)}")
+    E(f"v_mov_b32 {xy(63)}, v14")
+    # z: 32 words per lane; new word j = old[j].hi | old[j+1].lo << 16 ; the last one wraps to old[0]
+    E(f"ds_read2st64_b32 v[14:15], {v('zaddr')} offset0:0 offset1:1")
+    E("s_waitcnt lgkmcnt(0)")
+    E("v_mov_b32 v24, v14")
+    for j in range(0, 32, 2):
+        if j + 2 < 32:
+            E(f"ds_read2st64_b32 v[16:17], {v('zaddr')} offset0:{j+2} offset1:{j+3}")
+            E("s_waitcnt lgkmcnt(0)")
+            nxt = "v16"
+        else:
+            nxt = "v24"
+        E("v_alignbit_b32 v18, v15, v14, 16")
+        E(f"v_alignbit_b32 v19, {nxt}, v15, 16")
+        E(f"ds_write2st64_b32 {v('zaddr')}, v18, v19 offset0:{j} offset1:{j+1}")
+        if j + 2 < 32:
+            E("v_mov_b32 v14, v16")
+            E("v_mov_b32 v15, v17")
+    E(f"""
+    s_waitcnt lgkmcnt(0)
+    v_and_b32 v14, 1, {v('uns0')}
+    v_lshrrev_b64 v[{V['uns0']}:{V['uns1']}], 1, v[{V['uns0']}:{V['uns1']}]
+    v_lshl_or_b32 {v('uns1')}, v14, 31, {v('uns1')}
+    s_add_u32 {s('rot')}, {s('rot')}, 1
+    s_and_b32 {s('rot')}, {s('rot')}, 63
+    """)
+    fill_p0(tag)
+
+
+fill_p0("init")
+
+# ---------------------------------------------------------------------------------------------- sweeps, runs
+E(f"""
+s_mov_b32 {s('sw')}, 0
+L_sweep:
+// displ + ((cbase + sw) * 3N) * 8 ; uni + ((cbase + sw) * N) * 8 ; n0 = offs[cbase + sw]
+s_load_dwordx4 {st4(4)}, {KARG}, {K_DISPL}
+s_load_dwordx2 {stp(2)}, {KARG}, {K_OFFS}
+s_add_u32 {st(0)}, {s('cbase')}, {s('sw')}
+s_lshl_b32 {st(1)}, {st(0)}, 2
+s_waitcnt lgkmcnt(0)
+s_load_dword {s('n0')}, {stp(2)}, {st(1)}
+s_mul_i32 {st(2)}, {s('N')}, 8
+s_mul_hi_u32 {st(3)}, {st(2)}, {st(0)}
+s_mul_i32 {st(2)}, {st(2)}, {st(0)}
+s_add_u32 {s('uni')}, {st(6)}, {st(2)}
+s_addc_u32 {s('uni',1)}, {st(7)}, {st(3)}
+s_mul_i32 {st(6)}, {s('N')}, 24
+s_mul_hi_u32 {st(3)}, {st(6)}, {st(0)}
+s_mul_i32 {st(2)}, {st(6)}, {st(0)}
+s_add_u32 {s('displ')}, {st(4)}, {st(2)}
+s_addc_u32 {s('displ',1)}, {st(5)}, {st(3)}
+s_mov_b32 {s('jacc')}, 0
+s_mov_b32 {s('run')}, 0
+s_waitcnt lgkmcnt(0)
+L_run:
+s_sub_u32 {st(0)}, {s('N')}, {s('n0')}
+s_cmp_eq_u32 {s('run')}, 0
+s_cselect_b32 {s('first')}, {s('n0')}, 0
+s_cselect_b32 {s('len')}, {st(0)}, {s('n0')}
+s_cselect_b32 {s('vbase')}, 0, {st(0)}
+s_cmp_eq_u32 {s('len')}, 0
+s_cbranch_scc1 L_run_next
+L_rot_to:
+s_lshr_b32 {st(7)}, {s('first')}, 6
+s_cmp_eq_u32 {s('rot')}, {st(7)}
+s_cbranch_scc1 L_rot_ok
+""")
+rotate("r1")
+E(f"""
+s_branch L_rot_to
+L_rot_ok:
+s_and_b32 {s('tl')}, {s('first')}, 63
+s_sub_u32 {s('tl')}, {s('tl')}, 1
+// dK = displ + 24 first ; uK = uni + 8 vbase
+s_mul_i32 {st(0)}, {s('first')}, 24
+s_add_u32 {s('dK')}, {s('displ')}, {st(0)}
+s_addc_u32 {s('dK',1)}, {s('displ',1)}, 0
+s_lshl_b32 {st(0)}, {s('vbase')}, 3
+s_add_u32 {s('uK')}, {s('uni')}, {st(0)}
+s_addc_u32 {s('uK',1)}, {s('uni',1)}, 0
+s_mov_b32 {s('i')}, -1
+s_mov_b32 {s('hasA')}, 0
+s_mov_b32 {s('hasB')}, 1
+s_mov_b32 {s('azz')}, 0
+s_mov_b32 {s('az16')}, 0
+s_mov_b32 {s('ua')}, 0
+v_mov_b32 {v('axy')}, 0
+v_mov_b32 {v('FmV')}, 0
+v_mov_b32 {v('FmV',1)}, 0
+v_mov_b32 {v('DdV')}, 0
+v_mov_b32 {v('DdV',1)}, 0
+L_move:
+""")
+
+# ---------------------------------------------------------------------------------------------- B's compact copy
+E(f"""
+s_mov_b32 {s('bzz')}, 0
+s_mov_b32 {s('ub')}, 0
+s_mov_b32 {s('cross')}, 0
+s_mov_b32 {s('lb')}, 0
+v_mov_b32 {v('bxy')}, 0
+s_cmp_eq_u32 {s('hasB')}, 0
+s_cbranch_scc1 L_nob1
+ds_read_b32 v14, {v('zaddr')}
+s_add_u32 {s('lb')}, {s('tl')}, 1
+s_cmp_eq_u32 {s('tl')}, 63
+s_cselect_b32 {s('lb')}, 0, {s('lb')}
+s_cselect_b32 {s('cross')}, 1, 0
+s_cbranch_scc1 L_bcross
+v_readlane_b32 {st(0)}, {xy(0)}, {s('lb')}
+v_readlane_b32 {st(2)}, {v('uns0')}, {s('lb')}
+s_waitcnt lgkmcnt(0)
+v_readlane_b32 {st(1)}, v14, {s('lb')}
+s_and_b32 {s('ub')}, {st(2)}, 1
+s_and_b32 {st(1)}, {st(1)}, 0xffff
+s_branch L_bjoin
+L_bcross:
+v_readlane_b32 {st(0)}, {xy(1)}, 0
+v_readlane_b32 {st(2)}, {v('uns0')}, 0
+s_waitcnt lgkmcnt(0)
+v_readlane_b32 {st(1)}, v14, 0
+s_bfe_u32 {s('ub')}, {st(2)}, 0x10001
+s_lshr_b32 {st(1)}, {st(1)}, 16
+L_bjoin:
+s_mul_i32 {s('bzz')}, {st(1)}, 0x10001
+s_nop 0
+v_mov_b32 {v('bxy')}, {st(0)}
+L_nob1:
+""")
+
+# ---------------------------------------------------------------------------------------------- screen
+
+
+def screen_group(k0, zlo, zhi, wa, wb):
+    """slots k0..k0+3, z words zlo = slots (k0, k0+1), zhi = (k0+2, k0+3); descending slot order"""
+    a = ["v%d" % (V['t'] + j) for j in range(4)]       # slots k0+3, k0+2, k0+1, k0 of probe A
+    b = ["v%d" % (V['t'] + 4 + j) for j in range(4)]
+    za1, zb1, za0, zb0 = ["v%d" % (V['t'] + 8 + j) for j in range(4)]
+    X = [xy(k0 + 3), xy(k0 + 2), xy(k0 + 1), xy(k0)]
+    for j in range(4):
+        E(f"v_sub_u32 {a[j]}, {v('axy')}, {X[j]}")
+        E(f"v_sub_u32 {b[j]}, {v('bxy')}, {X[j]}")
+    for j in range(4):
+        E(f"v_dot2_i32_i16 {a[j]}, {a[j]}, {a[j]}, {s('negC')}")
+        E(f"v_dot2_i32_i16 {b[j]}, {b[j]}, {b[j]}, {s('negC')}")
+    E(f"v_pk_sub_i16 {za1}, {s('azz')}, {zhi} clamp")
+    E(f"v_pk_sub_i16 {zb1}, {s('bzz')}, {zhi} clamp")
+    E(f"v_pk_sub_i16 {za0}, {s('azz')}, {zlo} clamp")
+    E(f"v_pk_sub_i16 {zb0}, {s('bzz')}, {zlo} clamp")
+    for j in range(4):
+        E(f"v_ashrrev_i32 {a[j]}, {2 * ZS}, {a[j]}")
+        E(f"v_ashrrev_i32 {b[j]}, {2 * ZS}, {b[j]}")
+    zA = [za1, za1, za0, za0]
+    zB = [zb1, zb1, zb0, zb0]
+    hi = [True, False, True, False]
+    for j in range(4):
+        sel = " op_sel:[1,1,0,0]" if hi[j] else ""
+        E(f"v_mad_i32_i16 {a[j]}, {zA[j]}, {zA[j]}, {a[j]}{sel}")
+        E(f"v_mad_i32_i16 {b[j]}, {zB[j]}, {zB[j]}, {b[j]}{sel}")
+    for j in range(4):
+        E(f"v_alignbit_b32 {wa}, {wa}, {a[j]}, 31")
+        E(f"v_alignbit_b32 {wb}, {wb}, {b[j]}, 31")
+
+
+E(f"""
+v_mov_b32 {v('wa0')}, 0
+v_mov_b32 {v('wa1')}, 0
+v_mov_b32 {v('wb0')}, 0
+v_mov_b32 {v('wb1')}, 0
+ds_read2st64_b32 v[{V['zA']}:{V['zA']+1}], {v('zaddr')} offset0:30 offset1:31
+ds_read2st64_b32 v[{V['zB']}:{V['zB']+1}], {v('zaddr')} offset0:28 offset1:29
+""")
+groups = list(range(60, -1, -4))
+for gi, k0 in enumerate(groups):
+    buf = 'zA' if gi % 2 == 0 else 'zB'
+    E("s_waitcnt lgkmcnt(1)" if gi < len(groups) - 1 else "s_waitcnt lgkmcnt(0)")
+    w = 1 if k0 >= 32 else 0
+    screen_group(k0, "v%d" % V[buf], "v%d" % (V[buf] + 1), v('wa%d' % w), v('wb%d' % w))
+    if gi + 2 < len(groups):
+        nk = groups[gi + 2]
+        E(f"ds_read2st64_b32 v[{V[buf]}:{V[buf]+1}], {v('zaddr')} offset0:{nk // 2} offset1:{nk // 2 + 1}")
+
+# ---------------------------------------------------------------------------------------------- fix-ups
+E(f"""
+// log-uniform of move i+1: scalar load, asked for after the screen (an SMEM in flight would turn the
+// screen's counted LDS waits into full drains), used at the end of the move
+s_cmp_eq_u32 {s('hasB')}, 0
+s_cbranch_scc1 L_nolu
+s_add_u32 {st(0)}, {s('i')}, 1
+s_lshl_b32 {st(0)}, {st(0)}, 3
+s_load_dwordx2 {sp('nlu')}, {sp('uK')}, {st(0)}
+L_nolu:
+v_or_b32 {v('wa0')}, {v('wa0')}, {v('uns0')}
+v_or_b32 {v('wa1')}, {v('wa1')}, {v('uns1')}
+v_or_b32 {v('wb0')}, {v('wb0')}, {v('uns0')}
+v_or_b32 {v('wb1')}, {v('wb1')}, {v('uns1')}
+s_cmp_eq_u32 {s('ua')}, 0
+s_cbranch_scc1 L_ua0
+v_mov_b32 {v('wa0')}, -1
+v_mov_b32 {v('wa1')}, -1
+L_ua0:
+s_cmp_eq_u32 {s('ub')}, 0
+s_cbranch_scc1 L_ub0
+v_mov_b32 {v('wb0')}, -1
+v_mov_b32 {v('wb1')}, -1
+L_ub0:
+s_cmp_eq_u32 {s('hasA')}, 0
+s_cbranch_scc0 L_hasA1
+v_mov_b32 {v('wa0')}, 0
+v_mov_b32 {v('wa1')}, 0
+s_branch L_exB
+L_hasA1:
+// the moving particle itself (slot 0 of lane tl): not a neighbour of A, and it reaches B through the side pair
+s_lshl_b64 {stp(0)}, 1, {s('tl')}
+s_mov_b64 exec, {stp(0)}
+v_and_b32 {v('wa0')}, -2, {v('wa0')}
+v_and_b32 {v('wb0')}, -2, {v('wb0')}
+s_mov_b64 exec, -1
+L_exB:
+s_cmp_eq_u32 {s('hasB')}, 0
+s_cbranch_scc0 L_hasB1
+v_mov_b32 {v('wb0')}, 0
+v_mov_b32 {v('wb1')}, 0
+s_branch L_fixdone
+L_hasB1:
+// the particle probe B stands for: slot 0 of lane tl+1, or slot 1 of lane 0 when the order crosses slots
+s_lshl_b64 {stp(0)}, 1, {s('lb')}
+s_mov_b64 exec, {stp(0)}
+s_cmp_eq_u32 {s('cross')}, 1
+s_cbranch_scc1 L_exBc
+v_and_b32 {v('wb0')}, -2, {v('wb0')}
+s_branch L_fixdone
+L_exBc:
+v_and_b32 {v('wb0')}, -3, {v('wb0')}
+L_fixdone:
+s_mov_b64 exec, -1
+""")
+
+
+def pick_fetch(w0, w1, X, spec_mask, have):
+    """lanes with a candidate (and not in spec_mask) take their lowest one out of w and load its fp64
+    position into X[0:5]; `have` (s pair) <- the lanes whose load is in flight"""
+    E(f"""
+    v_cmp_ne_u64 vcc, 0, v[{w0}:{w1}]
+    s_andn2_b64 {have}, vcc, {spec_mask}
+    s_mov_b64 exec, {have}
+    v_ffbl_b32 v44, v{w0}
+    v_ffbl_b32 v45, v{w1}
+    v_lshl_add_u64 v[46:47], v[{w0}:{w1}], 0, -1
+    v_or_b32 v45, 32, v45
+    v_min_u32 v44, v44, v45
+    v_and_b32 v{w0}, v{w0}, v46
+    v_and_b32 v{w1}, v{w1}, v47
+    v_add_u32 v44, {s('rot')}, v44
+    v_and_b32 v44, 63, v44
+    v_lshl_or_b32 v44, v44, 6, {LANE}
+    v_cmp_gt_u32 vcc, {s('N')}, v44
+    v_mul_u32_u24 v45, 24, v44
+    s_and_b64 exec, exec, vcc
+    global_load_dwordx4 v[{X}:{X+3}], v45, {sp('Rg')}
+    global_load_dwordx2 v[{X+4}:{X+5}], v45, {sp('Rg')} offset:16
+    s_mov_b64 {have}, exec
+    s_mov_b64 exec, -1
+    """)
+
+
+def coeff_one():
+    E(f"""
+    v_mov_b32 {v('C',0)}, 0
+    v_mov_b32 {v('C',1)}, {ONE_HI}
+    v_mov_b32 {v('C',2)}, 0
+    v_mov_b32 {v('C',3)}, {ONE_HI}
+    """)
+
+
+def wall_fetch(X, with_pos=True):
+    """lanes 0..M2: site position (sx, sy) into X[0:3] and the coefficients (ca, cb) into C, from the table"""
+    coeff_one()
+    E(f"""
+    s_mov_b64 exec, {sp('wallM')}
+    v_lshlrev_b32 v46, 5, {LANE}
+    global_load_dwordx4 v[{X}:{X+3}], v46, {sp('wtab')}
+    global_load_dwordx4 v[{V['C']}:{V['C']+3}], v46, {sp('wtab')} offset:16
+    s_mov_b64 exec, -1
+    """)
+
+
+def wall_dz(tag, pz_is_sgpr, pz):
+    """wdz (uniform) = signed distance of pz to the nearer wall with the reference's clamp (SMC.c:736-739)"""
+    if pz_is_sgpr:
+        E(f"v_mov_b32 {v('wdz')}, {pz[0]}")
+        E(f"v_mov_b32 {v('wdz',1)}, {pz[1]}")
+        src = vp('wdz')
+    else:
+        src = pz
+    E(f"""
+    v_add_f64 {vp('T')}, {src}, {sp('halfLz')}
+    v_cmp_le_f64 {stp(0)}, {src}, -{sp('halfLz')}
+    v_cmp_ge_f64 {stp(2)}, {src}, {sp('halfLz')}
+    v_mul_f64 {vp('S6')}, {vp('T')}, {sp('invLz')}
+    v_rndne_f64 {vp('S6')}, {vp('S6')}
+    v_fma_f64 {vp('wdz')}, -{vp('S6')}, {sp('Lz')}, {vp('T')}
+    s_or_b64 {stp(4)}, {stp(0)}, {stp(2)}
+    s_cmp_lg_u64 {stp(4)}, 0
+    s_cbranch_scc0 L_wdz_{tag}
+    // at or beyond a wall: +1e-4 below the lower one, -1e-4 above the upper one
+    v_mov_b32 {v('wdz')}, 0xeb1c432d
+    v_mov_b32 {v('T')}, 0xbf1a36e2
+    v_mov_b32 {v('T',1)}, 0x3f1a36e2
+    v_cndmask_b32 {v('wdz',1)}, {v('T')}, {v('T',1)}, {stp(0)}
+    L_wdz_{tag}:
+    """)
+
+
+def body(tag, P, X, items, round0):
+    """the fp64 body for the lanes in `items` (s pair): d = probe - X, the walls' dz, signed minimum image,
+    the plane's rules, cutoff test, lj_acc's sequence (SMC.c:567-578, 601-614, 740-761, 787-809)"""
+    E(f"""
+    s_mov_b64 exec, {items}
+    v_add_f64 {vp('D',0)}, {P[0]}, -v[{X}:{X+1}]
+    v_add_f64 {vp('D',1)}, {P[1]}, -v[{X+2}:{X+3}]
+    v_add_f64 {vp('D',2)}, {P[2]}, -v[{X+4}:{X+5}]
+    """)
+    if round0:
+        E(f"""
+        s_and_b64 exec, {items}, {sp('wallM')}
+        v_mov_b32 {v('D',4)}, {v('wdz')}
+        v_mov_b32 {v('D',5)}, {v('wdz',1)}
+        s_mov_b64 exec, {items}
+        """)
+    E(f"""
+    v_mul_f64 {vp('T')}, {vp('D',0)}, {sp('invL')}
+    v_mul_f64 {vp('S6')}, {vp('D',1)}, {sp('invL')}
+    v_rndne_f64 {vp('T')}, {vp('T')}
+    v_rndne_f64 {vp('S6')}, {vp('S6')}
+    v_fma_f64 {vp('M',0)}, -{vp('T')}, {sp('L')}, {vp('D',0)}
+    v_fma_f64 {vp('M',1)}, -{vp('S6')}, {sp('L')}, {vp('D',1)}
+    """)
+    if round0:
+        E(f"""
+        s_and_b64 exec, {items}, {sp('planeM')}
+        v_mov_b32 {v('M',0)}, 0
+        v_mov_b32 {v('M',1)}, 0
+        v_mov_b32 {v('M',2)}, 0
+        v_mov_b32 {v('M',3)}, 0
+        s_mov_b64 exec, {items}
+        """)
+    E(f"""
+    v_mul_f64 {vp('dr2')}, {vp('M',0)}, {vp('M',0)}
+    v_fma_f64 {vp('dr2')}, {vp('M',1)}, {vp('M',1)}, {vp('dr2')}
+    v_fma_f64 {vp('dr2')}, {vp('D',2)}, {vp('D',2)}, {vp('dr2')}
+    v_cmp_gt_f64 vcc, {sp('cut2')}, {vp('dr2')}
+    """)
+    if round0:
+        E(f"s_or_b64 vcc, vcc, {sp('planeM')}")
+    E(f"""
+    s_and_b64 exec, exec, vcc
+    s_cbranch_execz L_nolj_{tag}
+    v_rcp_f64 {vp('ir2')}, {vp('dr2')}
+    s_nop 0
+    v_fma_f64 {vp('T')}, -{vp('dr2')}, {vp('ir2')}, 1.0
+    v_fma_f64 {vp('ir2')}, {vp('T')}, {vp('ir2')}, {vp('ir2')}
+    v_fma_f64 {vp('T')}, -{vp('dr2')}, {vp('ir2')}, 1.0
+    v_fma_f64 {vp('ir2')}, {vp('T')}, {vp('ir2')}, {vp('ir2')}
+    v_mul_f64 {vp('T')}, {vp('ir2')}, {vp('ir2')}
+    v_mul_f64 {vp('S6')}, {vp('T')}, {vp('ir2')}
+    v_mul_f64 {vp('T')}, {vp('C',0)}, {vp('S6')}
+    v_mul_f64 {vp('F')}, {vp('C',1)}, {vp('S6')}
+    v_mul_f64 {vp('T')}, {vp('T')}, {vp('S6')}
+    v_add_f64 {vp('S6')}, {vp('T')}, -{vp('F')}
+    v_mul_f64 {vp('F')}, {vp('F')}, {sp('neg24')}
+    v_add_f64 {vp('acc',0)}, {vp('acc',0)}, {vp('S6')}
+    v_fmac_f64 {vp('F')}, 0x40480000, {vp('T')}
+    v_mul_f64 {vp('F')}, {vp('ir2')}, {vp('F')}
+    v_fma_f64 {vp('acc',1)}, {vp('F')}, {vp('M',0)}, {vp('acc',1)}
+    v_fma_f64 {vp('acc',2)}, {vp('F')}, {vp('M',1)}, {vp('acc',2)}
+    v_fma_f64 {vp('acc',3)}, {vp('F')}, {vp('D',2)}, {vp('acc',3)}
+    L_nolj_{tag}:
+    s_mov_b64 exec, -1
+    """)
+
+
+def reduce4(dst):
+    """dst pair <- totals of acc[0..3], one per 16-lane row"""
+    a = [V['acc'] + 2 * j for j in range(4)]
+    lo, hi = (int(x) for x in dst[2:-1].split(":"))
+    E(f"""
+    s_nop 1
+    v_permlane32_swap_b32 v{a[0]}, v{a[2]}
+    v_permlane32_swap_b32 v{a[0]+1}, v{a[2]+1}
+    v_permlane32_swap_b32 v{a[1]}, v{a[3]}
+    v_permlane32_swap_b32 v{a[1]+1}, v{a[3]+1}
+    s_nop 0
+    v_add_f64 v[{a[0]}:{a[0]+1}], v[{a[0]}:{a[0]+1}], v[{a[2]}:{a[2]+1}]
+    v_add_f64 v[{a[1]}:{a[1]+1}], v[{a[1]}:{a[1]+1}], v[{a[3]}:{a[3]+1}]
+    s_nop 1
+    v_permlane16_swap_b32 v{a[0]}, v{a[1]}
+    v_permlane16_swap_b32 v{a[0]+1}, v{a[1]+1}
+    s_nop 0
+    v_add_f64 {dst}, v[{a[0]}:{a[0]+1}], v[{a[1]}:{a[1]+1}]
+    """)
+    for ctrl in ("row_ror:8", "row_half_mirror", "quad_perm:[2,3,0,1]", "quad_perm:[1,0,3,2]"):
+        E(f"""
+        s_nop 1
+        v_mov_b32_dpp {v('T')}, v{lo} {ctrl} row_mask:0xf bank_mask:0xf bound_ctrl:1
+        v_mov_b32_dpp {v('T',1)}, v{hi} {ctrl} row_mask:0xf bank_mask:0xf bound_ctrl:1
+        v_add_f64 {dst}, {dst}, {vp('T')}
+        """)
+
+
+def probe(tag, P, pz_sgpr, pz, w0, w1, X, have, side):
+    """a whole probe: round 0 (specials + the first candidates, already requested into X / `have`), then
+    further rounds while any lane still has a candidate"""
+    for j in range(8):
+        E(f"v_mov_b32 v{V['acc'] + j}, 0")
+    E(f"s_cmp_lg_u64 {sp('wallM')}, 0")
+    E(f"s_cbranch_scc0 L_nw_{tag}")
+    wall_dz(tag, pz_sgpr, pz)
+    E(f"L_nw_{tag}:")
+    E(f"s_or_b64 {stp(6)}, {have}, {sp('wallM')}")
+    if side:
+        E(f"s_cmp_eq_u32 {s('hasA')}, 0")
+        E(f"s_cbranch_scc1 L_noside_{tag}")
+        E(f"s_or_b64 {stp(6)}, {stp(6)}, {sp('sideM')}")
+        E(f"L_noside_{tag}:")
+    E("s_waitcnt vmcnt(0) lgkmcnt(0)")
+    body(tag + "r0", P, X, stp(6), True)
+    E(f"""
+    L_more_{tag}:
+    v_cmp_ne_u64 vcc, 0, v[{w0}:{w1}]
+    s_cmp_lg_u64 vcc, 0
+    s_cbranch_scc0 L_done_{tag}
+    """)
+    coeff_one()
+    pick_fetch(w0, w1, X, "0", stp(6))
+    E("s_waitcnt vmcnt(0)")
+    body(tag + "rm", P, X, stp(6), False)
+    E(f"s_branch L_more_{tag}")
+    E(f"L_done_{tag}:")
+
+
+# ---- the first candidate of both probes; probe A's wall table rows
+E(f"s_mov_b64 {sp('haveA')}, 0")
+E(f"s_mov_b64 {sp('haveB')}, 0")
+E(f"s_cmp_eq_u32 {s('hasA')}, 0")
+E("s_cbranch_scc1 L_nofa")
+pick_fetch(V['wa0'], V['wa1'], V['XA'], sp('wallM'), sp('haveA'))
+wall_fetch(V['XA'])
+E("L_nofa:")
+E(f"s_cmp_eq_u32 {s('hasB')}, 0")
+E("s_cbranch_scc1 L_nofb")
+E(f"s_mov_b64 {stp(0)}, {sp('wallM')}")
+E(f"s_cmp_eq_u32 {s('hasA')}, 0")
+E("s_cbranch_scc1 L_fb1")
+E(f"s_or_b64 {stp(0)}, {sp('wallM')}, {sp('sideM')}")
+E("L_fb1:")
+pick_fetch(V['wb0'], V['wb1'], V['XB'], stp(0), sp('haveB'))
+E("L_nofb:")
+
+# ---------------------------------------------------------------------------------------------- probe A + Metropolis
+E(f"s_cmp_eq_u32 {s('hasA')}, 0")
+E("s_cbranch_scc1 L_noA")
+QP = [sp('Q', 0), sp('Q', 1), sp('Q', 2)]
+probe("A", QP, True, (s('Q', 4), s('Q', 5)), V['wa0'], V['wa1'], V['XA'], sp('haveA'), False)
+FnV = vp('M', 0)          # v[36:37]: the body's M registers are free now
+reduce4(FnV)
+E(f"""
+// ---- Metropolis step in row layout (SMC.c:326-335); DdV = displacement of this move per row
+v_add_f64 {vp('D',0)}, {FnV}, -{vp('FmV')}
+v_add_f64 {vp('D',1)}, {FnV}, {vp('FmV')}
+v_fma_f64 {vp('D',2)}, {vp('FmV')}, {sp('AoT')}, {vp('DdV')}
+v_mul_f64 {vp('D',2)}, {vp('D',2)}, 0.5
+v_fma_f64 {vp('D',2)}, {vp('D',0)}, {sp('Ao4T')}, {vp('D',2)}
+v_mul_f64 {vp('D',2)}, {vp('D',2)}, {vp('D',1)}
+s_mov_b32 {st(0)}, 0xffff
+s_mov_b32 {st(1)}, 0
+s_mov_b64 exec, {stp(0)}
+v_mul_f64 {vp('D',2)}, {vp('D',0)}, 4.0
+s_mov_b64 exec, -1
+// sum over the four rows: lanes ^32, then rows ^1
+v_mov_b32 {v('T')}, {v('D',4)}
+v_mov_b32 {v('T',1)}, {v('D',5)}
+s_nop 1
+v_permlane32_swap_b32 {v('D',4)}, {v('T')}
+v_permlane32_swap_b32 {v('D',5)}, {v('T',1)}
+s_nop 0
+v_add_f64 {vp('D',2)}, {vp('D',2)}, {vp('T')}
+s_nop 0
+v_mov_b32 {v('T')}, {v('D',4)}
+v_mov_b32 {v('T',1)}, {v('D',5)}
+s_nop 1
+v_permlane16_swap_b32 {v('D',4)}, {v('T')}
+v_permlane16_swap_b32 {v('D',5)}, {v('T',1)}
+s_nop 0
+v_add_f64 {vp('D',2)}, {vp('D',2)}, {vp('T')}
+v_mul_f64 {vp('D',2)}, {vp('D',2)}, -{sp('invT')}
+v_cmp_lt_f64 vcc, {sp('lu')}, {vp('D',2)}
+s_cmp_lg_u64 vcc, 0
+s_cbranch_scc0 L_reject
+// accepted: E += Un - Um = 4 (eA - eB) (row 0 of g), particle n takes the proposal
+v_readlane_b32 {st(0)}, {v('D',0)}, 0
+v_readlane_b32 {st(1)}, {v('D',1)}, 0
+s_add_u32 {s('jacc')}, {s('jacc')}, 1
+s_nop 0
+v_mov_b32 {v('T')}, {st(0)}
+v_mov_b32 {v('T',1)}, {st(1)}
+v_fma_f64 {vp('T')}, {vp('T')}, 4.0, {sp('E')}
+s_lshl_b64 {stp(0)}, 1, {s('tl')}
+s_add_u32 {st(2)}, {s('first')}, {s('i')}
+s_mul_i32 {st(2)}, {st(2)}, 24
+v_readfirstlane_b32 {s('E')}, {v('T')}
+v_readfirstlane_b32 {s('E',1)}, {v('T',1)}
+s_mov_b64 exec, {stp(0)}
+v_mov_b32 {xy(0)}, {v('axy')}
+v_and_b32 {v('uns0')}, -2, {v('uns0')}
+v_or_b32 {v('uns0')}, {s('ua')}, {v('uns0')}
+v_mov_b32 {v('T')}, {s('az16')}
+v_mov_b32 v14, {s('Q',0)}
+v_mov_b32 v15, {s('Q',1)}
+v_mov_b32 v16, {s('Q',2)}
+v_mov_b32 v17, {s('Q',3)}
+v_mov_b32 v18, {s('Q',4)}
+v_mov_b32 v19, {s('Q',5)}
+v_mov_b32 {v('T',1)}, {st(2)}
+v_mul_u32_u24 {v('S6')}, 24, {LANE}
+ds_write_b16 {v('zaddr')}, {v('T')}
+global_store_dwordx4 {v('T',1)}, v[14:17], {sp('Rg')}
+global_store_dwordx2 {v('T',1)}, v[18:19], {sp('Rg')} offset:16
+ds_write_b64 {v('S6')}, v[14:15] offset:{LDS_P0}
+ds_write_b64 {v('S6')}, v[16:17] offset:{LDS_P0 + 8}
+ds_write_b64 {v('S6')}, v[18:19] offset:{LDS_P0 + 16}
+s_mov_b64 exec, -1
+s_nop 1
+L_reject:
+L_noA:
+""")
+
+# ---------------------------------------------------------------------------------------------- probe B
+E(f"s_cmp_eq_u32 {s('hasB')}, 0")
+E("s_cbranch_scc1 L_noB")
+E(f"""
+// probe B's fp64 position from the LDS cache: row = cross ? 64 : tl + 1
+s_cmp_eq_u32 {s('cross')}, 1
+s_cselect_b32 {st(0)}, 64, {s('lb')}
+s_mul_i32 {st(0)}, {st(0)}, 24
+v_mov_b32 {v('T')}, {st(0)}
+ds_read_b64 v[14:15], {v('T')} offset:{LDS_P0}
+ds_read_b64 v[16:17], {v('T')} offset:{LDS_P0 + 8}
+ds_read_b64 v[18:19], {v('T')} offset:{LDS_P0 + 16}
+""")
+wall_fetch(V['XB'])
+E(f"""
+// the side pair's source on lane 30: particle n where the move left it = p0[tl]
+s_cmp_eq_u32 {s('hasA')}, 0
+s_cbranch_scc1 L_nosrc
+s_mul_i32 {st(0)}, {s('tl')}, 24
+v_mov_b32 {v('T')}, {st(0)}
+s_mov_b64 exec, {sp('sideM')}
+ds_read_b64 v[{V['XB']}:{V['XB']+1}], {v('T')} offset:{LDS_P0}
+ds_read_b64 v[{V['XB']+2}:{V['XB']+3}], {v('T')} offset:{LDS_P0 + 8}
+ds_read_b64 v[{V['XB']+4}:{V['XB']+5}], {v('T')} offset:{LDS_P0 + 16}
+s_mov_b64 exec, -1
+L_nosrc:
+""")
+E("s_waitcnt lgkmcnt(0)")
+BP = ["v[14:15]", "v[16:17]", "v[18:19]"]
+probe("B", BP, False, "v[18:19]", V['wb0'], V['wb1'], V['XB'], sp('haveB'), True)
+reduce4(vp('FmV'))
+E(f"""
+// ---- proposal of particle n+1 in row layout (SMC.c:307-316): q = p + (Fm A/T + displ)
+// rows 1..3 read component row-1 of p0[rowB] and of displ[3 (i+1) ..]; row 0 idles along with component 0
+v_lshrrev_b32 {v('T')}, 4, {LANE}
+v_add_u32 {v('T')}, -1, {v('T')}
+v_max_i32 {v('T')}, 0, {v('T')}
+v_lshlrev_b32 {v('T')}, 3, {v('T')}
+s_cmp_eq_u32 {s('cross')}, 1
+s_cselect_b32 {st(0)}, 64, {s('lb')}
+s_mul_i32 {st(0)}, {st(0)}, 24
+s_add_u32 {st(1)}, {s('i')}, 1
+s_mul_i32 {st(1)}, {st(1)}, 24
+v_add_u32 {v('T',1)}, {st(0)}, {v('T')}
+v_add_u32 {v('S6')}, {st(1)}, {v('T')}
+ds_read_b64 {vp('D',0)}, {v('T',1)} offset:{LDS_P0}
+global_load_dwordx2 {vp('DdV')}, {v('S6')}, {sp('dK')}
+s_waitcnt vmcnt(0) lgkmcnt(0)
+s_mov_b64 {sp('lu')}, {sp('nlu')}
+v_fma_f64 {vp('D',1)}, {vp('FmV')}, {sp('AoT')}, {vp('DdV')}
+v_add_f64 {vp('D',0)}, {vp('D',0)}, {vp('D',1)}
+// wrap x and y (rows 1, 2 = lanes 16..47), fixed point with 65536/L
+s_mov_b32 {st(0)}, 0xffff0000
+s_mov_b32 {st(1)}, 0x0000ffff
+s_mov_b64 exec, {stp(0)}
+v_mul_f64 {vp('D',1)}, {vp('D',0)}, {sp('invL')}
+v_rndne_f64 {vp('D',1)}, {vp('D',1)}
+v_fma_f64 {vp('D',0)}, -{vp('D',1)}, {sp('L')}, {vp('D',0)}
+v_mul_f64 {vp('D',1)}, {vp('D',0)}, {sp('toFix')}
+// z (row 3 = lanes 48..63): fixed point with 1/uz; outside the safe range?
+s_mov_b32 {st(0)}, 0
+s_mov_b32 {st(1)}, 0xffff0000
+s_mov_b64 exec, {stp(0)}
+v_mul_f64 {vp('D',1)}, {vp('D',0)}, {sp('zFix')}
+v_cmp_nlt_f64 vcc, |{vp('D',0)}|, {sp('zsafe')}
+s_mov_b64 exec, -1
+v_rndne_f64 {vp('D',1)}, {vp('D',1)}
+v_mov_b32 {v('T')}, 0x7fff
+v_mov_b32 {v('T',1)}, 0xffff8001
+v_cvt_i32_f64 {v('D',4)}, {vp('D',1)}
+s_bfe_u32 {s('ua')}, vcc_hi, 0x10010
+v_med3_i32 {v('D',5)}, {v('D',4)}, {v('T')}, {v('T',1)}
+v_readlane_b32 {s('Q',0)}, {v('D',0)}, 16
+v_readlane_b32 {s('Q',1)}, {v('D',1)}, 16
+v_readlane_b32 {s('Q',2)}, {v('D',0)}, 32
+v_readlane_b32 {s('Q',3)}, {v('D',1)}, 32
+v_readlane_b32 {s('Q',4)}, {v('D',0)}, 48
+v_readlane_b32 {s('Q',5)}, {v('D',1)}, 48
+v_readlane_b32 {st(0)}, {v('D',4)}, 16
+v_readlane_b32 {st(1)}, {v('D',4)}, 32
+v_readlane_b32 {st(2)}, {v('D',5)}, 48
+s_and_b32 {st(0)}, {st(0)}, 0xffff
+s_lshl_b32 {st(1)}, {st(1)}, 16
+s_or_b32 {st(0)}, {st(0)}, {st(1)}
+s_and_b32 {s('az16')}, {st(2)}, 0xffff
+s_mul_i32 {s('azz')}, {s('az16')}, 0x10001
+v_mov_b32 {v('axy')}, {st(0)}
+""")
+E(f"s_cmp_eq_u32 {s('cross')}, 1")
+E("s_cbranch_scc0 L_nocross")
+rotate("r2")
+E(f"s_mov_b32 {s('tl')}, -1")
+E("L_nocross:")
+E(f"s_add_u32 {s('tl')}, {s('tl')}, 1")
+E("L_noB:")
+E(f"""
+s_add_u32 {s('i')}, {s('i')}, 1
+s_mov_b32 {s('hasA')}, 1
+s_add_u32 {st(0)}, {s('i')}, 1
+s_cmp_lt_i32 {st(0)}, {s('len')}
+s_cselect_b32 {s('hasB')}, 1, 0
+s_cmp_lt_i32 {s('i')}, {s('len')}
+s_cbranch_scc1 L_move
+L_run_next:
+s_add_u32 {s('run')}, {s('run')}, 1
+s_cmp_lt_u32 {s('run')}, 2
+s_cbranch_scc1 L_run
+// C: rec[sw] = (E, accepted) for the bookkeeping kernel (SMC.c:194-195)
+v_mov_b32 v14, {s('E')}
+v_mov_b32 v15, {s('E',1)}
+v_mov_b32 v16, {s('jacc')}
+v_mov_b32 v17, 0
+s_lshl_b32 {st(0)}, {s('sw')}, 4
+v_mov_b32 v18, {st(0)}
+s_mov_b64 exec, 1
+s_nop 1
+global_store_dwordx4 v18, v[14:17], {sp('rec')}
+s_mov_b64 exec, -1
+s_add_u32 {s('sw')}, {s('sw')}, 1
+s_cmp_lt_u32 {s('sw')}, {s('nsw')}
+s_cbranch_scc1 L_sweep
+// end stamp
+s_memtime {stp(4)}
+s_memrealtime {stp(6)}
+s_waitcnt lgkmcnt(0)
+v_mov_b32 v14, 16
+v_mov_b32 v16, {st(4)}
+v_mov_b32 v17, {st(5)}
+v_mov_b32 v18, {st(6)}
+v_mov_b32 v19, {st(7)}
+s_mov_b64 exec, 1
+s_nop 1
+global_store_dwordx4 v14, v[16:19], {sp('clk')}
+s_mov_b64 exec, -1
+s_waitcnt vmcnt(0) lgkmcnt(0)
+""")
+
+with open(sys.argv[1] if len(sys.argv) > 1 else "smcx_sweep_ma_body.inc", "w") as f:
+    f.write("// generated by gen_sweep_ma.py -- do not edit\n")
+    for ln in out:
+        f.write('"%s\\n\\t"\n' % ln)
+print("%d lines" % len(out), file=sys.stderr)

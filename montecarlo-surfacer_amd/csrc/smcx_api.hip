@@ -241,7 +241,7 @@ extern "C" int smcx_destroy(smcx_handle *hh)
     hipFree(c.uni); hipFree(c.offs); hipFree(c.obs); hipFree(c.zhist); hipFree(c.Eseries);
     hipFree(c.jjseries); hipFree(c.rec); hipFree(h.d_save); hipFree(h.d_tmp);
     hipFree(c.D); hipFree(c.Mu); hipFree(c.Rbin); hipFree(c.Pseries);
-    hipFree(h.lca_bits); hipFree(h.lca_counts); hipFree(c.clk);
+    hipFree(h.lca_bits); hipFree(h.lca_counts); hipFree(c.clk); hipFree((void *)c.wtab);
 #ifdef SMCX_CHECK
     hipFree(c.dbg);
 #endif
@@ -303,6 +303,7 @@ extern "C" int smcx_create(const smcx_params *p, smcx_handle **out)
     CRT(hipMalloc(&c.obs, nrep * sizeof(ObsRec)));
     CRT(hipMalloc(&c.rec, nrep * h.chunk * sizeof(SweepRec)));
     CRT(hipMalloc(&c.zhist, nrep * p->Ncz * sizeof(unsigned long long)));
+    CRT(hipMalloc((void **)&c.wtab, (size_t)(c.M2 + 1) * 4 * sizeof(double)));
     CRT(hipMalloc(&c.clk, nrep * 4 * sizeof(unsigned long long)));
     CRT(hipMemset(c.clk, 0, nrep * 4 * sizeof(unsigned long long)));
     CRT(hipMalloc(&h.d_save, nrep * sizeof(double)));
@@ -366,7 +367,7 @@ extern "C" int smcx_kernel_form(const smcx_handle *hh, int *form, char *name, in
     if (form) *form = mx ? 2 : 1;
     const bool mi = mx && mi_supported(h.S, h.WPR, h.p.L, h.p.Lz, h.p.cutoff * h.p.cutoff);
     if (name && len > 0)
-        std::snprintf(name, (size_t)len, "%s", mi ? mi_kernel_name(h.S, h.p.L, h.p.Lz)
+        std::snprintf(name, (size_t)len, "%s", mi ? mi_kernel_name(h.S, h.p.N, h.p.L, h.p.Lz)
                                                   : mx ? mx_kernel_name(h.S, h.WPR, h.p.Lz) : fp64_kernel_name(h.S, h.WPR));
     return SMCX_OK;
 }
@@ -408,6 +409,16 @@ extern "C" int smcx_upload(smcx_handle *hh, const double *R0, int r0_per_replica
     }
     if (W)
         HIPCHK(&h, hipMemcpy((void *)c.W, W, 2 * (size_t)c.M2 * sizeof(double), hipMemcpyHostToDevice));
+    {   // wall table of sweep_kernel_ma: per site its position (i dw, j dw) (SMC.c:748-750) and strengths, the plane last
+        std::vector<double> wt((size_t)(c.M2 + 1) * 4, 0.0);
+        const double dw = p.L / p.M;
+        for (int m = 0; m < c.M2; m++) {
+            wt[4 * m] = (m / p.M) * dw; wt[4 * m + 1] = (m % p.M) * dw;
+            wt[4 * m + 2] = W ? W[2 * m] : 0.0; wt[4 * m + 3] = W ? W[2 * m + 1] : 0.0;
+        }
+        wt[4 * c.M2 + 2] = p.a0; wt[4 * c.M2 + 3] = p.b0;
+        HIPCHK(&h, hipMemcpy((void *)c.wtab, wt.data(), wt.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
     std::vector<uint32_t> st(nrep * 32);
     for (size_t r = 0; r < nrep; r++) {
         const uint32_t seed = seeds ? seeds[r] : (uint32_t)(p.base_seed + p.first_replica + r);

@@ -72,6 +72,7 @@ struct DevCtx {
     double *Pseries;              // [nrep][pstride] pressure + wallsPressure per gather (SMC.c:140)
     int pstride;
     unsigned long long *clk;      // [nrep][4] shader-clock and 100 MHz stamps of the last sweep launch (see SweepArgs)
+    const double *wtab;           // [M2 + 1][4] wall table of sweep_kernel_ma: site x, y, W[2m], W[2m+1]; plane last
 #ifdef SMCX_CHECK
     unsigned long long *dbg;      // [4] diagnostic build only (see SweepArgs)
 #endif

@@ -19,10 +19,16 @@ hipError_t launch_sweeps_mx(const SweepArgs &a, const DevCtx &c, int S, int WPR,
 
 // integer-screen sweep kernel for one wavefront per replica (smcx_sweep_mi.hip)
 bool mi_supported(int S, int WPR, double L, double Lz, double cutoff2);
-const char *mi_kernel_name(int S, double L, double Lz);
+const char *mi_kernel_name(int S, int N, double L, double Lz);
 void mi_bound_values(double L, double Lz, double cutoff2, double *thr, double *u2, double *toFix, double *zsafe,
                      double *uz, int *negC, int *zshift);
 hipError_t launch_sweeps_mi(const SweepArgs &a, const DevCtx &c, int S, int nsweeps, double A, hipStream_t st);
+
+// hand-scheduled form of the same kernel for 64 particles per lane (smcx_sweep_ma.hip)
+bool ma_supported(int S, int WPR, int N, int M2);
+const char *ma_kernel_name();
+hipError_t launch_sweeps_ma(const SweepArgs &s, const DevCtx &c, const double *wtab, int nsweeps, double A,
+                            double toFix, double zFix, double zsafe, int negC, hipStream_t st);
 
 hipError_t launch_rng_prepass(const DevCtx &c, int nsweeps, double A, hipStream_t st);
 // kernel: 0 = auto, 1 = fp64 kernels, 2 = screened kernel (smcx_sweep_mx.hip)
