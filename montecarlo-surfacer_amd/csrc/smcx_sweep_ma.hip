@@ -62,6 +62,9 @@ __global__ void __launch_bounds__(64, 4) sweep_kernel_ma(MaArgs a)
 
 bool ma_supported(int S, int WPR, int N, int M2)
 {
+#ifdef SMCX_CHECK
+    return false; // the diagnostic build counts the screen's misses in sweep_kernel_mi (same screen, hipcc-scheduled)
+#endif
     static const char *env = getenv("SMCX_MA"); // SMCX_MA=0: sweep_kernel_mi instead, for A/B measurements
     if (env && env[0] == '0') return false;
     return S == 64 && WPR == 1 && N > 2048 && N <= 4096 && M2 + 1 <= 30;

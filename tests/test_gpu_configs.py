@@ -152,6 +152,46 @@ def test_screen_ab_against_fp64_kernel_at_scale(S, O, N, lat, nrep, nsw, mx_geom
     assert diverged <= max(1, nrep // 50), diverged
 
 
+_MI_WORKER = r"""
+import sys, os
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+import numpy as np, torch
+import smcx_loader
+S = smcx_loader.load()
+N, Na, Nz, nrep, nsw = (int(v) for v in sys.argv[3:8])
+p = S.default_params(N, nrep, flags=S.FLAG_WALLS | S.FLAG_SERIES, tune_slots=64, tune_waves=1)
+with S.Engine(p) as eng:
+    name = eng.kernel_form[1]
+    eng.upload(S.fcc_init(Na, Nz), S.W_REFERENCE)
+    eng.run(0, nsw, nsw)
+    E, jj = eng.series(nsw)
+    np.savez(sys.argv[2], E=E, jj=jj, R=eng.positions(), name=name)
+"""
+
+
+@pytest.mark.parametrize("N,lat,nrep,nsw", [(4096, (8, 16), 4096, 3), (4000, (10, 10), 64, 3)])
+def test_hand_scheduled_kernel_matches_compiled_kernel(S, O, tmp_path, N, lat, nrep, nsw):
+    """sweep_kernel_ma (hand-scheduled, the benchmark's kernel) against sweep_kernel_mi (the same algorithm
+    compiled by hipcc, whose screen the miss counter of the diagnostic build validates) on the whole bench
+    workload: 4096 replicas x 3 sweeps = 5e7 moves, and a ragged N with padding slots.  Both evaluate the
+    same pairs in the same lanes and rounds; they differ in the Metropolis arithmetic's association
+    (row layout), i.e. by rounding.  A pair missed by either screen would shift E by >= 5e-3."""
+    w = tmp_path / "mi_worker.py"
+    w.write_text(_MI_WORKER)
+    out = {}
+    for tag, env in (("ma", {}), ("mi", {"SMCX_MA": "0"})):
+        f = str(tmp_path / (tag + ".npz"))
+        r = subprocess.run([sys.executable, str(w), ROOT, f, str(N), str(lat[0]), str(lat[1]), str(nrep), str(nsw)],
+                           env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        out[tag] = np.load(f)
+    assert str(out["ma"]["name"]) == "smcx::sweep_kernel_ma" and "sweep_kernel_mi" in str(out["mi"]["name"])
+    assert np.array_equal(out["ma"]["jj"], out["mi"]["jj"]) and out["ma"]["jj"].sum() > 0
+    dE = np.abs(out["ma"]["E"] - out["mi"]["E"])
+    assert np.all(dE <= 1e-9 * (1.0 + np.abs(out["mi"]["E"]))), dE.max()
+    assert np.abs(out["ma"]["R"] - out["mi"]["R"]).max() < 1e-8
+
+
 def _load_check_build():
     path = os.path.join(ROOT, "montecarlo-surfacer_amd", "libsmcx_check.so")
     if not os.path.exists(path):
