@@ -383,112 +383,50 @@ L_nob1:
 # ---------------------------------------------------------------------------------------------- screen
 
 
-def screen_group(k0, zlo, zhi, wa, wb):
-    """slots k0..k0+3, z words zlo = slots (k0, k0+1), zhi = (k0+2, k0+3); descending slot order"""
-    a = ["v%d" % (V['t'] + j) for j in range(4)]       # slots k0+3, k0+2, k0+1, k0 of probe A
-    b = ["v%d" % (V['t'] + 4 + j) for j in range(4)]
-    za1, zb1, za0, zb0 = ["v%d" % (V['t'] + 8 + j) for j in range(4)]
+def screen_group(k0, zlo, zhi, pxy, pzz, w):
+    """one probe against slots k0..k0+3 (z words zlo = slots (k0, k0+1), zhi = (k0+2, k0+3)), descending slot
+    order: 22 instructions, four chains; every result is consumed at least four instructions after its issue
+    (six for the v_dot2 results)"""
+    a = ["v%d" % (V['t'] + j) for j in range(4)]       # slots k0+3, k0+2, k0+1, k0
+    z1, z0 = "v%d" % (V['t'] + 4), "v%d" % (V['t'] + 5)
     X = [xy(k0 + 3), xy(k0 + 2), xy(k0 + 1), xy(k0)]
     for j in range(4):
-        E(f"v_sub_u32 {a[j]}, {v('axy')}, {X[j]}")
-        E(f"v_sub_u32 {b[j]}, {v('bxy')}, {X[j]}")
+        E(f"v_sub_u32 {a[j]}, {pxy}, {X[j]}")
     for j in range(4):
         E(f"v_dot2_i32_i16 {a[j]}, {a[j]}, {a[j]}, {s('negC')}")
-        E(f"v_dot2_i32_i16 {b[j]}, {b[j]}, {b[j]}, {s('negC')}")
-    E(f"v_pk_sub_i16 {za1}, {s('azz')}, {zhi} clamp")
-    E(f"v_pk_sub_i16 {zb1}, {s('bzz')}, {zhi} clamp")
-    E(f"v_pk_sub_i16 {za0}, {s('azz')}, {zlo} clamp")
-    E(f"v_pk_sub_i16 {zb0}, {s('bzz')}, {zlo} clamp")
+    E(f"v_pk_sub_i16 {z1}, {pzz}, {zhi} clamp")
+    E(f"v_pk_sub_i16 {z0}, {pzz}, {zlo} clamp")
     for j in range(4):
         E(f"v_ashrrev_i32 {a[j]}, {2 * ZS}, {a[j]}")
-        E(f"v_ashrrev_i32 {b[j]}, {2 * ZS}, {b[j]}")
-    zA = [za1, za1, za0, za0]
-    zB = [zb1, zb1, zb0, zb0]
+    zz = [z1, z1, z0, z0]
     hi = [True, False, True, False]
     for j in range(4):
         sel = " op_sel:[1,1,0,0]" if hi[j] else ""
-        E(f"v_mad_i32_i16 {a[j]}, {zA[j]}, {zA[j]}, {a[j]}{sel}")
-        E(f"v_mad_i32_i16 {b[j]}, {zB[j]}, {zB[j]}, {b[j]}{sel}")
+        E(f"v_mad_i32_i16 {a[j]}, {zz[j]}, {zz[j]}, {a[j]}{sel}")
     for j in range(4):
-        E(f"v_alignbit_b32 {wa}, {wa}, {a[j]}, 31")
-        E(f"v_alignbit_b32 {wb}, {wb}, {b[j]}, 31")
+        E(f"v_alignbit_b32 {w}, {w}, {a[j]}, 31")
 
 
-E(f"""
-v_mov_b32 {v('wa0')}, 0
-v_mov_b32 {v('wa1')}, 0
-v_mov_b32 {v('wb0')}, 0
-v_mov_b32 {v('wb1')}, 0
-ds_read2st64_b32 v[{V['zA']}:{V['zA']+1}], {v('zaddr')} offset0:30 offset1:31
-ds_read2st64_b32 v[{V['zB']}:{V['zB']+1}], {v('zaddr')} offset0:28 offset1:29
-""")
-groups = list(range(60, -1, -4))
-for gi, k0 in enumerate(groups):
-    buf = 'zA' if gi % 2 == 0 else 'zB'
-    E("s_waitcnt lgkmcnt(1)" if gi < len(groups) - 1 else "s_waitcnt lgkmcnt(0)")
-    w = 1 if k0 >= 32 else 0
-    screen_group(k0, "v%d" % V[buf], "v%d" % (V[buf] + 1), v('wa%d' % w), v('wb%d' % w))
-    if gi + 2 < len(groups):
-        nk = groups[gi + 2]
-        E(f"ds_read2st64_b32 v[{V[buf]}:{V[buf]+1}], {v('zaddr')} offset0:{nk // 2} offset1:{nk // 2 + 1}")
-
-# ---------------------------------------------------------------------------------------------- fix-ups
-E(f"""
-// log-uniform of move i+1: scalar load, asked for after the screen (an SMEM in flight would turn the
-// screen's counted LDS waits into full drains), used at the end of the move
-s_cmp_eq_u32 {s('hasB')}, 0
-s_cbranch_scc1 L_nolu
-s_add_u32 {st(0)}, {s('i')}, 1
-s_lshl_b32 {st(0)}, {st(0)}, 3
-s_load_dwordx2 {sp('nlu')}, {sp('uK')}, {st(0)}
-L_nolu:
-v_or_b32 {v('wa0')}, {v('wa0')}, {v('uns0')}
-v_or_b32 {v('wa1')}, {v('wa1')}, {v('uns1')}
-v_or_b32 {v('wb0')}, {v('wb0')}, {v('uns0')}
-v_or_b32 {v('wb1')}, {v('wb1')}, {v('uns1')}
-s_cmp_eq_u32 {s('ua')}, 0
-s_cbranch_scc1 L_ua0
-v_mov_b32 {v('wa0')}, -1
-v_mov_b32 {v('wa1')}, -1
-L_ua0:
-s_cmp_eq_u32 {s('ub')}, 0
-s_cbranch_scc1 L_ub0
-v_mov_b32 {v('wb0')}, -1
-v_mov_b32 {v('wb1')}, -1
-L_ub0:
-s_cmp_eq_u32 {s('hasA')}, 0
-s_cbranch_scc0 L_hasA1
-v_mov_b32 {v('wa0')}, 0
-v_mov_b32 {v('wa1')}, 0
-s_branch L_exB
-L_hasA1:
-// the moving particle itself (slot 0 of lane tl): not a neighbour of A, and it reaches B through the side pair
-s_lshl_b64 {stp(0)}, 1, {s('tl')}
-s_mov_b64 exec, {stp(0)}
-v_and_b32 {v('wa0')}, -2, {v('wa0')}
-v_and_b32 {v('wb0')}, -2, {v('wb0')}
-s_mov_b64 exec, -1
-L_exB:
-s_cmp_eq_u32 {s('hasB')}, 0
-s_cbranch_scc0 L_hasB1
-v_mov_b32 {v('wb0')}, 0
-v_mov_b32 {v('wb1')}, 0
-s_branch L_fixdone
-L_hasB1:
-// the particle probe B stands for: slot 0 of lane tl+1, or slot 1 of lane 0 when the order crosses slots
-s_lshl_b64 {stp(0)}, 1, {s('lb')}
-s_mov_b64 exec, {stp(0)}
-s_cmp_eq_u32 {s('cross')}, 1
-s_cbranch_scc1 L_exBc
-v_and_b32 {v('wb0')}, -2, {v('wb0')}
-s_branch L_fixdone
-L_exBc:
-v_and_b32 {v('wb0')}, -3, {v('wb0')}
-L_fixdone:
-s_mov_b64 exec, -1
-""")
+def screen_pass(pxy, pzz, w0, w1):
+    """candidate bits of one probe: 16 groups, the z words read two groups ahead (counted LDS waits: nothing
+    else may be in flight on the LDS / scalar-memory counter while a pass runs)"""
+    E(f"""
+    v_mov_b32 {w0}, 0
+    v_mov_b32 {w1}, 0
+    ds_read2st64_b32 v[{V['zA']}:{V['zA']+1}], {v('zaddr')} offset0:30 offset1:31
+    ds_read2st64_b32 v[{V['zB']}:{V['zB']+1}], {v('zaddr')} offset0:28 offset1:29
+    """)
+    groups = list(range(60, -1, -4))
+    for gi, k0 in enumerate(groups):
+        buf = 'zA' if gi % 2 == 0 else 'zB'
+        E("s_waitcnt lgkmcnt(1)" if gi < len(groups) - 1 else "s_waitcnt lgkmcnt(0)")
+        screen_group(k0, "v%d" % V[buf], "v%d" % (V[buf] + 1), pxy, pzz, w1 if k0 >= 32 else w0)
+        if gi + 2 < len(groups):
+            nk = groups[gi + 2]
+            E(f"ds_read2st64_b32 v[{V[buf]}:{V[buf]+1}], {v('zaddr')} offset0:{nk // 2} offset1:{nk // 2 + 1}")
 
 
+# ---------------------------------------------------------------------------------------------- helpers
 def pick_fetch(w0, w1, X, spec_mask, have):
     """lanes with a candidate (and not in spec_mask) take their lowest one out of w and load its fp64
     position into X[0:5]; `have` (s pair) <- the lanes whose load is in flight"""
@@ -516,23 +454,22 @@ def pick_fetch(w0, w1, X, spec_mask, have):
     """)
 
 
-def coeff_one():
+def coeff_one(C):
     E(f"""
-    v_mov_b32 {v('C',0)}, 0
-    v_mov_b32 {v('C',1)}, {ONE_HI}
-    v_mov_b32 {v('C',2)}, 0
-    v_mov_b32 {v('C',3)}, {ONE_HI}
+    v_mov_b64 v[{C}:{C+1}], 1.0
+    v_mov_b64 v[{C+2}:{C+3}], 1.0
     """)
 
 
-def wall_fetch(X, with_pos=True):
-    """lanes 0..M2: site position (sx, sy) into X[0:3] and the coefficients (ca, cb) into C, from the table"""
-    coeff_one()
+def wall_fetch(X, C):
+    """lanes 0..M2: site position (sx, sy) into X[0:3] and the coefficients (ca, cb) into C[0:3], from the table;
+    every other lane's coefficients are 1"""
+    coeff_one(C)
     E(f"""
     s_mov_b64 exec, {sp('wallM')}
     v_lshlrev_b32 v46, 5, {LANE}
     global_load_dwordx4 v[{X}:{X+3}], v46, {sp('wtab')}
-    global_load_dwordx4 v[{V['C']}:{V['C']+3}], v46, {sp('wtab')} offset:16
+    global_load_dwordx4 v[{C}:{C+3}], v46, {sp('wtab')} offset:16
     s_mov_b64 exec, -1
     """)
 
@@ -564,7 +501,7 @@ def wall_dz(tag, pz_is_sgpr, pz):
     """)
 
 
-def body(tag, P, X, items, round0):
+def body(tag, P, X, C, items, round0):
     """the fp64 body for the lanes in `items` (s pair): d = probe - X, the walls' dz, signed minimum image,
     the plane's rules, cutoff test, lj_acc's sequence (SMC.c:567-578, 601-614, 740-761, 787-809)"""
     E(f"""
@@ -616,8 +553,8 @@ def body(tag, P, X, items, round0):
     v_fma_f64 {vp('ir2')}, {vp('T')}, {vp('ir2')}, {vp('ir2')}
     v_mul_f64 {vp('T')}, {vp('ir2')}, {vp('ir2')}
     v_mul_f64 {vp('S6')}, {vp('T')}, {vp('ir2')}
-    v_mul_f64 {vp('T')}, {vp('C',0)}, {vp('S6')}
-    v_mul_f64 {vp('F')}, {vp('C',1)}, {vp('S6')}
+    v_mul_f64 {vp('T')}, v[{C}:{C+1}], {vp('S6')}
+    v_mul_f64 {vp('F')}, v[{C+2}:{C+3}], {vp('S6')}
     v_mul_f64 {vp('T')}, {vp('T')}, {vp('S6')}
     v_add_f64 {vp('S6')}, {vp('T')}, -{vp('F')}
     v_mul_f64 {vp('F')}, {vp('F')}, {sp('neg24')}
@@ -660,11 +597,11 @@ def reduce4(dst):
         """)
 
 
-def probe(tag, P, pz_sgpr, pz, w0, w1, X, have, side):
+def probe(tag, P, pz_sgpr, pz, w0, w1, X, C, have, side, wait):
     """a whole probe: round 0 (specials + the first candidates, already requested into X / `have`), then
-    further rounds while any lane still has a candidate"""
-    for j in range(8):
-        E(f"v_mov_b32 v{V['acc'] + j}, 0")
+    further rounds while any lane still has a candidate.  `wait`: the s_waitcnt that covers round 0's loads"""
+    for j in range(4):
+        E(f"v_mov_b64 {vp('acc', j)}, 0")
     E(f"s_cmp_lg_u64 {sp('wallM')}, 0")
     E(f"s_cbranch_scc0 L_nw_{tag}")
     wall_dz(tag, pz_sgpr, pz)
@@ -675,45 +612,107 @@ def probe(tag, P, pz_sgpr, pz, w0, w1, X, have, side):
         E(f"s_cbranch_scc1 L_noside_{tag}")
         E(f"s_or_b64 {stp(6)}, {stp(6)}, {sp('sideM')}")
         E(f"L_noside_{tag}:")
-    E("s_waitcnt vmcnt(0) lgkmcnt(0)")
-    body(tag + "r0", P, X, stp(6), True)
+    E(wait)
+    body(tag + "r0", P, X, C, stp(6), True)
     E(f"""
     L_more_{tag}:
     v_cmp_ne_u64 vcc, 0, v[{w0}:{w1}]
     s_cmp_lg_u64 vcc, 0
     s_cbranch_scc0 L_done_{tag}
     """)
-    coeff_one()
+    coeff_one(C)
     pick_fetch(w0, w1, X, "0", stp(6))
     E("s_waitcnt vmcnt(0)")
-    body(tag + "rm", P, X, stp(6), False)
+    body(tag + "rm", P, X, C, stp(6), False)
     E(f"s_branch L_more_{tag}")
     E(f"L_done_{tag}:")
 
 
-# ---- the first candidate of both probes; probe A's wall table rows
-E(f"s_mov_b64 {sp('haveA')}, 0")
-E(f"s_mov_b64 {sp('haveB')}, 0")
-E(f"s_cmp_eq_u32 {s('hasA')}, 0")
-E("s_cbranch_scc1 L_nofa")
-pick_fetch(V['wa0'], V['wa1'], V['XA'], sp('wallM'), sp('haveA'))
-wall_fetch(V['XA'])
+XA_, CA_, XB_, CB_ = 30, 26, 20, 10   # round-0 data: A in the D registers (d = p - X in place), B in v20..25; coefficients
+
+# ---------------------------------------------------------------------------------------------- screen + fetch, probe A first
+screen_pass(v('axy'), s('azz'), v('wa0'), v('wa1'))
+E(f"""
+v_or_b32 {v('wa0')}, {v('wa0')}, {v('uns0')}
+v_or_b32 {v('wa1')}, {v('wa1')}, {v('uns1')}
+s_mov_b64 {sp('haveA')}, 0
+s_cmp_eq_u32 {s('hasA')}, 0
+s_cbranch_scc1 L_nofa
+s_cmp_eq_u32 {s('ua')}, 0
+s_cbranch_scc1 L_ua0
+v_mov_b32 {v('wa0')}, -1
+v_mov_b32 {v('wa1')}, -1
+L_ua0:
+// the moving particle itself (slot 0 of lane tl) is not a neighbour of its proposal
+s_lshl_b64 {stp(0)}, 1, {s('tl')}
+s_mov_b64 exec, {stp(0)}
+v_and_b32 {v('wa0')}, -2, {v('wa0')}
+s_mov_b64 exec, -1
+""")
+pick_fetch(V['wa0'], V['wa1'], XA_, sp('wallM'), sp('haveA'))
+wall_fetch(XA_, CA_)
 E("L_nofa:")
-E(f"s_cmp_eq_u32 {s('hasB')}, 0")
-E("s_cbranch_scc1 L_nofb")
-E(f"s_mov_b64 {stp(0)}, {sp('wallM')}")
-E(f"s_cmp_eq_u32 {s('hasA')}, 0")
-E("s_cbranch_scc1 L_fb1")
-E(f"s_or_b64 {stp(0)}, {sp('wallM')}, {sp('sideM')}")
-E("L_fb1:")
-pick_fetch(V['wb0'], V['wb1'], V['XB'], stp(0), sp('haveB'))
-E("L_nofb:")
+screen_pass(v('bxy'), s('bzz'), v('wb0'), v('wb1'))
+E(f"""
+v_or_b32 {v('wb0')}, {v('wb0')}, {v('uns0')}
+v_or_b32 {v('wb1')}, {v('wb1')}, {v('uns1')}
+s_mov_b64 {sp('haveB')}, 0
+s_cmp_eq_u32 {s('hasB')}, 0
+s_cbranch_scc1 L_nofb0
+// log-uniform of move i+1 (scalar load: only now that no screen pass is running on the LDS counter)
+s_add_u32 {st(0)}, {s('i')}, 1
+s_lshl_b32 {st(0)}, {st(0)}, 3
+s_load_dwordx2 {sp('nlu')}, {sp('uK')}, {st(0)}
+s_cmp_eq_u32 {s('ub')}, 0
+s_cbranch_scc1 L_ub0
+v_mov_b32 {v('wb0')}, -1
+v_mov_b32 {v('wb1')}, -1
+L_ub0:
+// not neighbours of B: the particle it stands for (slot 0 of lane tl+1, or slot 1 of lane 0 when the order
+// crosses slots) and the moving particle n (slot 0 of lane tl), which reaches B through the side pair
+s_lshl_b64 {stp(0)}, 1, {s('lb')}
+s_mov_b64 exec, {stp(0)}
+s_cmp_eq_u32 {s('cross')}, 1
+s_cbranch_scc1 L_exBc
+v_and_b32 {v('wb0')}, -2, {v('wb0')}
+s_branch L_exBd
+L_exBc:
+v_and_b32 {v('wb0')}, -3, {v('wb0')}
+L_exBd:
+s_mov_b64 {stp(0)}, {sp('wallM')}
+s_cmp_eq_u32 {s('hasA')}, 0
+s_cbranch_scc1 L_fb1
+s_lshl_b64 {stp(2)}, 1, {s('tl')}
+s_mov_b64 exec, {stp(2)}
+v_and_b32 {v('wb0')}, -2, {v('wb0')}
+s_or_b64 {stp(0)}, {sp('wallM')}, {sp('sideM')}
+L_fb1:
+s_mov_b64 exec, -1
+// probe A's data has had the whole second pass to arrive; B's travels while probe A is evaluated
+s_waitcnt vmcnt(0)
+""")
+pick_fetch(V['wb0'], V['wb1'], XB_, stp(0), sp('haveB'))
+wall_fetch(XB_, CB_)
+E(f"""
+// probe B's fp64 position from the LDS cache: row = cross ? 64 : tl + 1
+s_cmp_eq_u32 {s('cross')}, 1
+s_cselect_b32 {st(0)}, 64, {s('lb')}
+s_mul_i32 {st(0)}, {st(0)}, 24
+v_mov_b32 {v('T')}, {st(0)}
+ds_read_b64 v[14:15], {v('T')} offset:{LDS_P0}
+ds_read_b64 v[16:17], {v('T')} offset:{LDS_P0 + 8}
+ds_read_b64 v[18:19], {v('T')} offset:{LDS_P0 + 16}
+s_branch L_nofb
+L_nofb0:
+s_waitcnt vmcnt(0)
+L_nofb:
+""")
 
 # ---------------------------------------------------------------------------------------------- probe A + Metropolis
 E(f"s_cmp_eq_u32 {s('hasA')}, 0")
 E("s_cbranch_scc1 L_noA")
 QP = [sp('Q', 0), sp('Q', 1), sp('Q', 2)]
-probe("A", QP, True, (s('Q', 4), s('Q', 5)), V['wa0'], V['wa1'], V['XA'], sp('haveA'), False)
+probe("A", QP, True, (s('Q', 4), s('Q', 5)), V['wa0'], V['wa1'], XA_, CA_, sp('haveA'), False, "s_nop 0")
 FnV = vp('M', 0)          # v[36:37]: the body's M registers are free now
 reduce4(FnV)
 E(f"""
@@ -767,20 +766,20 @@ v_mov_b32 {xy(0)}, {v('axy')}
 v_and_b32 {v('uns0')}, -2, {v('uns0')}
 v_or_b32 {v('uns0')}, {s('ua')}, {v('uns0')}
 v_mov_b32 {v('T')}, {s('az16')}
-v_mov_b32 v14, {s('Q',0)}
-v_mov_b32 v15, {s('Q',1)}
-v_mov_b32 v16, {s('Q',2)}
-v_mov_b32 v17, {s('Q',3)}
-v_mov_b32 v18, {s('Q',4)}
-v_mov_b32 v19, {s('Q',5)}
+v_mov_b32 v50, {s('Q',0)}
+v_mov_b32 v51, {s('Q',1)}
+v_mov_b32 v52, {s('Q',2)}
+v_mov_b32 v53, {s('Q',3)}
+v_mov_b32 v54, {s('Q',4)}
+v_mov_b32 v55, {s('Q',5)}
 v_mov_b32 {v('T',1)}, {st(2)}
 v_mul_u32_u24 {v('S6')}, 24, {LANE}
 ds_write_b16 {v('zaddr')}, {v('T')}
-global_store_dwordx4 {v('T',1)}, v[14:17], {sp('Rg')}
-global_store_dwordx2 {v('T',1)}, v[18:19], {sp('Rg')} offset:16
-ds_write_b64 {v('S6')}, v[14:15] offset:{LDS_P0}
-ds_write_b64 {v('S6')}, v[16:17] offset:{LDS_P0 + 8}
-ds_write_b64 {v('S6')}, v[18:19] offset:{LDS_P0 + 16}
+global_store_dwordx4 {v('T',1)}, v[50:53], {sp('Rg')}
+global_store_dwordx2 {v('T',1)}, v[54:55], {sp('Rg')} offset:16
+ds_write_b64 {v('S6')}, v[50:51] offset:{LDS_P0}
+ds_write_b64 {v('S6')}, v[52:53] offset:{LDS_P0 + 8}
+ds_write_b64 {v('S6')}, v[54:55] offset:{LDS_P0 + 16}
 s_mov_b64 exec, -1
 s_nop 1
 L_reject:
@@ -791,32 +790,31 @@ L_noA:
 E(f"s_cmp_eq_u32 {s('hasB')}, 0")
 E("s_cbranch_scc1 L_noB")
 E(f"""
-// probe B's fp64 position from the LDS cache: row = cross ? 64 : tl + 1
-s_cmp_eq_u32 {s('cross')}, 1
-s_cselect_b32 {st(0)}, 64, {s('lb')}
-s_mul_i32 {st(0)}, {st(0)}, 24
-v_mov_b32 {v('T')}, {st(0)}
-ds_read_b64 v[14:15], {v('T')} offset:{LDS_P0}
-ds_read_b64 v[16:17], {v('T')} offset:{LDS_P0 + 8}
-ds_read_b64 v[18:19], {v('T')} offset:{LDS_P0 + 16}
-""")
-wall_fetch(V['XB'])
-E(f"""
+// per-row component offset: rows 1..3 -> 0, 8, 16 (row 0 idles along with component 0)
+v_lshrrev_b32 {v('T')}, 4, {LANE}
+v_add_u32 {v('T')}, -1, {v('T')}
+v_max_i32 {v('T')}, 0, {v('T')}
+v_lshlrev_b32 {v('T')}, 3, {v('T')}
+s_add_u32 {st(1)}, {s('i')}, 1
+s_mul_i32 {st(1)}, {st(1)}, 24
+v_add_u32 {v('S6')}, {st(1)}, {v('T')}
 // the side pair's source on lane 30: particle n where the move left it = p0[tl]
 s_cmp_eq_u32 {s('hasA')}, 0
 s_cbranch_scc1 L_nosrc
 s_mul_i32 {st(0)}, {s('tl')}, 24
 v_mov_b32 {v('T')}, {st(0)}
 s_mov_b64 exec, {sp('sideM')}
-ds_read_b64 v[{V['XB']}:{V['XB']+1}], {v('T')} offset:{LDS_P0}
-ds_read_b64 v[{V['XB']+2}:{V['XB']+3}], {v('T')} offset:{LDS_P0 + 8}
-ds_read_b64 v[{V['XB']+4}:{V['XB']+5}], {v('T')} offset:{LDS_P0 + 16}
+ds_read_b64 v[{XB_}:{XB_+1}], {v('T')} offset:{LDS_P0}
+ds_read_b64 v[{XB_+2}:{XB_+3}], {v('T')} offset:{LDS_P0 + 8}
+ds_read_b64 v[{XB_+4}:{XB_+5}], {v('T')} offset:{LDS_P0 + 16}
 s_mov_b64 exec, -1
 L_nosrc:
+// displacement of move i+1 per row: asked for now, needed after probe B
+global_load_dwordx2 {vp('DdV')}, {v('S6')}, {sp('dK')}
+s_waitcnt lgkmcnt(0)
 """)
-E("s_waitcnt lgkmcnt(0)")
 BP = ["v[14:15]", "v[16:17]", "v[18:19]"]
-probe("B", BP, False, "v[18:19]", V['wb0'], V['wb1'], V['XB'], sp('haveB'), True)
+probe("B", BP, False, "v[18:19]", V['wb0'], V['wb1'], XB_, CB_, sp('haveB'), True, "s_waitcnt vmcnt(1)")
 reduce4(vp('FmV'))
 E(f"""
 // ---- proposal of particle n+1 in row layout (SMC.c:307-316): q = p + (Fm A/T + displ)
@@ -828,12 +826,8 @@ v_lshlrev_b32 {v('T')}, 3, {v('T')}
 s_cmp_eq_u32 {s('cross')}, 1
 s_cselect_b32 {st(0)}, 64, {s('lb')}
 s_mul_i32 {st(0)}, {st(0)}, 24
-s_add_u32 {st(1)}, {s('i')}, 1
-s_mul_i32 {st(1)}, {st(1)}, 24
 v_add_u32 {v('T',1)}, {st(0)}, {v('T')}
-v_add_u32 {v('S6')}, {st(1)}, {v('T')}
 ds_read_b64 {vp('D',0)}, {v('T',1)} offset:{LDS_P0}
-global_load_dwordx2 {vp('DdV')}, {v('S6')}, {sp('dK')}
 s_waitcnt vmcnt(0) lgkmcnt(0)
 s_mov_b64 {sp('lu')}, {sp('nlu')}
 v_fma_f64 {vp('D',1)}, {vp('FmV')}, {sp('AoT')}, {vp('DdV')}
