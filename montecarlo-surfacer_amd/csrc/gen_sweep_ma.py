@@ -29,6 +29,7 @@ Hazards are padded by the rules hipcc applies on gfx950 (read off its output): 2
 VALU write of an SGPR/VCC and a VALU read of it, 1 before v_readlane / v_readfirstlane of a fresh VGPR,
 2 before DPP or v_permlane*_swap of a fresh VGPR, 1 after v_rcp_f64, 3 after v_dot2 (met by the interleave).
 """
+import re
 import sys
 
 out = []
@@ -74,7 +75,9 @@ def st4(i): return "s[%d:%d]" % (S["t"] + i, S["t"] + i + 3)
 
 
 ZS = 4
-LDS_P0 = 8192
+NS = int(sys.argv[2]) if len(sys.argv) > 2 else 64      # particles per lane: 64, 32 or 16
+assert NS in (16, 32, 64)
+LDS_P0 = (NS // 2) * 256                                  # after the int16 z words
 ONE_HI = "0x3ff00000"
 
 # kernarg layout (struct MaArgs in smcx_sweep_ma.hip)
@@ -196,14 +199,14 @@ v_add_u32 v26, {st(6)}, {v('zaddr')}
 ds_write_b16 v26, v24
 v_lshrrev_b64 v[{V['uns0']}:{V['uns1']}], 1, v[{V['uns0']}:{V['uns1']}]
 v_cndmask_b32 v27, 0, 1, {stp(4)}
-v_lshl_or_b32 {v('uns1')}, v27, 31, {v('uns1')}
+v_lshl_or_b32 {v('uns1') if NS == 64 else v('uns0')}, v27, {(NS - 1) % 32}, {v('uns1') if NS == 64 else v('uns0')}
 """)
-for k in range(63):
+for k in range(NS - 1):
     E(f"v_mov_b32 {xy(k)}, {xy(k+1)}")
 E(f"""
-v_mov_b32 {xy(63)}, v22
+v_mov_b32 {xy(NS - 1)}, v22
 s_add_u32 {st(0)}, {st(0)}, 1
-s_cmp_lt_u32 {st(0)}, 64
+s_cmp_lt_u32 {st(0)}, {NS}
 s_cbranch_scc1 L_init
 s_waitcnt lgkmcnt(0)
 """)
@@ -247,15 +250,16 @@ def fill_p0(tag):
 def rotate(tag):
     """slot j <- slot j+1 for the packed x,y, the int16 z in LDS and the unsafe bits; then the p0 cache"""
     E(f"v_mov_b32 v14, {xy(0)}")
-    for k in range(63):
+    for k in range(NS - 1):
         E(f"v_mov_b32 {xy(k)}, {xy(k+1)}")
-    E(f"v_mov_b32 {xy(63)}, v14")
+    E(f"v_mov_b32 {xy(NS - 1)}, v14")
     # z: 32 words per lane; new word j = old[j].hi | old[j+1].lo << 16 ; the last one wraps to old[0]
     E(f"ds_read2st64_b32 v[14:15], {v('zaddr')} offset0:0 offset1:1")
     E("s_waitcnt lgkmcnt(0)")
     E("v_mov_b32 v24, v14")
-    for j in range(0, 32, 2):
-        if j + 2 < 32:
+    NWRD = NS // 2
+    for j in range(0, NWRD, 2):
+        if j + 2 < NWRD:
             E(f"ds_read2st64_b32 v[16:17], {v('zaddr')} offset0:{j+2} offset1:{j+3}")
             E("s_waitcnt lgkmcnt(0)")
             nxt = "v16"
@@ -264,16 +268,16 @@ def rotate(tag):
         E("v_alignbit_b32 v18, v15, v14, 16")
         E(f"v_alignbit_b32 v19, {nxt}, v15, 16")
         E(f"ds_write2st64_b32 {v('zaddr')}, v18, v19 offset0:{j} offset1:{j+1}")
-        if j + 2 < 32:
+        if j + 2 < NWRD:
             E("v_mov_b32 v14, v16")
             E("v_mov_b32 v15, v17")
     E(f"""
     s_waitcnt lgkmcnt(0)
     v_and_b32 v14, 1, {v('uns0')}
     v_lshrrev_b64 v[{V['uns0']}:{V['uns1']}], 1, v[{V['uns0']}:{V['uns1']}]
-    v_lshl_or_b32 {v('uns1')}, v14, 31, {v('uns1')}
+    v_lshl_or_b32 {v('uns1') if NS == 64 else v('uns0')}, v14, {(NS - 1) % 32}, {v('uns1') if NS == 64 else v('uns0')}
     s_add_u32 {s('rot')}, {s('rot')}, 1
-    s_and_b32 {s('rot')}, {s('rot')}, 63
+    s_and_b32 {s('rot')}, {s('rot')}, {NS - 1}
     """)
     fill_p0(tag)
 
@@ -413,10 +417,10 @@ def screen_pass(pxy, pzz, w0, w1):
     E(f"""
     v_mov_b32 {w0}, 0
     v_mov_b32 {w1}, 0
-    ds_read2st64_b32 v[{V['zA']}:{V['zA']+1}], {v('zaddr')} offset0:30 offset1:31
-    ds_read2st64_b32 v[{V['zB']}:{V['zB']+1}], {v('zaddr')} offset0:28 offset1:29
+    ds_read2st64_b32 v[{V['zA']}:{V['zA']+1}], {v('zaddr')} offset0:{NS // 2 - 2} offset1:{NS // 2 - 1}
+    ds_read2st64_b32 v[{V['zB']}:{V['zB']+1}], {v('zaddr')} offset0:{NS // 2 - 4} offset1:{NS // 2 - 3}
     """)
-    groups = list(range(60, -1, -4))
+    groups = list(range(NS - 4, -1, -4))
     for gi, k0 in enumerate(groups):
         buf = 'zA' if gi % 2 == 0 else 'zB'
         E("s_waitcnt lgkmcnt(1)" if gi < len(groups) - 1 else "s_waitcnt lgkmcnt(0)")
@@ -442,7 +446,7 @@ def pick_fetch(w0, w1, X, spec_mask, have):
     v_and_b32 v{w0}, v{w0}, v46
     v_and_b32 v{w1}, v{w1}, v47
     v_add_u32 v44, {s('rot')}, v44
-    v_and_b32 v44, 63, v44
+    v_and_b32 v44, {NS - 1}, v44
     v_lshl_or_b32 v44, v44, 6, {LANE}
     v_cmp_gt_u32 vcc, {s('N')}, v44
     v_mul_u32_u24 v45, 24, v44
@@ -640,8 +644,8 @@ s_cmp_eq_u32 {s('hasA')}, 0
 s_cbranch_scc1 L_nofa
 s_cmp_eq_u32 {s('ua')}, 0
 s_cbranch_scc1 L_ua0
-v_mov_b32 {v('wa0')}, -1
-v_mov_b32 {v('wa1')}, -1
+v_mov_b32 {v('wa0')}, {'-1' if NS >= 32 else '0xffff'}
+v_mov_b32 {v('wa1')}, {'-1' if NS == 64 else '0'}
 L_ua0:
 // the moving particle itself (slot 0 of lane tl) is not a neighbour of its proposal
 s_lshl_b64 {stp(0)}, 1, {s('tl')}
@@ -665,8 +669,8 @@ s_lshl_b32 {st(0)}, {st(0)}, 3
 s_load_dwordx2 {sp('nlu')}, {sp('uK')}, {st(0)}
 s_cmp_eq_u32 {s('ub')}, 0
 s_cbranch_scc1 L_ub0
-v_mov_b32 {v('wb0')}, -1
-v_mov_b32 {v('wb1')}, -1
+v_mov_b32 {v('wb0')}, {'-1' if NS >= 32 else '0xffff'}
+v_mov_b32 {v('wb1')}, {'-1' if NS == 64 else '0'}
 L_ub0:
 // not neighbours of B: the particle it stands for (slot 0 of lane tl+1, or slot 1 of lane 0 when the order
 // crosses slots) and the moving particle n (slot 0 of lane tl), which reaches B through the side pair
@@ -921,5 +925,7 @@ s_waitcnt vmcnt(0) lgkmcnt(0)
 with open(sys.argv[1] if len(sys.argv) > 1 else "smcx_sweep_ma_body.inc", "w") as f:
     f.write("// generated by gen_sweep_ma.py -- do not edit\n")
     for ln in out:
+        # labels are per variant: the three bodies are assembled into one object
+        ln = re.sub(r"\bL_(\w+)", r"L%d_\1" % NS, ln)
         f.write('"%s\\n\\t"\n' % ln)
 print("%d lines" % len(out), file=sys.stderr)

@@ -27,53 +27,68 @@ struct MaArgs {
 };
 static_assert(sizeof(MaArgs) == 0xc0, "offsets are hard-wired in gen_sweep_ma.py");
 
-constexpr unsigned MA_LDS_BYTES = 8192 + 65 * 24;
+// LDS (dynamic, at launch; the body addresses it by fixed offsets): unsigned zw[S/2][64] (int16 z, slot pairs x
+// lanes) at 0, double p0[65][3] (fp64 positions of the slot-0 particles + lane 0's slot-1 particle) behind it
+constexpr unsigned ma_lds_bytes(int S) { return (unsigned)(S / 2) * 256u + 65u * 24u; }
 
-__global__ void __launch_bounds__(64, 4) sweep_kernel_ma(MaArgs a)
+#define SMCX_MA_SGPRS "s0", "s1", "s2", "s3", "s4", "s5", "s6", "s7", "s8", "s9", "s10", "s11", "s12", "s13", "s14", "s15", "s16", "s17", "s18", "s19", "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27", "s28", "s29", "s30", "s31", "s32", "s33", "s34", "s35", "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95"
+#define SMCX_MA_V63 "v1", "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17", "v18", "v19", "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63"
+#define SMCX_MA_V79 SMCX_MA_V63, "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79"
+#define SMCX_MA_V95 SMCX_MA_V79, "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95"
+#define SMCX_MA_V127 SMCX_MA_V95, "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127"
+
+// one kernel per particles-per-lane count; launch bounds = the waves per SIMD 64 + S VGPRs allow
+__global__ void __launch_bounds__(64, 4) sweep_kernel_ma64(MaArgs a)
 {
-    // LDS (dynamic, MA_LDS_BYTES at launch; the body addresses it by fixed offsets):
-    //   0     unsigned zw[32][64]   int16 z, slot pairs x lanes
-    //   8192  double   p0[65][3]    fp64 positions of the slot-0 particles (+ lane 0's slot-1 particle)
     unsigned lane = threadIdx.x;
     unsigned long long kp = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
     unsigned rep = blockIdx.x;
     asm volatile(
-#include "smcx_sweep_ma_body.inc"
+#include "smcx_sweep_ma_body64.inc"
         : "+v"(lane), "+s"(kp), "+s"(rep)
         :
-        : "memory", "vcc", "scc",
-          "v1", "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15", "v16",
-          "v17", "v18", "v19", "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31",
-          "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46",
-          "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61",
-          "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76",
-          "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91",
-          "v92", "v93", "v94", "v95", "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105",
-          "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118",
-          "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127",
-          "s0", "s1", "s2", "s3", "s4", "s5", "s6", "s7", "s8", "s9", "s10", "s11", "s12", "s13", "s14", "s15",
-          "s16", "s17", "s18", "s19", "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27", "s28", "s29", "s30",
-          "s31", "s32", "s33", "s34", "s35", "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45",
-          "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60",
-          "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75",
-          "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90",
-          "s91", "s92", "s93", "s94", "s95");
+        : "memory", "vcc", "scc", SMCX_MA_SGPRS, SMCX_MA_V127);
+}
+
+__global__ void __launch_bounds__(64, 5) sweep_kernel_ma32(MaArgs a)
+{
+    unsigned lane = threadIdx.x;
+    unsigned long long kp = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
+    unsigned rep = blockIdx.x;
+    asm volatile(
+#include "smcx_sweep_ma_body32.inc"
+        : "+v"(lane), "+s"(kp), "+s"(rep)
+        :
+        : "memory", "vcc", "scc", SMCX_MA_SGPRS, SMCX_MA_V95);
+}
+
+__global__ void __launch_bounds__(64, 6) sweep_kernel_ma16(MaArgs a)
+{
+    unsigned lane = threadIdx.x;
+    unsigned long long kp = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
+    unsigned rep = blockIdx.x;
+    asm volatile(
+#include "smcx_sweep_ma_body16.inc"
+        : "+v"(lane), "+s"(kp), "+s"(rep)
+        :
+        : "memory", "vcc", "scc", SMCX_MA_SGPRS, SMCX_MA_V79);
 }
 
 bool ma_supported(int S, int WPR, int N, int M2)
 {
+    if (S != 16 && S != 32 && S != 64) return false;
 #ifdef SMCX_CHECK
     return false; // the diagnostic build counts the screen's misses in sweep_kernel_mi (same screen, hipcc-scheduled)
 #endif
     static const char *env = getenv("SMCX_MA"); // SMCX_MA=0: sweep_kernel_mi instead, for A/B measurements
     if (env && env[0] == '0') return false;
-    return S == 64 && WPR == 1 && N > 2048 && N <= 4096 && M2 + 1 <= 30;
+    return WPR == 1 && N > 32 * S && N <= 64 * S && M2 + 1 <= 30;
 }
 
-const char *ma_kernel_name() { return "smcx::sweep_kernel_ma"; }
+const char *ma_kernel_name(int S) { return S == 64 ? "smcx::sweep_kernel_ma64" : S == 32 ? "smcx::sweep_kernel_ma32" : "smcx::sweep_kernel_ma16"; }
 
 // wtab: [M2 + 1][4] doubles on the device, built by the caller (smcx_api.hip)
-hipError_t launch_sweeps_ma(const SweepArgs &s, const DevCtx &c, const double *wtab, int nsweeps, double A,
+hipError_t launch_sweeps_ma(const SweepArgs &s, const DevCtx &c, int S, const double *wtab, int nsweeps, double A,
                             double toFix, double zFix, double zsafe, int negC, hipStream_t st)
 {
     MaArgs a;
@@ -84,7 +99,8 @@ hipError_t launch_sweeps_ma(const SweepArgs &s, const DevCtx &c, const double *w
     a.zsafe = zsafe; a.halfLz = c.halfLz; a.Lz = c.Lz; a.invLz = c.invLz;
     a.N = s.N; a.chunk = s.chunk; a.nsweeps = nsweeps; a.negC = negC;
     a.M2 = (c.flags & 0x1u) ? c.M2 : -1; a.pad0 = a.pad1 = a.pad2 = 0;
-    hipLaunchKernelGGL(sweep_kernel_ma, dim3(c.nrep), dim3(64), MA_LDS_BYTES, st, a);
+    void (*f)(MaArgs) = S == 64 ? sweep_kernel_ma64 : S == 32 ? sweep_kernel_ma32 : sweep_kernel_ma16;
+    hipLaunchKernelGGL(f, dim3(c.nrep), dim3(64), ma_lds_bytes(S), st, a);
     return hipGetLastError();
 }
 

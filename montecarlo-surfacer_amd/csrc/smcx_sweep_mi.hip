@@ -608,7 +608,7 @@ bool mi_supported(int S, int WPR, double L, double Lz, double cutoff2)
 const char *mi_kernel_name(int S, int N, double L, double Lz)
 {
     const int zs = mi_zshift(L, Lz);
-    if (zs == 4 && ma_supported(S, 1, N, 0)) return ma_kernel_name();
+    if (zs == 4 && ma_supported(S, 1, N, 0)) return ma_kernel_name(S);
 #define SMCX_MI(s, z, w) if (S == s && zs == z) return "smcx::sweep_kernel_mi<" #s ", " #z ", " #w ">";
     SMCX_MI_TABLE(SMCX_MI)
 #undef SMCX_MI
@@ -636,7 +636,7 @@ hipError_t launch_sweeps_mi(const SweepArgs &a, const DevCtx &c, int S, int nswe
     if (!f || !mi_bound(c.L, c.Lz, c.cutoff2, zs, &m)) return hipErrorInvalidValue;
     // 64 particles per lane with the standard z unit: the hand-scheduled form of this kernel
     if (zs == 4 && c.wtab && ma_supported(S, 1, c.N, (c.flags & 0x1u) ? c.M2 : 0))
-        return launch_sweeps_ma(a, c, c.wtab, nsweeps, A, m.toFix, m.zFix, m.zsafe, m.negC, st);
+        return launch_sweeps_ma(a, c, S, c.wtab, nsweeps, A, m.toFix, m.zFix, m.zsafe, m.negC, st);
     MiWalls wl;
     wl.on = (c.flags & 0x1u) ? 1 : 0; wl.M = c.M; wl.M2 = c.M2;
     wl.dw = c.L / c.M; wl.Lz = c.Lz; wl.invLz = c.invLz; wl.halfLz = c.halfLz;

@@ -158,8 +158,8 @@ sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "t
 import numpy as np, torch
 import smcx_loader
 S = smcx_loader.load()
-N, Na, Nz, nrep, nsw = (int(v) for v in sys.argv[3:8])
-p = S.default_params(N, nrep, flags=S.FLAG_WALLS | S.FLAG_SERIES, tune_slots=64, tune_waves=1)
+N, Na, Nz, nrep, nsw, slots = (int(v) for v in sys.argv[3:9])
+p = S.default_params(N, nrep, flags=S.FLAG_WALLS | S.FLAG_SERIES, tune_slots=slots, tune_waves=1)
 with S.Engine(p) as eng:
     name = eng.kernel_form[1]
     eng.upload(S.fcc_init(Na, Nz), S.W_REFERENCE)
@@ -169,11 +169,14 @@ with S.Engine(p) as eng:
 """
 
 
-@pytest.mark.parametrize("N,lat,nrep,nsw", [(4096, (8, 16), 4096, 3), (4000, (10, 10), 64, 3)])
-def test_hand_scheduled_kernel_matches_compiled_kernel(S, O, tmp_path, N, lat, nrep, nsw):
+@pytest.mark.parametrize("N,lat,nrep,nsw,slots", [(4096, (8, 16), 4096, 3, 64), (4000, (10, 10), 64, 3, 64),
+                                                  (1024, (8, 4), 1024, 4, 16), (2048, (8, 8), 256, 3, 32),
+                                                  (1960, (7, 10), 64, 3, 32), (720, (6, 5), 64, 4, 16)])
+def test_hand_scheduled_kernel_matches_compiled_kernel(S, O, tmp_path, N, lat, nrep, nsw, slots):
     """sweep_kernel_ma (hand-scheduled, the benchmark's kernel) against sweep_kernel_mi (the same algorithm
     compiled by hipcc, whose screen the miss counter of the diagnostic build validates) on the whole bench
-    workload: 4096 replicas x 3 sweeps = 5e7 moves, and a ragged N with padding slots.  Both evaluate the
+    workload: 4096 replicas x 3 sweeps = 5e7 moves, a ragged N with padding slots, and the 16- and 32-particles-per-lane variants that serve
+    N <= 2048 (BASELINE configs[1] is N=1024).  Both evaluate the
     same pairs in the same lanes and rounds; they differ in the Metropolis arithmetic's association
     (row layout), i.e. by rounding.  A pair missed by either screen would shift E by >= 5e-3."""
     w = tmp_path / "mi_worker.py"
@@ -181,11 +184,11 @@ def test_hand_scheduled_kernel_matches_compiled_kernel(S, O, tmp_path, N, lat, n
     out = {}
     for tag, env in (("ma", {}), ("mi", {"SMCX_MA": "0"})):
         f = str(tmp_path / (tag + ".npz"))
-        r = subprocess.run([sys.executable, str(w), ROOT, f, str(N), str(lat[0]), str(lat[1]), str(nrep), str(nsw)],
-                           env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+        r = subprocess.run([sys.executable, str(w), ROOT, f, str(N), str(lat[0]), str(lat[1]), str(nrep), str(nsw),
+                            str(slots)], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
         out[tag] = np.load(f)
-    assert str(out["ma"]["name"]) == "smcx::sweep_kernel_ma" and "sweep_kernel_mi" in str(out["mi"]["name"])
+    assert str(out["ma"]["name"]) == "smcx::sweep_kernel_ma%d" % slots and "sweep_kernel_mi" in str(out["mi"]["name"])
     assert np.array_equal(out["ma"]["jj"], out["mi"]["jj"]) and out["ma"]["jj"].sum() > 0
     dE = np.abs(out["ma"]["E"] - out["mi"]["E"])
     assert np.all(dE <= 1e-9 * (1.0 + np.abs(out["mi"]["E"]))), dE.max()
