@@ -43,6 +43,18 @@ def E(txt=""):
 
 
 # ---------------------------------------------------------------------------------------------- registers
+ZS = 4
+NS = int(sys.argv[2]) if len(sys.argv) > 2 else 64      # particles per lane: 64, 32 or 16
+assert NS in (16, 32, 64)
+# "zb": z-binned storage.  The register/LDS cells hold the particles in the order of a z sort done before the
+# launch (Rs = positions in cell order, loc = cell of each particle); a probe screens only the 4-slot groups
+# whose z range (kept per group, widened by accepted moves) can reach it.
+ZBC = len(sys.argv) > 3 and sys.argv[3] == "zbc"        # diagnostic: every pass also runs the full screen and counts
+ZB = ZBC or (len(sys.argv) > 3 and sys.argv[3] == "zb")   # the bits the ranged pass lacks (must be none)
+NG = NS // 4                                              # 4-slot groups
+LDS_P0 = (NS // 2) * 256                                  # after the int16 z words
+LDS_GB = LDS_P0 + 65 * 24                                 # zb: (min, max) z of each group while the copies are built
+LDS_CNT = LDS_GB + 512                                    # zbc: per lane (candidates, bits missing from the ranged pass)
 LANE, KARG, REP = "%0", "%1", "%2"
 
 V = dict(zaddr=1, uns0=2, uns1=3, wa0=4, wa1=5, wb0=6, wb1=7, axy=8, bxy=9,
@@ -52,6 +64,15 @@ V = dict(zaddr=1, uns0=2, uns1=3, wa0=4, wa1=5, wb0=6, wb1=7, axy=8, bxy=9,
          acc=50,                  # e, fx, fy, fz: v50..v57
          wdz=58, FmV=60, DdV=62)
 XY0 = 64
+
+
+if ZB:
+    # the probes' packed x,y live in SGPRs (copied to a screen temporary per pass); v8/v9 carry the current
+    # 64-particle row instead: rxy = packed x,y, rzl = z16 | unsafe << 16 | cell << 17 of particle row*64 + lane.
+    # The walls' dz goes to the F registers (free until the body's force step); v58/v59 = the groups' z ranges
+    # (lane g: lowest z - RZ, highest z + RZ, in z units).
+    del V['axy'], V['bxy']
+    V.update(rxy=8, rzl=9, pxy=20, wdz=V['F'], gloR=58, ghiR=59)
 
 
 def v(name, i=0): return "v%d" % (V[name] + i)
@@ -67,6 +88,14 @@ S = dict(Rg=0, displ=2, uni=4, dK=6, uK=8, wtab=10, rec=12, clk=14,
          Q=66, lu=72, nlu=74, E=76, haveA=78, wallM=80, haveB=82, planeM=84, sideM=86, t=88)   # s88..s95 scratch
 
 
+if ZB:
+    # displ/uni/rec/clk are re-derived from the kernel arguments where they are used; their registers hold
+    # Rs, the cells of particles n and n+1, the probes' packed x,y and the compact copy of particle row*64 + 64
+    for k in ('displ', 'uni', 'rec', 'clk'):
+        del S[k]
+    S.update(Rs=2, locA=4, locB=5, axys=12, bxys=13, nxy=14, nzl=15)
+
+
 def s(name, i=0): return "s%d" % (S[name] + i)
 def sp(name, i=0): return "s[%d:%d]" % (S[name] + 2 * i, S[name] + 2 * i + 1)
 def st(i): return "s%d" % (S["t"] + i)
@@ -74,15 +103,12 @@ def stp(i): return "s[%d:%d]" % (S["t"] + i, S["t"] + i + 1)
 def st4(i): return "s[%d:%d]" % (S["t"] + i, S["t"] + i + 3)
 
 
-ZS = 4
-NS = int(sys.argv[2]) if len(sys.argv) > 2 else 64      # particles per lane: 64, 32 or 16
-assert NS in (16, 32, 64)
-LDS_P0 = (NS // 2) * 256                                  # after the int16 z words
 ONE_HI = "0x3ff00000"
 
 # kernarg layout (struct MaArgs in smcx_sweep_ma.hip)
 K_R, K_DISPL, K_UNI, K_OFFS, K_OBS, K_REC, K_WTAB, K_CLK = 0x0, 0x8, 0x10, 0x18, 0x20, 0x28, 0x30, 0x38
 K_CONST16, K_CONST8, K_INTS, K_M2 = 0x40, 0x80, 0xa0, 0xb0
+K_RZ, K_RS, K_LOC, K_SW0, K_DBG = 0xb4, 0xb8, 0xc0, 0xc8, 0xd0   # zb
 
 # ---------------------------------------------------------------------------------------------- prologue
 E(f"""
@@ -93,9 +119,9 @@ s_load_dwordx16 s[16:31], {KARG}, {K_CONST16}
 s_load_dwordx8 s[32:39], {KARG}, {K_CONST8}
 s_waitcnt lgkmcnt(0)
 // stp(0) obs, stp(2) rec, stp(4) wtab, stp(6) clk
-s_mov_b64 {sp('rec')}, {stp(2)}
+{"" if ZB else f"s_mov_b64 {sp('rec')}, {stp(2)}"}
 s_mov_b64 {sp('wtab')}, {stp(4)}
-s_mov_b64 {sp('clk')}, {stp(6)}
+{"" if ZB else f"s_mov_b64 {sp('clk')}, {stp(6)}"}
 s_lshl_b32 {st(2)}, {REP}, 6
 s_add_u32 {st(0)}, {st(0)}, {st(2)}
 s_addc_u32 {st(1)}, {st(1)}, 0
@@ -116,12 +142,60 @@ s_mul_hi_u32 {st(1)}, {st(0)}, {REP}
 s_mul_i32 {st(0)}, {st(0)}, {REP}
 s_add_u32 {s('Rg')}, {s('Rg')}, {st(0)}
 s_addc_u32 {s('Rg',1)}, {s('Rg',1)}, {st(1)}
-s_lshl_b32 {st(0)}, {s('cbase')}, 4
-s_add_u32 {s('rec')}, {s('rec')}, {st(0)}
-s_addc_u32 {s('rec',1)}, {s('rec',1)}, 0
-s_lshl_b32 {st(0)}, {REP}, 5
-s_add_u32 {s('clk')}, {s('clk')}, {st(0)}
-s_addc_u32 {s('clk',1)}, {s('clk',1)}, 0
+""")
+if not ZB:
+    E(f"""
+    s_lshl_b32 {st(0)}, {s('cbase')}, 4
+    s_add_u32 {s('rec')}, {s('rec')}, {st(0)}
+    s_addc_u32 {s('rec',1)}, {s('rec',1)}, 0
+    s_lshl_b32 {st(0)}, {REP}, 5
+    s_add_u32 {s('clk')}, {s('clk')}, {st(0)}
+    s_addc_u32 {s('clk',1)}, {s('clk',1)}, 0
+    """)
+else:
+    # Rs = Rs + rep * NS*64*24 ; the sweep counter runs from sw0 (the host sorts between launches)
+    E(f"""
+    s_load_dwordx2 {sp('Rs')}, {KARG}, {K_RS}
+    s_load_dword {st(3)}, {KARG}, {K_SW0}
+    s_mov_b32 {st(0)}, {NS * 64 * 24}
+    s_mul_hi_u32 {st(1)}, {st(0)}, {REP}
+    s_mul_i32 {st(0)}, {st(0)}, {REP}
+    s_waitcnt lgkmcnt(0)
+    s_add_u32 {s('Rs')}, {s('Rs')}, {st(0)}
+    s_addc_u32 {s('Rs',1)}, {s('Rs',1)}, {st(1)}
+    s_mov_b32 {s('sw')}, {st(3)}
+    s_add_u32 {s('nsw')}, {s('nsw')}, {st(3)}
+    // a launch that continues a chunk (sw0 > 0) takes the running energy from the previous sweep's record
+    s_cmp_eq_u32 {st(3)}, 0
+    s_cbranch_scc1 L_e0
+    s_load_dwordx2 {stp(4)}, {KARG}, {K_REC}
+    s_add_u32 {st(0)}, {s('cbase')}, {st(3)}
+    s_sub_u32 {st(0)}, {st(0)}, 1
+    s_lshl_b32 {st(0)}, {st(0)}, 4
+    s_waitcnt lgkmcnt(0)
+    s_load_dwordx2 {sp('E')}, {stp(4)}, {st(0)}
+    s_waitcnt lgkmcnt(0)
+    L_e0:
+    """)
+
+
+def clk_ptr(dst):
+    """dst (s pair) <- this replica's row of the clock stamps"""
+    if not ZB:
+        return sp('clk')
+    lo, hi = (int(x) for x in dst[2:-1].split(":"))
+    E(f"""
+    s_load_dwordx2 {dst}, {KARG}, {K_CLK}
+    s_lshl_b32 {st(0)}, {REP}, 5
+    s_waitcnt lgkmcnt(0)
+    s_add_u32 s{lo}, s{lo}, {st(0)}
+    s_addc_u32 s{hi}, s{hi}, 0
+    """)
+    return dst
+
+
+CLK0 = clk_ptr(stp(2))
+E(f"""
 // start stamp: clk[rep][0..1] = s_memtime, s_memrealtime
 s_memtime {stp(4)}
 s_memrealtime {stp(6)}
@@ -132,7 +206,7 @@ v_mov_b32 v17, {st(5)}
 v_mov_b32 v18, {st(6)}
 v_mov_b32 v19, {st(7)}
 s_mov_b64 exec, 1
-global_store_dwordx4 v14, v[16:19], {sp('clk')}
+global_store_dwordx4 v14, v[16:19], {CLK0}
 s_mov_b64 exec, -1
 // masks of the special lanes: wall sites + plane = lanes 0..M2 (none if M2 < 0), plane = lane M2, side pair = lane 30
 s_mov_b64 {sp('wallM')}, 0
@@ -151,6 +225,29 @@ v_mov_b32 {v('uns0')}, 0
 v_mov_b32 {v('uns1')}, 0
 s_mov_b32 {s('rot')}, 0
 """)
+SRC = sp('Rs') if ZB else sp('Rg')    # what the compact copies are built from / candidates are fetched from
+if ZB:
+    # LDS gb[g] = (max int, min int); lane g will read its group's pair when the copies are built
+    E(f"""
+    v_lshlrev_b32 v14, 3, {LANE}
+    v_mov_b32 v16, 0x7fffffff
+    v_mov_b32 v17, 0x80000000
+    ds_write_b64 v14, v[16:17] offset:{LDS_GB}
+    {f"v_mov_b32 v16, 0" if ZBC else ""}
+    {f"v_mov_b32 v17, 0" if ZBC else ""}
+    {f"ds_write_b64 v14, v[16:17] offset:{LDS_CNT}" if ZBC else ""}
+    s_waitcnt lgkmcnt(0)
+    """)
+
+zb_range_update = "" if not ZB else f"""
+s_lshr_b32 {st(6)}, {st(0)}, 2
+s_lshl_b32 {st(6)}, {st(6)}, 3
+v_mov_b32 v26, {st(6)}
+s_mov_b64 exec, vcc
+ds_min_i32 v26, v24 offset:{LDS_GB}
+ds_max_i32 v26, v24 offset:{LDS_GB + 4}
+s_mov_b64 exec, -1
+"""
 
 # ---- compact copies: 64 passes, each loads logical slot k of this lane, packs it, and shifts it in at the
 # top of the register file (xy[j] <- xy[j+1], xy[63] <- new): after 64 passes slot k sits in xy[k]
@@ -167,8 +264,8 @@ v_mov_b32 v19, 0
 v_mov_b32 v20, 0
 v_mov_b32 v21, 0
 s_and_saveexec_b64 {stp(2)}, vcc
-global_load_dwordx4 v[16:19], v15, {sp('Rg')}
-global_load_dwordx2 v[20:21], v15, {sp('Rg')} offset:16
+global_load_dwordx4 v[16:19], v15, {SRC}
+global_load_dwordx2 v[20:21], v15, {SRC} offset:16
 s_waitcnt vmcnt(0)
 s_mov_b64 exec, -1
 v_mul_f64 v[22:23], v[16:17], {sp('toFix')}
@@ -197,6 +294,7 @@ s_lshl_b32 {st(7)}, {st(7)}, 1
 s_add_u32 {st(6)}, {st(6)}, {st(7)}
 v_add_u32 v26, {st(6)}, {v('zaddr')}
 ds_write_b16 v26, v24
+{zb_range_update}
 v_lshrrev_b64 v[{V['uns0']}:{V['uns1']}], 1, v[{V['uns0']}:{V['uns1']}]
 v_cndmask_b32 v27, 0, 1, {stp(4)}
 v_lshl_or_b32 {v('uns1') if NS == 64 else v('uns0')}, v27, {(NS - 1) % 32}, {v('uns1') if NS == 64 else v('uns0')}
@@ -210,37 +308,111 @@ s_cmp_lt_u32 {st(0)}, {NS}
 s_cbranch_scc1 L_init
 s_waitcnt lgkmcnt(0)
 """)
+if ZB:
+    # lane g < NG: (lowest z - RZ, highest z + RZ) of group g; an empty group and the other lanes: never reached
+    E(f"""
+    s_load_dword {st(0)}, {KARG}, {K_RZ}
+    v_lshlrev_b32 v14, 3, {LANE}
+    ds_read_b64 v[16:17], v14 offset:{LDS_GB}
+    s_waitcnt lgkmcnt(0)
+    s_mov_b32 {s('M2')}, {st(0)}                // M2 has done its work (the lane masks): the register holds RZ from here on
+    v_subrev_u32 {v('gloR')}, {st(0)}, v16
+    v_add_u32 {v('ghiR')}, {st(0)}, v17
+    v_cmp_gt_i32 vcc, v16, v17
+    v_cmp_le_u32 {stp(2)}, {NG}, {LANE}
+    s_or_b64 vcc, vcc, {stp(2)}
+    v_mov_b32 v16, 0x7fffffff
+    v_mov_b32 v17, 0x80000000
+    v_cndmask_b32 {v('gloR')}, {v('gloR')}, v16, vcc
+    v_cndmask_b32 {v('ghiR')}, {v('ghiR')}, v17, vcc
+    """)
+
+
+def compact_row(xyd, zld, locv):
+    """zb: compact copy of the fp64 position in v[16:21] -> xyd = packed x,y ; zld = z16 | unsafe << 16 | cell << 17
+    (cell = locv, loaded from loc[]).  Same conversions as the register copies above."""
+    E(f"""
+    v_mul_f64 v[26:27], v[16:17], {sp('toFix')}
+    v_mul_f64 v[28:29], v[18:19], {sp('toFix')}
+    v_rndne_f64 v[26:27], v[26:27]
+    v_rndne_f64 v[28:29], v[28:29]
+    v_cvt_i32_f64 v26, v[26:27]
+    v_cvt_i32_f64 v28, v[28:29]
+    v_and_b32 v26, 0xffff, v26
+    v_lshl_or_b32 {xyd}, v28, 16, v26
+    v_mul_f64 v[28:29], v[20:21], {sp('zFix')}
+    v_rndne_f64 v[28:29], v[28:29]
+    v_cvt_i32_f64 v28, v[28:29]
+    v_mov_b32 v29, 0x7fff
+    v_mov_b32 v27, 0xffff8001
+    v_med3_i32 v28, v28, v29, v27
+    v_and_b32 v28, 0xffff, v28
+    v_cmp_nlt_f64 vcc, |v[20:21]|, {sp('zsafe')}
+    v_cndmask_b32 v29, 0, 1, vcc
+    v_lshl_or_b32 v28, v29, 16, v28
+    v_lshl_or_b32 {zld}, {locv}, 17, v28
+    """)
 
 
 def fill_p0(tag):
-    """p0[lane] = fp64 position of this lane's slot-0 particle, p0[64] = lane 0's slot-1 particle"""
+    """p0[lane] = fp64 position of particle rot*64 + lane (this lane's slot-0 particle), p0[64] = particle
+    rot*64 + 64 (lane 0's slot-1 particle); zb: also their compact copies and cells (rxy, rzl; nxy, nzl)"""
     E(f"""
     s_lshl_b32 {st(0)}, {s('rot')}, 6
     v_or_b32 v14, {st(0)}, {LANE}
     v_cmp_gt_u32 vcc, {s('N')}, v14
     v_mul_u32_u24 v15, 24, v14
     v_mul_u32_u24 v22, 24, {LANE}
+    """)
+    if ZB:
+        E(f"""
+        s_load_dwordx2 {stp(4)}, {KARG}, {K_LOC}
+        s_mul_i32 {st(6)}, {REP}, {s('N')}
+        s_lshl_b32 {st(6)}, {st(6)}, 1
+        v_lshlrev_b32 v23, 1, v14
+        s_waitcnt lgkmcnt(0)
+        s_add_u32 {st(4)}, {st(4)}, {st(6)}
+        s_addc_u32 {st(5)}, {st(5)}, 0
+        """)
+    E(f"""
     s_and_saveexec_b64 {stp(2)}, vcc
     global_load_dwordx4 v[16:19], v15, {sp('Rg')}
     global_load_dwordx2 v[20:21], v15, {sp('Rg')} offset:16
+    {f"global_load_ushort v24, v23, {stp(4)}" if ZB else ""}
     s_waitcnt vmcnt(0)
     ds_write_b64 v22, v[16:17] offset:{LDS_P0}
     ds_write_b64 v22, v[18:19] offset:{LDS_P0 + 8}
     ds_write_b64 v22, v[20:21] offset:{LDS_P0 + 16}
+    """)
+    if ZB:
+        compact_row(v('rxy'), v('rzl'), "v24")
+    E(f"""
     s_mov_b64 exec, 1
     s_add_u32 {st(0)}, {st(0)}, 64
     s_cmp_lt_u32 {st(0)}, {s('N')}
     s_cbranch_scc0 L_p0done_{tag}
     s_mul_i32 {st(1)}, {st(0)}, 24
     v_mov_b32 v15, {st(1)}
+    {f"s_lshl_b32 {st(1)}, {st(0)}, 1" if ZB else ""}
+    {f"v_mov_b32 v23, {st(1)}" if ZB else ""}
     s_nop 1
     global_load_dwordx4 v[16:19], v15, {sp('Rg')}
     global_load_dwordx2 v[20:21], v15, {sp('Rg')} offset:16
+    {f"global_load_ushort v24, v23, {stp(4)}" if ZB else ""}
     v_mov_b32 v22, {LDS_P0 + 64 * 24}
     s_waitcnt vmcnt(0)
     ds_write_b64 v22, v[16:17]
     ds_write_b64 v22, v[18:19] offset:8
     ds_write_b64 v22, v[20:21] offset:16
+    """)
+    if ZB:
+        compact_row("v30", "v31", "v24")
+        E(f"""
+        s_nop 0
+        v_readfirstlane_b32 {s('nxy')}, v30
+        v_readfirstlane_b32 {s('nzl')}, v31
+        """)
+    E(f"""
     L_p0done_{tag}:
     s_mov_b64 exec, -1
     s_waitcnt lgkmcnt(0)
@@ -248,7 +420,12 @@ def fill_p0(tag):
 
 
 def rotate(tag):
-    """slot j <- slot j+1 for the packed x,y, the int16 z in LDS and the unsafe bits; then the p0 cache"""
+    """slot j <- slot j+1 for the packed x,y, the int16 z in LDS and the unsafe bits; then the p0 cache
+    (zb: the cells never move; only the row of current particles advances)"""
+    if ZB:
+        E(f"s_add_u32 {s('rot')}, {s('rot')}, 1")
+        fill_p0(tag)
+        return
     E(f"v_mov_b32 v14, {xy(0)}")
     for k in range(NS - 1):
         E(f"v_mov_b32 {xy(k)}, {xy(k+1)}")
@@ -285,29 +462,44 @@ def rotate(tag):
 fill_p0("init")
 
 # ---------------------------------------------------------------------------------------------- sweeps, runs
+if not ZB:
+    E(f"""
+    s_mov_b32 {s('sw')}, 0
+    L_sweep:
+    // displ + ((cbase + sw) * 3N) * 8 ; uni + ((cbase + sw) * N) * 8 ; n0 = offs[cbase + sw]
+    s_load_dwordx4 {st4(4)}, {KARG}, {K_DISPL}
+    s_load_dwordx2 {stp(2)}, {KARG}, {K_OFFS}
+    s_add_u32 {st(0)}, {s('cbase')}, {s('sw')}
+    s_lshl_b32 {st(1)}, {st(0)}, 2
+    s_waitcnt lgkmcnt(0)
+    s_load_dword {s('n0')}, {stp(2)}, {st(1)}
+    s_mul_i32 {st(2)}, {s('N')}, 8
+    s_mul_hi_u32 {st(3)}, {st(2)}, {st(0)}
+    s_mul_i32 {st(2)}, {st(2)}, {st(0)}
+    s_add_u32 {s('uni')}, {st(6)}, {st(2)}
+    s_addc_u32 {s('uni',1)}, {st(7)}, {st(3)}
+    s_mul_i32 {st(6)}, {s('N')}, 24
+    s_mul_hi_u32 {st(3)}, {st(6)}, {st(0)}
+    s_mul_i32 {st(2)}, {st(6)}, {st(0)}
+    s_add_u32 {s('displ')}, {st(4)}, {st(2)}
+    s_addc_u32 {s('displ',1)}, {st(5)}, {st(3)}
+    s_mov_b32 {s('jacc')}, 0
+    s_mov_b32 {s('run')}, 0
+    s_waitcnt lgkmcnt(0)
+    """)
+else:
+    E(f"""
+    L_sweep:
+    s_load_dwordx2 {stp(2)}, {KARG}, {K_OFFS}
+    s_add_u32 {st(0)}, {s('cbase')}, {s('sw')}
+    s_lshl_b32 {st(1)}, {st(0)}, 2
+    s_waitcnt lgkmcnt(0)
+    s_load_dword {s('n0')}, {stp(2)}, {st(1)}
+    s_mov_b32 {s('jacc')}, 0
+    s_mov_b32 {s('run')}, 0
+    s_waitcnt lgkmcnt(0)
+    """)
 E(f"""
-s_mov_b32 {s('sw')}, 0
-L_sweep:
-// displ + ((cbase + sw) * 3N) * 8 ; uni + ((cbase + sw) * N) * 8 ; n0 = offs[cbase + sw]
-s_load_dwordx4 {st4(4)}, {KARG}, {K_DISPL}
-s_load_dwordx2 {stp(2)}, {KARG}, {K_OFFS}
-s_add_u32 {st(0)}, {s('cbase')}, {s('sw')}
-s_lshl_b32 {st(1)}, {st(0)}, 2
-s_waitcnt lgkmcnt(0)
-s_load_dword {s('n0')}, {stp(2)}, {st(1)}
-s_mul_i32 {st(2)}, {s('N')}, 8
-s_mul_hi_u32 {st(3)}, {st(2)}, {st(0)}
-s_mul_i32 {st(2)}, {st(2)}, {st(0)}
-s_add_u32 {s('uni')}, {st(6)}, {st(2)}
-s_addc_u32 {s('uni',1)}, {st(7)}, {st(3)}
-s_mul_i32 {st(6)}, {s('N')}, 24
-s_mul_hi_u32 {st(3)}, {st(6)}, {st(0)}
-s_mul_i32 {st(2)}, {st(6)}, {st(0)}
-s_add_u32 {s('displ')}, {st(4)}, {st(2)}
-s_addc_u32 {s('displ',1)}, {st(5)}, {st(3)}
-s_mov_b32 {s('jacc')}, 0
-s_mov_b32 {s('run')}, 0
-s_waitcnt lgkmcnt(0)
 L_run:
 s_sub_u32 {st(0)}, {s('N')}, {s('n0')}
 s_cmp_eq_u32 {s('run')}, 0
@@ -316,31 +508,63 @@ s_cselect_b32 {s('len')}, {st(0)}, {s('n0')}
 s_cselect_b32 {s('vbase')}, 0, {st(0)}
 s_cmp_eq_u32 {s('len')}, 0
 s_cbranch_scc1 L_run_next
-L_rot_to:
-s_lshr_b32 {st(7)}, {s('first')}, 6
-s_cmp_eq_u32 {s('rot')}, {st(7)}
-s_cbranch_scc1 L_rot_ok
 """)
-rotate("r1")
+if not ZB:
+    E(f"""
+    L_rot_to:
+    s_lshr_b32 {st(7)}, {s('first')}, 6
+    s_cmp_eq_u32 {s('rot')}, {st(7)}
+    s_cbranch_scc1 L_rot_ok
+    """)
+    rotate("r1")
+    E(f"""
+    s_branch L_rot_to
+    L_rot_ok:
+    s_and_b32 {s('tl')}, {s('first')}, 63
+    s_sub_u32 {s('tl')}, {s('tl')}, 1
+    // dK = displ + 24 first ; uK = uni + 8 vbase
+    s_mul_i32 {st(0)}, {s('first')}, 24
+    s_add_u32 {s('dK')}, {s('displ')}, {st(0)}
+    s_addc_u32 {s('dK',1)}, {s('displ',1)}, 0
+    s_lshl_b32 {st(0)}, {s('vbase')}, 3
+    s_add_u32 {s('uK')}, {s('uni')}, {st(0)}
+    s_addc_u32 {s('uK',1)}, {s('uni',1)}, 0
+    """)
+else:
+    E(f"s_lshr_b32 {s('rot')}, {s('first')}, 6")
+    fill_p0("r1")
+    E(f"""
+    s_and_b32 {s('tl')}, {s('first')}, 63
+    s_sub_u32 {s('tl')}, {s('tl')}, 1
+    // dK = displ + ((cbase + sw) * N + first) * 24 ; uK = uni + ((cbase + sw) * N + vbase) * 8
+    s_load_dwordx4 {st4(4)}, {KARG}, {K_DISPL}
+    s_add_u32 {st(0)}, {s('cbase')}, {s('sw')}
+    s_mul_i32 {st(2)}, {s('N')}, 8
+    s_mul_hi_u32 {st(3)}, {st(2)}, {st(0)}
+    s_mul_i32 {st(2)}, {st(2)}, {st(0)}
+    s_waitcnt lgkmcnt(0)
+    s_add_u32 {s('uK')}, {st(6)}, {st(2)}
+    s_addc_u32 {s('uK',1)}, {st(7)}, {st(3)}
+    s_lshl_b32 {st(1)}, {s('vbase')}, 3
+    s_add_u32 {s('uK')}, {s('uK')}, {st(1)}
+    s_addc_u32 {s('uK',1)}, {s('uK',1)}, 0
+    s_mul_i32 {st(6)}, {s('N')}, 24
+    s_mul_hi_u32 {st(3)}, {st(6)}, {st(0)}
+    s_mul_i32 {st(2)}, {st(6)}, {st(0)}
+    s_add_u32 {s('dK')}, {st(4)}, {st(2)}
+    s_addc_u32 {s('dK',1)}, {st(5)}, {st(3)}
+    s_mul_i32 {st(1)}, {s('first')}, 24
+    s_add_u32 {s('dK')}, {s('dK')}, {st(1)}
+    s_addc_u32 {s('dK',1)}, {s('dK',1)}, 0
+    """)
 E(f"""
-s_branch L_rot_to
-L_rot_ok:
-s_and_b32 {s('tl')}, {s('first')}, 63
-s_sub_u32 {s('tl')}, {s('tl')}, 1
-// dK = displ + 24 first ; uK = uni + 8 vbase
-s_mul_i32 {st(0)}, {s('first')}, 24
-s_add_u32 {s('dK')}, {s('displ')}, {st(0)}
-s_addc_u32 {s('dK',1)}, {s('displ',1)}, 0
-s_lshl_b32 {st(0)}, {s('vbase')}, 3
-s_add_u32 {s('uK')}, {s('uni')}, {st(0)}
-s_addc_u32 {s('uK',1)}, {s('uni',1)}, 0
 s_mov_b32 {s('i')}, -1
 s_mov_b32 {s('hasA')}, 0
 s_mov_b32 {s('hasB')}, 1
 s_mov_b32 {s('azz')}, 0
 s_mov_b32 {s('az16')}, 0
 s_mov_b32 {s('ua')}, 0
-v_mov_b32 {v('axy')}, 0
+{f"s_mov_b32 {s('axys')}, 0" if ZB else f"v_mov_b32 {v('axy')}, 0"}
 v_mov_b32 {v('FmV')}, 0
 v_mov_b32 {v('FmV',1)}, 0
 v_mov_b32 {v('DdV')}, 0
@@ -349,7 +573,8 @@ L_move:
 """)
 
 # ---------------------------------------------------------------------------------------------- B's compact copy
-E(f"""
+if not ZB:
+  E(f"""
 s_mov_b32 {s('bzz')}, 0
 s_mov_b32 {s('ub')}, 0
 s_mov_b32 {s('cross')}, 0
@@ -383,6 +608,33 @@ s_nop 0
 v_mov_b32 {v('bxy')}, {st(0)}
 L_nob1:
 """)
+else:
+  # zb: from the row registers (lane tl + 1), or the scalar copy of particle row*64 + 64 when the order crosses rows
+  E(f"""
+  s_mov_b32 {s('bzz')}, 0
+  s_mov_b32 {s('ub')}, 0
+  s_mov_b32 {s('cross')}, 0
+  s_mov_b32 {s('lb')}, 0
+  s_mov_b32 {s('bxys')}, 0
+  s_mov_b32 {s('locB')}, 0
+  s_cmp_eq_u32 {s('hasB')}, 0
+  s_cbranch_scc1 L_nob1
+  s_add_u32 {s('lb')}, {s('tl')}, 1
+  s_cmp_eq_u32 {s('tl')}, 63
+  s_cselect_b32 {s('lb')}, 0, {s('lb')}
+  s_cselect_b32 {s('cross')}, 1, 0
+  s_mov_b32 {s('bxys')}, {s('nxy')}
+  s_mov_b32 {st(1)}, {s('nzl')}
+  s_cbranch_scc1 L_bjoin
+  v_readlane_b32 {s('bxys')}, {v('rxy')}, {s('lb')}
+  v_readlane_b32 {st(1)}, {v('rzl')}, {s('lb')}
+  L_bjoin:
+  s_bfe_u32 {s('ub')}, {st(1)}, 0x10010
+  s_lshr_b32 {s('locB')}, {st(1)}, 17
+  s_and_b32 {st(1)}, {st(1)}, 0xffff
+  s_mul_i32 {s('bzz')}, {st(1)}, 0x10001
+  L_nob1:
+  """)
 
 # ---------------------------------------------------------------------------------------------- screen
 
@@ -430,6 +682,102 @@ def screen_pass(pxy, pzz, w0, w1):
             E(f"ds_read2st64_b32 v[{V[buf]}:{V[buf]+1}], {v('zaddr')} offset0:{nk // 2} offset1:{nk // 2 + 1}")
 
 
+def screen_ranged(tag, pxys, pzz, w0, w1):
+    """zb: candidate bits of one probe from the groups whose z range can hold a slot within RZ of the probe's z.
+    Lane g of gloR/ghiR holds group g's range; the groups between the lowest and the highest hit run in
+    descending order (entered by a computed jump), each fetching the z words of the next one; the bits land
+    at the bottom of w0 / w1 and are shifted to their slots at the end."""
+    w = lambda g: w1 if 4 * g >= 32 else w0
+    buf = lambda g: 'zA' if g % 2 == 0 else 'zB'
+    E(f"""
+    v_mov_b32 {w0}, 0
+    v_mov_b32 {w1}, 0
+    s_sext_i32_i16 {st(0)}, {pzz}
+    v_mov_b32 {v('pxy')}, {pxys}
+    v_cmp_ge_i32 vcc, {st(0)}, {v('gloR')}
+    v_cmp_le_i32 {stp(2)}, {st(0)}, {v('ghiR')}
+    s_and_b32 {st(1)}, vcc_lo, {st(2)}
+    s_cmp_eq_u32 {st(1)}, 0
+    s_cbranch_scc1 L_sdone_{tag}
+    s_ff1_i32_b32 {st(4)}, {st(1)}
+    s_flbit_i32_b32 {st(5)}, {st(1)}
+    s_sub_u32 {st(5)}, 31, {st(5)}
+    s_getpc_b64 {stp(2)}
+    L_spc_{tag}:
+    s_mul_i32 {st(5)}, {st(5)}, L_se1_{tag}-L_se0_{tag}
+    s_add_u32 {st(2)}, {st(2)}, {st(5)}
+    s_addc_u32 {st(3)}, {st(3)}, 0
+    s_add_u32 {st(2)}, {st(2)}, L_se0_{tag}-L_spc_{tag}
+    s_addc_u32 {st(3)}, {st(3)}, 0
+    s_setpc_b64 {stp(2)}
+    """)
+    for g in range(NG):
+        E(f"L_se{g}_{tag}:")
+        E(f"ds_read2st64_b32 v[{V[buf(g)]}:{V[buf(g)]+1}], {v('zaddr')} offset0:{2 * g} offset1:{2 * g + 1}")
+        E(f"s_branch L_sg{g}_{tag}")
+    if NG == 1:
+        E(f"L_se1_{tag}:")
+    for g in range(NG - 1, -1, -1):
+        E(f"L_sg{g}_{tag}:")
+        if g > 0:
+            E(f"ds_read2st64_b32 v[{V[buf(g-1)]}:{V[buf(g-1)]+1}], {v('zaddr')} offset0:{2 * g - 2} offset1:{2 * g - 1}")
+            E("s_waitcnt lgkmcnt(1)")
+        else:
+            E("s_waitcnt lgkmcnt(0)")
+        screen_group(4 * g, "v%d" % V[buf(g)], "v%d" % (V[buf(g)] + 1), v('pxy'), pzz, w(g))
+        if g > 0:
+            E(f"s_cmp_eq_u32 {st(4)}, {g}")
+            E(f"s_cbranch_scc1 L_sfin_{tag}")
+    E(f"""
+    L_sfin_{tag}:
+    s_lshl_b32 {st(0)}, {st(4)}, 2
+    s_waitcnt lgkmcnt(0)
+    v_lshlrev_b32 {w0}, {st(0)}, {w0}
+    """)
+    if NS == 64:
+        E(f"""
+        s_sub_u32 {st(1)}, {st(4)}, 8
+        s_max_i32 {st(1)}, {st(1)}, 0
+        s_lshl_b32 {st(1)}, {st(1)}, 2
+        v_lshlrev_b32 {w1}, {st(1)}, {w1}
+        """)
+    E(f"L_sdone_{tag}:")
+
+
+def zbc_check(pzz, w0, w1):
+    """diagnostic: the full pass of the same probe; count its bits and those the ranged pass did not set"""
+    screen_pass(v('pxy'), pzz, "v21", "v22")
+    E(f"""
+    v_not_b32 v23, {w0}
+    v_not_b32 v24, {w1}
+    v_and_b32 v23, v21, v23
+    v_and_b32 v24, v22, v24
+    v_bcnt_u32_b32 v23, v23, 0
+    v_bcnt_u32_b32 v23, v24, v23
+    v_bcnt_u32_b32 v24, v21, 0
+    v_bcnt_u32_b32 v24, v22, v24
+    v_lshlrev_b32 v25, 3, {LANE}
+    ds_add_u32 v25, v24 offset:{LDS_CNT}
+    ds_add_u32 v25, v23 offset:{LDS_CNT + 4}
+    s_waitcnt lgkmcnt(0)
+    """)
+
+
+def excl(w0, w1, loc):
+    """zb: the particle in cell `loc` (s: slot << 6 | lane) is not a candidate"""
+    E(f"""
+    s_and_b32 {st(0)}, {loc}, 63
+    s_lshr_b32 {st(1)}, {loc}, 6
+    s_lshl_b64 {stp(2)}, 1, {st(0)}
+    s_lshl_b64 {stp(4)}, 1, {st(1)}
+    s_not_b64 {stp(4)}, {stp(4)}
+    s_mov_b64 exec, {stp(2)}
+    v_and_b32 {w0}, {st(4)}, {w0}
+    v_and_b32 {w1}, {st(5)}, {w1}
+    s_mov_b64 exec, -1
+    """)
+
+
 # ---------------------------------------------------------------------------------------------- helpers
 def pick_fetch(w0, w1, X, spec_mask, have):
     """lanes with a candidate (and not in spec_mask) take their lowest one out of w and load its fp64
@@ -445,14 +793,14 @@ def pick_fetch(w0, w1, X, spec_mask, have):
     v_min_u32 v44, v44, v45
     v_and_b32 v{w0}, v{w0}, v46
     v_and_b32 v{w1}, v{w1}, v47
-    v_add_u32 v44, {s('rot')}, v44
-    v_and_b32 v44, {NS - 1}, v44
+    {"" if ZB else f"v_add_u32 v44, {s('rot')}, v44"}
+    {"" if ZB else f"v_and_b32 v44, {NS - 1}, v44"}
     v_lshl_or_b32 v44, v44, 6, {LANE}
     v_cmp_gt_u32 vcc, {s('N')}, v44
     v_mul_u32_u24 v45, 24, v44
     s_and_b64 exec, exec, vcc
-    global_load_dwordx4 v[{X}:{X+3}], v45, {sp('Rg')}
-    global_load_dwordx2 v[{X+4}:{X+5}], v45, {sp('Rg')} offset:16
+    global_load_dwordx4 v[{X}:{X+3}], v45, {SRC}
+    global_load_dwordx2 v[{X+4}:{X+5}], v45, {SRC} offset:16
     s_mov_b64 {have}, exec
     s_mov_b64 exec, -1
     """)
@@ -635,7 +983,12 @@ def probe(tag, P, pz_sgpr, pz, w0, w1, X, C, have, side, wait):
 XA_, CA_, XB_, CB_ = 30, 26, 20, 10   # round-0 data: A in the D registers (d = p - X in place), B in v20..25; coefficients
 
 # ---------------------------------------------------------------------------------------------- screen + fetch, probe A first
-screen_pass(v('axy'), s('azz'), v('wa0'), v('wa1'))
+if ZB:
+    screen_ranged("A", s('axys'), s('azz'), v('wa0'), v('wa1'))
+    if ZBC:
+        zbc_check(s('azz'), v('wa0'), v('wa1'))
+else:
+    screen_pass(v('axy'), s('azz'), v('wa0'), v('wa1'))
 E(f"""
 v_or_b32 {v('wa0')}, {v('wa0')}, {v('uns0')}
 v_or_b32 {v('wa1')}, {v('wa1')}, {v('uns1')}
@@ -647,16 +1000,26 @@ s_cbranch_scc1 L_ua0
 v_mov_b32 {v('wa0')}, {'-1' if NS >= 32 else '0xffff'}
 v_mov_b32 {v('wa1')}, {'-1' if NS == 64 else '0'}
 L_ua0:
-// the moving particle itself (slot 0 of lane tl) is not a neighbour of its proposal
-s_lshl_b64 {stp(0)}, 1, {s('tl')}
-s_mov_b64 exec, {stp(0)}
-v_and_b32 {v('wa0')}, -2, {v('wa0')}
-s_mov_b64 exec, -1
 """)
+if ZB:
+    excl(v('wa0'), v('wa1'), s('locA'))    # the moving particle itself is not a neighbour of its proposal
+else:
+    E(f"""
+    // the moving particle itself (slot 0 of lane tl) is not a neighbour of its proposal
+    s_lshl_b64 {stp(0)}, 1, {s('tl')}
+    s_mov_b64 exec, {stp(0)}
+    v_and_b32 {v('wa0')}, -2, {v('wa0')}
+    s_mov_b64 exec, -1
+    """)
 pick_fetch(V['wa0'], V['wa1'], XA_, sp('wallM'), sp('haveA'))
 wall_fetch(XA_, CA_)
 E("L_nofa:")
-screen_pass(v('bxy'), s('bzz'), v('wb0'), v('wb1'))
+if ZB:
+    screen_ranged("B", s('bxys'), s('bzz'), v('wb0'), v('wb1'))
+    if ZBC:
+        zbc_check(s('bzz'), v('wb0'), v('wb1'))
+else:
+    screen_pass(v('bxy'), s('bzz'), v('wb0'), v('wb1'))
 E(f"""
 v_or_b32 {v('wb0')}, {v('wb0')}, {v('uns0')}
 v_or_b32 {v('wb1')}, {v('wb1')}, {v('uns1')}
@@ -672,29 +1035,48 @@ s_cbranch_scc1 L_ub0
 v_mov_b32 {v('wb0')}, {'-1' if NS >= 32 else '0xffff'}
 v_mov_b32 {v('wb1')}, {'-1' if NS == 64 else '0'}
 L_ub0:
-// not neighbours of B: the particle it stands for (slot 0 of lane tl+1, or slot 1 of lane 0 when the order
-// crosses slots) and the moving particle n (slot 0 of lane tl), which reaches B through the side pair
-s_lshl_b64 {stp(0)}, 1, {s('lb')}
-s_mov_b64 exec, {stp(0)}
-s_cmp_eq_u32 {s('cross')}, 1
-s_cbranch_scc1 L_exBc
-v_and_b32 {v('wb0')}, -2, {v('wb0')}
-s_branch L_exBd
-L_exBc:
-v_and_b32 {v('wb0')}, -3, {v('wb0')}
-L_exBd:
-s_mov_b64 {stp(0)}, {sp('wallM')}
-s_cmp_eq_u32 {s('hasA')}, 0
-s_cbranch_scc1 L_fb1
-s_lshl_b64 {stp(2)}, 1, {s('tl')}
-s_mov_b64 exec, {stp(2)}
-v_and_b32 {v('wb0')}, -2, {v('wb0')}
-s_or_b64 {stp(0)}, {sp('wallM')}, {sp('sideM')}
-L_fb1:
-s_mov_b64 exec, -1
-// probe A's data has had the whole second pass to arrive; B's travels while probe A is evaluated
-s_waitcnt vmcnt(0)
 """)
+if ZB:
+    # not neighbours of B: the particle it stands for, and the moving particle n, which reaches B through the side pair
+    excl(v('wb0'), v('wb1'), s('locB'))
+    E(f"""
+    s_mov_b64 {stp(6)}, {sp('wallM')}
+    s_cmp_eq_u32 {s('hasA')}, 0
+    s_cbranch_scc1 L_fb1
+    """)
+    excl(v('wb0'), v('wb1'), s('locA'))
+    E(f"""
+    s_or_b64 {stp(6)}, {sp('wallM')}, {sp('sideM')}
+    L_fb1:
+    s_mov_b64 {stp(0)}, {stp(6)}
+    // probe A's data has had the whole second pass to arrive; B's travels while probe A is evaluated
+    s_waitcnt vmcnt(0)
+    """)
+else:
+    E(f"""
+    // not neighbours of B: the particle it stands for (slot 0 of lane tl+1, or slot 1 of lane 0 when the order
+    // crosses slots) and the moving particle n (slot 0 of lane tl), which reaches B through the side pair
+    s_lshl_b64 {stp(0)}, 1, {s('lb')}
+    s_mov_b64 exec, {stp(0)}
+    s_cmp_eq_u32 {s('cross')}, 1
+    s_cbranch_scc1 L_exBc
+    v_and_b32 {v('wb0')}, -2, {v('wb0')}
+    s_branch L_exBd
+    L_exBc:
+    v_and_b32 {v('wb0')}, -3, {v('wb0')}
+    L_exBd:
+    s_mov_b64 {stp(0)}, {sp('wallM')}
+    s_cmp_eq_u32 {s('hasA')}, 0
+    s_cbranch_scc1 L_fb1
+    s_lshl_b64 {stp(2)}, 1, {s('tl')}
+    s_mov_b64 exec, {stp(2)}
+    v_and_b32 {v('wb0')}, -2, {v('wb0')}
+    s_or_b64 {stp(0)}, {sp('wallM')}, {sp('sideM')}
+    L_fb1:
+    s_mov_b64 exec, -1
+    // probe A's data has had the whole second pass to arrive; B's travels while probe A is evaluated
+    s_waitcnt vmcnt(0)
+    """)
 pick_fetch(V['wb0'], V['wb1'], XB_, stp(0), sp('haveB'))
 wall_fetch(XB_, CB_)
 E(f"""
@@ -765,27 +1147,89 @@ s_add_u32 {st(2)}, {s('first')}, {s('i')}
 s_mul_i32 {st(2)}, {st(2)}, 24
 v_readfirstlane_b32 {s('E')}, {v('T')}
 v_readfirstlane_b32 {s('E',1)}, {v('T',1)}
-s_mov_b64 exec, {stp(0)}
-v_mov_b32 {xy(0)}, {v('axy')}
-v_and_b32 {v('uns0')}, -2, {v('uns0')}
-v_or_b32 {v('uns0')}, {s('ua')}, {v('uns0')}
-v_mov_b32 {v('T')}, {s('az16')}
-v_mov_b32 v50, {s('Q',0)}
-v_mov_b32 v51, {s('Q',1)}
-v_mov_b32 v52, {s('Q',2)}
-v_mov_b32 v53, {s('Q',3)}
-v_mov_b32 v54, {s('Q',4)}
-v_mov_b32 v55, {s('Q',5)}
-v_mov_b32 {v('T',1)}, {st(2)}
-v_mul_u32_u24 {v('S6')}, 24, {LANE}
-ds_write_b16 {v('zaddr')}, {v('T')}
-global_store_dwordx4 {v('T',1)}, v[50:53], {sp('Rg')}
-global_store_dwordx2 {v('T',1)}, v[54:55], {sp('Rg')} offset:16
-ds_write_b64 {v('S6')}, v[50:51] offset:{LDS_P0}
-ds_write_b64 {v('S6')}, v[52:53] offset:{LDS_P0 + 8}
-ds_write_b64 {v('S6')}, v[54:55] offset:{LDS_P0 + 16}
-s_mov_b64 exec, -1
-s_nop 1
+""")
+if not ZB:
+    E(f"""
+    s_mov_b64 exec, {stp(0)}
+    v_mov_b32 {xy(0)}, {v('axy')}
+    v_and_b32 {v('uns0')}, -2, {v('uns0')}
+    v_or_b32 {v('uns0')}, {s('ua')}, {v('uns0')}
+    v_mov_b32 {v('T')}, {s('az16')}
+    v_mov_b32 v50, {s('Q',0)}
+    v_mov_b32 v51, {s('Q',1)}
+    v_mov_b32 v52, {s('Q',2)}
+    v_mov_b32 v53, {s('Q',3)}
+    v_mov_b32 v54, {s('Q',4)}
+    v_mov_b32 v55, {s('Q',5)}
+    v_mov_b32 {v('T',1)}, {st(2)}
+    v_mul_u32_u24 {v('S6')}, 24, {LANE}
+    ds_write_b16 {v('zaddr')}, {v('T')}
+    global_store_dwordx4 {v('T',1)}, v[50:53], {sp('Rg')}
+    global_store_dwordx2 {v('T',1)}, v[54:55], {sp('Rg')} offset:16
+    ds_write_b64 {v('S6')}, v[50:51] offset:{LDS_P0}
+    ds_write_b64 {v('S6')}, v[52:53] offset:{LDS_P0 + 8}
+    ds_write_b64 {v('S6')}, v[54:55] offset:{LDS_P0 + 16}
+    s_mov_b64 exec, -1
+    s_nop 1
+    """)
+else:
+    # lane tl: the fp64 position to R (particle order), Rs (cell order) and the row cache; then the owner lane of
+    # the particle's cell: packed x,y (indexed register write), unsafe bit, int16 z; then lane g: the group's range
+    E(f"""
+    s_mul_i32 {st(3)}, {s('locA')}, 24
+    s_mov_b64 exec, {stp(0)}
+    v_mov_b32 v50, {s('Q',0)}
+    v_mov_b32 v51, {s('Q',1)}
+    v_mov_b32 v52, {s('Q',2)}
+    v_mov_b32 v53, {s('Q',3)}
+    v_mov_b32 v54, {s('Q',4)}
+    v_mov_b32 v55, {s('Q',5)}
+    v_mov_b32 {v('T',1)}, {st(2)}
+    v_mov_b32 {v('T')}, {st(3)}
+    v_mul_u32_u24 {v('S6')}, 24, {LANE}
+    global_store_dwordx4 {v('T',1)}, v[50:53], {sp('Rg')}
+    global_store_dwordx2 {v('T',1)}, v[54:55], {sp('Rg')} offset:16
+    global_store_dwordx4 {v('T')}, v[50:53], {sp('Rs')}
+    global_store_dwordx2 {v('T')}, v[54:55], {sp('Rs')} offset:16
+    ds_write_b64 {v('S6')}, v[50:51] offset:{LDS_P0}
+    ds_write_b64 {v('S6')}, v[52:53] offset:{LDS_P0 + 8}
+    ds_write_b64 {v('S6')}, v[54:55] offset:{LDS_P0 + 16}
+    s_and_b32 {st(0)}, {s('locA')}, 63
+    s_lshr_b32 {st(1)}, {s('locA')}, 6
+    s_lshl_b64 {stp(2)}, 1, {st(0)}
+    s_lshl_b64 {stp(4)}, 1, {st(1)}
+    s_not_b64 {stp(6)}, {stp(4)}
+    s_cmp_eq_u32 {s('ua')}, 0
+    s_cselect_b64 {stp(4)}, 0, {stp(4)}
+    s_mov_b64 exec, {stp(2)}
+    v_mov_b32 {v('T')}, {s('axys')}
+    v_and_b32 {v('uns0')}, {st(6)}, {v('uns0')}
+    v_and_b32 {v('uns1')}, {st(7)}, {v('uns1')}
+    s_set_gpr_idx_on {st(1)}, gpr_idx(DST)
+    v_mov_b32 {xy(0)}, {v('T')}
+    s_set_gpr_idx_off
+    v_or_b32 {v('uns0')}, {st(4)}, {v('uns0')}
+    v_or_b32 {v('uns1')}, {st(5)}, {v('uns1')}
+    s_lshr_b32 {st(2)}, {st(1)}, 1
+    s_lshl_b32 {st(2)}, {st(2)}, 8
+    s_and_b32 {st(3)}, {st(1)}, 1
+    s_lshl_b32 {st(3)}, {st(3)}, 1
+    s_add_u32 {st(2)}, {st(2)}, {st(3)}
+    v_add_u32 {v('S6')}, {st(2)}, {v('zaddr')}
+    v_mov_b32 {v('T',1)}, {s('az16')}
+    ds_write_b16 {v('S6')}, {v('T',1)}
+    s_lshr_b32 {st(1)}, {st(1)}, 2
+    s_lshl_b64 {stp(2)}, 1, {st(1)}
+    s_sext_i32_i16 {st(0)}, {s('az16')}
+    s_sub_i32 {st(4)}, {st(0)}, {s('M2')}
+    s_add_i32 {st(5)}, {st(0)}, {s('M2')}
+    s_mov_b64 exec, {stp(2)}
+    v_min_i32 {v('gloR')}, {st(4)}, {v('gloR')}
+    v_max_i32 {v('ghiR')}, {st(5)}, {v('ghiR')}
+    s_mov_b64 exec, -1
+    s_nop 1
+    """)
+E(f"""
 L_reject:
 L_noA:
 """)
@@ -871,7 +1315,7 @@ s_lshl_b32 {st(1)}, {st(1)}, 16
 s_or_b32 {st(0)}, {st(0)}, {st(1)}
 s_and_b32 {s('az16')}, {st(2)}, 0xffff
 s_mul_i32 {s('azz')}, {s('az16')}, 0x10001
-v_mov_b32 {v('axy')}, {st(0)}
+{f"s_mov_b32 {s('axys')}, {st(0)}" if ZB else f"v_mov_b32 {v('axy')}, {st(0)}"}
 """)
 E(f"s_cmp_eq_u32 {s('cross')}, 1")
 E("s_cbranch_scc0 L_nocross")
@@ -880,6 +1324,8 @@ E(f"s_mov_b32 {s('tl')}, -1")
 E("L_nocross:")
 E(f"s_add_u32 {s('tl')}, {s('tl')}, 1")
 E("L_noB:")
+if ZB:
+    E(f"s_mov_b32 {s('locA')}, {s('locB')}")
 E(f"""
 s_add_u32 {s('i')}, {s('i')}, 1
 s_mov_b32 {s('hasA')}, 1
@@ -897,15 +1343,49 @@ v_mov_b32 v14, {s('E')}
 v_mov_b32 v15, {s('E',1)}
 v_mov_b32 v16, {s('jacc')}
 v_mov_b32 v17, 0
-s_lshl_b32 {st(0)}, {s('sw')}, 4
-v_mov_b32 v18, {st(0)}
-s_mov_b64 exec, 1
-s_nop 1
-global_store_dwordx4 v18, v[14:17], {sp('rec')}
-s_mov_b64 exec, -1
+""")
+if not ZB:
+    E(f"""
+    s_lshl_b32 {st(0)}, {s('sw')}, 4
+    v_mov_b32 v18, {st(0)}
+    s_mov_b64 exec, 1
+    s_nop 1
+    global_store_dwordx4 v18, v[14:17], {sp('rec')}
+    s_mov_b64 exec, -1
+    """)
+else:
+    E(f"""
+    s_load_dwordx2 {stp(2)}, {KARG}, {K_REC}
+    s_add_u32 {st(0)}, {s('cbase')}, {s('sw')}
+    s_lshl_b32 {st(0)}, {st(0)}, 4
+    v_mov_b32 v18, {st(0)}
+    s_mov_b64 exec, 1
+    s_waitcnt lgkmcnt(0)
+    global_store_dwordx4 v18, v[14:17], {stp(2)}
+    s_mov_b64 exec, -1
+    """)
+E(f"""
 s_add_u32 {s('sw')}, {s('sw')}, 1
 s_cmp_lt_u32 {s('sw')}, {s('nsw')}
 s_cbranch_scc1 L_sweep
+""")
+if ZBC:
+    E(f"""
+    v_lshlrev_b32 v25, 3, {LANE}
+    ds_read_b64 v[22:23], v25 offset:{LDS_CNT}
+    s_load_dwordx2 {stp(2)}, {KARG}, {K_DBG}
+    v_mov_b32 v30, 0
+    v_mov_b32 v27, 0
+    v_mov_b32 v29, 0
+    s_waitcnt lgkmcnt(0)
+    v_mov_b32 v26, v22
+    v_mov_b32 v28, v23
+    global_atomic_add_x2 v30, v[26:27], {stp(2)} offset:8
+    global_atomic_add_x2 v30, v[28:29], {stp(2)} offset:16
+    s_waitcnt vmcnt(0)
+    """)
+CLK1 = clk_ptr(stp(2))
+E(f"""
 // end stamp
 s_memtime {stp(4)}
 s_memrealtime {stp(6)}
@@ -917,7 +1397,7 @@ v_mov_b32 v18, {st(6)}
 v_mov_b32 v19, {st(7)}
 s_mov_b64 exec, 1
 s_nop 1
-global_store_dwordx4 v14, v[16:19], {sp('clk')}
+global_store_dwordx4 v14, v[16:19], {CLK1}
 s_mov_b64 exec, -1
 s_waitcnt vmcnt(0) lgkmcnt(0)
 """)
@@ -926,6 +1406,6 @@ with open(sys.argv[1] if len(sys.argv) > 1 else "smcx_sweep_ma_body.inc", "w") a
     f.write("// generated by gen_sweep_ma.py -- do not edit\n")
     for ln in out:
         # labels are per variant: the three bodies are assembled into one object
-        ln = re.sub(r"\bL_(\w+)", r"L%d_\1" % NS, ln)
+        ln = re.sub(r"\bL_(\w+)", r"L%d%s_\1" % (NS, "z" if ZB else ""), ln)
         f.write('"%s\\n\\t"\n' % ln)
 print("%d lines" % len(out), file=sys.stderr)

@@ -241,7 +241,7 @@ extern "C" int smcx_destroy(smcx_handle *hh)
     hipFree(c.uni); hipFree(c.offs); hipFree(c.obs); hipFree(c.zhist); hipFree(c.Eseries);
     hipFree(c.jjseries); hipFree(c.rec); hipFree(h.d_save); hipFree(h.d_tmp);
     hipFree(c.D); hipFree(c.Mu); hipFree(c.Rbin); hipFree(c.Pseries);
-    hipFree(h.lca_bits); hipFree(h.lca_counts); hipFree(c.clk); hipFree((void *)c.wtab);
+    hipFree(h.lca_bits); hipFree(h.lca_counts); hipFree(c.clk); hipFree((void *)c.wtab); hipFree(c.Rs); hipFree(c.loc);
 #ifdef SMCX_CHECK
     hipFree(c.dbg);
 #endif
@@ -306,6 +306,10 @@ extern "C" int smcx_create(const smcx_params *p, smcx_handle **out)
     CRT(hipMalloc((void **)&c.wtab, (size_t)(c.M2 + 1) * 4 * sizeof(double)));
     CRT(hipMalloc(&c.clk, nrep * 4 * sizeof(unsigned long long)));
     CRT(hipMemset(c.clk, 0, nrep * 4 * sizeof(unsigned long long)));
+    if (mb_supported(h.S, h.WPR, p->N, (p->flags & SMCX_FLAG_WALLS) ? c.M2 : 0)) { // cell-ordered copy for sweep_kernel_mb
+        CRT(hipMalloc(&c.Rs, nrep * 4096 * 3 * sizeof(double)));
+        CRT(hipMalloc(&c.loc, nrep * N * sizeof(unsigned short)));
+    }
     CRT(hipMalloc(&h.d_save, nrep * sizeof(double)));
     CRT(hipMalloc(&h.d_tmp, nrep * sizeof(double)));
     if (p->flags & SMCX_FLAG_FULL_HIST) {

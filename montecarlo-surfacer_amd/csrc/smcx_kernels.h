@@ -26,7 +26,8 @@ hipError_t launch_sweeps_mi(const SweepArgs &a, const DevCtx &c, int S, int nswe
 
 // hand-scheduled form of the same kernel for 64 particles per lane (smcx_sweep_ma.hip)
 bool ma_supported(int S, int WPR, int N, int M2);
-const char *ma_kernel_name(int S);
+const char *ma_kernel_name(int S, int N);
+bool mb_supported(int S, int WPR, int N, int M2);
 hipError_t launch_sweeps_ma(const SweepArgs &s, const DevCtx &c, int S, const double *wtab, int nsweeps, double A,
                             double toFix, double zFix, double zsafe, int negC, hipStream_t st);
 

@@ -23,13 +23,21 @@ struct MaArgs {
     double L, invL, cutoff2, invT, AoT, Ao4T, toFix, zFix;   // 0x40 .. 0x78
     double zsafe, halfLz, Lz, invLz;                          // 0x80 .. 0x98
     int N, chunk, nsweeps, negC;                              // 0xa0 .. 0xac
-    int M2, pad0, pad1, pad2;                                 // 0xb0  (M2 < 0: no walls)
+    int M2, RZ;                                               // 0xb0  (M2 < 0: no walls) ; mb: reach of the screen in z units
+    double *Rs;                                               // 0xb8  mb: positions in cell order [nrep][S*64][3]
+    const unsigned short *loc;                                // 0xc0  mb: cell of each particle [nrep][N]
+    int sw0, pad0;                                            // 0xc8  mb: first sweep of this launch within the chunk
+    unsigned long long *dbg;                                  // 0xd0  diagnostic build: the screen's counters
+    unsigned long long pad1;
 };
-static_assert(sizeof(MaArgs) == 0xc0, "offsets are hard-wired in gen_sweep_ma.py");
+static_assert(sizeof(MaArgs) == 0xe0, "offsets are hard-wired in gen_sweep_ma.py");
 
 // LDS (dynamic, at launch; the body addresses it by fixed offsets): unsigned zw[S/2][64] (int16 z, slot pairs x
 // lanes) at 0, double p0[65][3] (fp64 positions of the slot-0 particles + lane 0's slot-1 particle) behind it
 constexpr unsigned ma_lds_bytes(int S) { return (unsigned)(S / 2) * 256u + 65u * 24u; }
+// sweep_kernel_mb: + int gb[64][2], the (lowest, highest) z of each 4-slot group while the compact copies are built
+// (+ the diagnostic build's per-lane counters)
+constexpr unsigned mb_lds_bytes(int S) { return ma_lds_bytes(S) + 512u + 512u; }
 
 #define SMCX_MA_SGPRS "s0", "s1", "s2", "s3", "s4", "s5", "s6", "s7", "s8", "s9", "s10", "s11", "s12", "s13", "s14", "s15", "s16", "s17", "s18", "s19", "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27", "s28", "s29", "s30", "s31", "s32", "s33", "s34", "s35", "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95"
 #define SMCX_MA_V63 "v1", "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17", "v18", "v19", "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63"
@@ -74,18 +82,94 @@ __global__ void __launch_bounds__(64, 6) sweep_kernel_ma16(MaArgs a)
         : "memory", "vcc", "scc", SMCX_MA_SGPRS, SMCX_MA_V79);
 }
 
+// z-binned form (gen_sweep_ma.py ... zb): the cells hold the particles in z order (zsort_kernel below), a probe
+// screens only the 4-slot groups whose z range can reach it
+__global__ void __launch_bounds__(64, 4) sweep_kernel_mb64(MaArgs a)
+{
+    unsigned lane = threadIdx.x;
+    unsigned long long kp = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
+    unsigned rep = blockIdx.x;
+    asm volatile(
+#ifdef SMCX_CHECK
+#include "smcx_sweep_mbc_body64.inc" // + the full screen beside every ranged pass, counting what the latter lacks
+#else
+#include "smcx_sweep_mb_body64.inc"
+#endif
+        : "+v"(lane), "+s"(kp), "+s"(rep)
+        :
+        : "memory", "vcc", "scc", "m0", SMCX_MA_SGPRS, SMCX_MA_V127);
+}
+
+// Order of the cells for sweep_kernel_mb: the particles of a replica sorted by z (bitonic sort of (float z,
+// particle) keys in LDS), written as Rs[cell] = position and loc[particle] = cell; cells beyond N stay empty.
+// One workgroup per replica.  The sweep kernel keeps R and Rs both current, so this reads R only.
+template <int CELLS>
+__global__ void __launch_bounds__(256) zsort_kernel(const double *__restrict__ R, double *__restrict__ Rs,
+                                                    unsigned short *__restrict__ loc, int N)
+{
+    __shared__ unsigned long long key[CELLS];
+    const double *Rr = R + (size_t)blockIdx.x * 3 * N;
+    for (int n = threadIdx.x; n < CELLS; n += 256) {
+        unsigned long long k = ~0ull;
+        if (n < N) {
+            unsigned u = __float_as_uint((float)Rr[3 * n + 2]);
+            u = (u & 0x80000000u) ? ~u : (u | 0x80000000u); // order of the floats as unsigned integers
+            k = ((unsigned long long)u << 32) | (unsigned)n;
+        }
+        key[n] = k;
+    }
+    __syncthreads();
+    for (int k = 2; k <= CELLS; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = threadIdx.x; t < CELLS / 2; t += 256) {
+                const int i = 2 * t - (t & (j - 1)); // lower index of the pair (bit j clear)
+                const int q = i + j;
+                const unsigned long long a = key[i], b = key[q];
+                const bool up = ((i & k) == 0);
+                if ((a > b) == up) { key[i] = b; key[q] = a; }
+            }
+            __syncthreads();
+        }
+    for (int c = threadIdx.x; c < CELLS; c += 256) {
+        const unsigned long long k = key[c];
+        double *d = Rs + ((size_t)blockIdx.x * CELLS + c) * 3;
+        if (k != ~0ull) {
+            const unsigned n = (unsigned)k;
+            loc[(size_t)blockIdx.x * N + n] = (unsigned short)c;
+            d[0] = Rr[3 * n]; d[1] = Rr[3 * n + 1]; d[2] = Rr[3 * n + 2];
+        } else {
+            d[0] = d[1] = d[2] = 0.0;
+        }
+    }
+}
+
 bool ma_supported(int S, int WPR, int N, int M2)
 {
     if (S != 16 && S != 32 && S != 64) return false;
 #ifdef SMCX_CHECK
-    return false; // the diagnostic build counts the screen's misses in sweep_kernel_mi (same screen, hipcc-scheduled)
+    // the diagnostic build counts the screen's misses in sweep_kernel_mi (same screen, hipcc-scheduled); with
+    // SMCX_CHECK_MB=1 it runs sweep_kernel_mb64 instead, whose ranged passes are checked against full ones
+    static const char *chk = getenv("SMCX_CHECK_MB");
+    if (!(chk && chk[0] == '1' && S == 64)) return false;
 #endif
     static const char *env = getenv("SMCX_MA"); // SMCX_MA=0: sweep_kernel_mi instead, for A/B measurements
     if (env && env[0] == '0') return false;
     return WPR == 1 && N > 32 * S && N <= 64 * S && M2 + 1 <= 30;
 }
 
-const char *ma_kernel_name(int S) { return S == 64 ? "smcx::sweep_kernel_ma64" : S == 32 ? "smcx::sweep_kernel_ma32" : "smcx::sweep_kernel_ma16"; }
+// the z-binned form serves the 64-particles-per-lane geometry; SMCX_MB=0 keeps sweep_kernel_ma64 (A/B measurements)
+bool mb_supported(int S, int WPR, int N, int M2)
+{
+    static const char *env = getenv("SMCX_MB");
+    if (env && env[0] == '0') return false;
+    return S == 64 && ma_supported(S, WPR, N, M2);
+}
+
+const char *ma_kernel_name(int S, int N)
+{
+    if (mb_supported(S, 1, N, 0)) return "smcx::sweep_kernel_mb64";
+    return S == 64 ? "smcx::sweep_kernel_ma64" : S == 32 ? "smcx::sweep_kernel_ma32" : "smcx::sweep_kernel_ma16";
+}
 
 // wtab: [M2 + 1][4] doubles on the device, built by the caller (smcx_api.hip)
 hipError_t launch_sweeps_ma(const SweepArgs &s, const DevCtx &c, int S, const double *wtab, int nsweeps, double A,
@@ -98,7 +182,26 @@ hipError_t launch_sweeps_ma(const SweepArgs &s, const DevCtx &c, int S, const do
     a.AoT = A * s.invT; a.Ao4T = A * 0.25 * s.invT; a.toFix = toFix; a.zFix = zFix;
     a.zsafe = zsafe; a.halfLz = c.halfLz; a.Lz = c.Lz; a.invLz = c.invLz;
     a.N = s.N; a.chunk = s.chunk; a.nsweeps = nsweeps; a.negC = negC;
-    a.M2 = (c.flags & 0x1u) ? c.M2 : -1; a.pad0 = a.pad1 = a.pad2 = 0;
+    a.M2 = (c.flags & 0x1u) ? c.M2 : -1;
+    a.RZ = 0; a.Rs = nullptr; a.loc = nullptr; a.sw0 = 0; a.pad0 = 0; a.dbg = nullptr; a.pad1 = 0;
+#ifdef SMCX_CHECK
+    a.dbg = s.dbg;
+#endif
+    if (mb_supported(S, 1, s.N, a.M2) && c.Rs && c.loc) {
+        // a slot is flagged only if dz^2 < ceil(C / 4^ZS) (dz in z units, C = -negC): the screen's reach in z
+        const long T = ((long)(-negC) + 255) >> 8;
+        a.RZ = (int)std::floor(std::sqrt((double)T)) + 1;
+        a.Rs = c.Rs; a.loc = c.loc;
+        // the cells are re-sorted by z every `every` sweeps (SMCX_RESORT, default 1): the groups' z ranges only
+        // widen inside a launch
+        static const int every = [] { const char *e = getenv("SMCX_RESORT"); int v = e ? atoi(e) : 1; return v > 0 ? v : 1; }();
+        for (int sw = 0; sw < nsweeps; sw += every) {
+            hipLaunchKernelGGL(zsort_kernel<64 * 64>, dim3(c.nrep), dim3(256), 0, st, (const double *)s.R, c.Rs, c.loc, s.N);
+            a.sw0 = sw; a.nsweeps = nsweeps - sw < every ? nsweeps - sw : every;
+            hipLaunchKernelGGL(sweep_kernel_mb64, dim3(c.nrep), dim3(64), mb_lds_bytes(64), st, a);
+        }
+        return hipGetLastError();
+    }
     void (*f)(MaArgs) = S == 64 ? sweep_kernel_ma64 : S == 32 ? sweep_kernel_ma32 : sweep_kernel_ma16;
     hipLaunchKernelGGL(f, dim3(c.nrep), dim3(64), ma_lds_bytes(S), st, a);
     return hipGetLastError();

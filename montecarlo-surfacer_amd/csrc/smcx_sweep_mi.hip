@@ -608,7 +608,7 @@ bool mi_supported(int S, int WPR, double L, double Lz, double cutoff2)
 const char *mi_kernel_name(int S, int N, double L, double Lz)
 {
     const int zs = mi_zshift(L, Lz);
-    if (zs == 4 && ma_supported(S, 1, N, 0)) return ma_kernel_name(S);
+    if (zs == 4 && ma_supported(S, 1, N, 0)) return ma_kernel_name(S, N);
 #define SMCX_MI(s, z, w) if (S == s && zs == z) return "smcx::sweep_kernel_mi<" #s ", " #z ", " #w ">";
     SMCX_MI_TABLE(SMCX_MI)
 #undef SMCX_MI
