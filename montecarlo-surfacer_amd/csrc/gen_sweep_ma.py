@@ -53,8 +53,8 @@ ZBC = len(sys.argv) > 3 and sys.argv[3] == "zbc"        # diagnostic: every pass
 ZB = ZBC or (len(sys.argv) > 3 and sys.argv[3] == "zb")   # the bits the ranged pass lacks (must be none)
 NG = NS // 4                                              # 4-slot groups
 LDS_P0 = (NS // 2) * 256                                  # after the int16 z words
-LDS_GB = LDS_P0 + 65 * 24                                 # zb: (min, max) z of each group while the copies are built
-LDS_CNT = LDS_GB + 512                                    # zbc: per lane (candidates, bits missing from the ranged pass)
+LDS_GB = LDS_P0                                           # zb: (min, max) z of each group while the copies are built (p0 is filled afterwards)
+LDS_CNT = LDS_P0 + 65 * 24 + 8                            # zbc: per lane (candidates, bits missing from the ranged pass)
 LANE, KARG, REP = "%0", "%1", "%2"
 
 V = dict(zaddr=1, uns0=2, uns1=3, wa0=4, wa1=5, wb0=6, wb1=7, axy=8, bxy=9,

@@ -35,7 +35,7 @@ struct Handle {
     double last_ms = 0.0;       // whole run
     double last_sweep_ms = 0.0; // sweep kernels only
     int last_launches = 0;
-    std::vector<hipEvent_t> evs; // start/stop pairs around the sweep launches
+    SweepTimer timer;            // start/stop events around every launch of the sweep kernel
     std::vector<int> last_sweeps; // sweeps in each launch of the last run
     int last_gathers = 0;
     // cluster analysis (SMCX_FLAG_CLUSTERS or on demand)
@@ -245,7 +245,7 @@ extern "C" int smcx_destroy(smcx_handle *hh)
 #ifdef SMCX_CHECK
     hipFree(c.dbg);
 #endif
-    for (hipEvent_t e : h.evs) hipEventDestroy(e);
+    for (hipEvent_t e : h.timer.evs) hipEventDestroy(e);
     if (h.ev0) hipEventDestroy(h.ev0);
     if (h.ev1) hipEventDestroy(h.ev1);
     if (h.stream) hipStreamDestroy(h.stream);
@@ -525,14 +525,7 @@ static int run_phase(Handle &h, int steps, double A, int production, int gather_
             if (next - done < k) k = next - done;
         }
         HIPCHK(&h, launch_rng_prepass(h.c, k, A, h.stream));
-        while ((int)h.evs.size() < 2 * (h.last_launches + 1)) {
-            hipEvent_t e;
-            HIPCHK(&h, hipEventCreate(&e));
-            h.evs.push_back(e);
-        }
-        HIPCHK(&h, hipEventRecord(h.evs[2 * h.last_launches], h.stream));
-        HIPCHK(&h, launch_sweeps(h.c, h.S, h.WPR, k, A, h.p.tune_kernel, h.stream));
-        HIPCHK(&h, hipEventRecord(h.evs[2 * h.last_launches + 1], h.stream));
+        HIPCHK(&h, launch_sweeps(h.c, h.S, h.WPR, k, A, h.p.tune_kernel, h.stream, &h.timer));
         HIPCHK(&h, launch_finalize(h.c, k, production, done, (production && first) ? 1 : 0, h.stream));
         h.last_launches++;
         h.last_sweeps.push_back(k);
@@ -552,6 +545,7 @@ extern "C" int smcx_run(smcx_handle *hh, int eqsteps, int maxsteps, int gather_l
     int rc = ensure_series(h, maxsteps);
     if (rc != SMCX_OK) return rc;
     h.last_launches = 0;
+    h.timer.n = 0;
     h.last_sweeps.clear();
     h.last_gathers = 0;
     if (h.c.D) { // D, Mu and Rbin start from zero in every sMC call (SMC.c:52-55)
@@ -593,9 +587,9 @@ extern "C" int smcx_run(smcx_handle *hh, int eqsteps, int maxsteps, int gather_l
     HIPCHK(&h, hipEventElapsedTime(&ms, h.ev0, h.ev1));
     h.last_ms = ms;
     h.last_sweep_ms = 0.0;
-    for (int i = 0; i < h.last_launches; i++) {
+    for (int i = 0; i + 1 < h.timer.n; i += 2) {
         float t = 0.f;
-        HIPCHK(&h, hipEventElapsedTime(&t, h.evs[2 * i], h.evs[2 * i + 1]));
+        HIPCHK(&h, hipEventElapsedTime(&t, h.timer.evs[i], h.timer.evs[i + 1]));
         h.last_sweep_ms += t;
     }
     h.last_maxsteps = maxsteps;
@@ -607,7 +601,7 @@ extern "C" int smcx_last_kernel_ms(smcx_handle *hh, double *ms, int *launches)
 {
     if (!hh) return SMCX_ERR_PARAM;
     if (ms) *ms = hh->h.last_sweep_ms;
-    if (launches) *launches = hh->h.last_launches;
+    if (launches) *launches = hh->h.timer.n / 2; // launches of the sweep kernel (sweep_kernel_mb64: one per sweep)
     return SMCX_OK;
 }
 

@@ -785,7 +785,8 @@ bool sweep_uses_mx(int S, int WPR, int kernel)
     return mx_supported(S, WPR); // auto
 }
 
-hipError_t launch_sweeps(const DevCtx &c, int S, int WPR, int nsweeps, double A, int kernel, hipStream_t st)
+hipError_t launch_sweeps(const DevCtx &c, int S, int WPR, int nsweeps, double A, int kernel, hipStream_t st,
+                         SweepTimer *tm)
 {
     const bool lead = use_lead(S, WPR);
     sweep_fn f = lookup(S, WPR, lead);
@@ -800,10 +801,17 @@ hipError_t launch_sweeps(const DevCtx &c, int S, int WPR, int nsweeps, double A,
 #ifdef SMCX_CHECK
     a.dbg = c.dbg;
 #endif
-    if (use_mx && mi_supported(S, WPR, c.L, c.Lz, c.cutoff2)) return launch_sweeps_mi(a, c, S, nsweeps, A, st);
-    if (use_mx) return launch_sweeps_mx(a, c, S, WPR, nsweeps, A, st);
-    hipLaunchKernelGGL(f, dim3(c.nrep), dim3(64 * WPR), 0, st, a, c, nsweeps, A);
-    return hipGetLastError();
+    if (use_mx && mi_supported(S, WPR, c.L, c.Lz, c.cutoff2)) return launch_sweeps_mi(a, c, S, nsweeps, A, st, tm);
+    hipError_t rc = tm ? tm->mark(st) : hipSuccess;
+    if (rc != hipSuccess) return rc;
+    if (use_mx) {
+        rc = launch_sweeps_mx(a, c, S, WPR, nsweeps, A, st);
+    } else {
+        hipLaunchKernelGGL(f, dim3(c.nrep), dim3(64 * WPR), 0, st, a, c, nsweeps, A);
+        rc = hipGetLastError();
+    }
+    if (rc == hipSuccess && tm) rc = tm->mark(st);
+    return rc;
 }
 
 hipError_t launch_finalize(const DevCtx &c, int nsweeps, int production, int sweep_base,

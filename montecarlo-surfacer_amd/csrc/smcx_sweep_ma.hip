@@ -35,9 +35,13 @@ static_assert(sizeof(MaArgs) == 0xe0, "offsets are hard-wired in gen_sweep_ma.py
 // LDS (dynamic, at launch; the body addresses it by fixed offsets): unsigned zw[S/2][64] (int16 z, slot pairs x
 // lanes) at 0, double p0[65][3] (fp64 positions of the slot-0 particles + lane 0's slot-1 particle) behind it
 constexpr unsigned ma_lds_bytes(int S) { return (unsigned)(S / 2) * 256u + 65u * 24u; }
-// sweep_kernel_mb: + int gb[64][2], the (lowest, highest) z of each 4-slot group while the compact copies are built
-// (+ the diagnostic build's per-lane counters)
-constexpr unsigned mb_lds_bytes(int S) { return ma_lds_bytes(S) + 512u + 512u; }
+// sweep_kernel_mb: the same 9752 bytes (16 wavefronts per CU fit in 160 KB); int gb[64][2], the (lowest, highest) z
+// of each 4-slot group, overlays p0 while the compact copies are built.  The diagnostic build adds per-lane counters.
+#ifdef SMCX_CHECK
+constexpr unsigned mb_lds_bytes(int S) { return ma_lds_bytes(S) + 8u + 512u; }
+#else
+constexpr unsigned mb_lds_bytes(int S) { return ma_lds_bytes(S); }
+#endif
 
 #define SMCX_MA_SGPRS "s0", "s1", "s2", "s3", "s4", "s5", "s6", "s7", "s8", "s9", "s10", "s11", "s12", "s13", "s14", "s15", "s16", "s17", "s18", "s19", "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27", "s28", "s29", "s30", "s31", "s32", "s33", "s34", "s35", "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95"
 #define SMCX_MA_V63 "v1", "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17", "v18", "v19", "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63"
@@ -100,12 +104,43 @@ __global__ void __launch_bounds__(64, 4) sweep_kernel_mb64(MaArgs a)
         : "memory", "vcc", "scc", "m0", SMCX_MA_SGPRS, SMCX_MA_V127);
 }
 
-// Order of the cells for sweep_kernel_mb: the particles of a replica sorted by z (bitonic sort of (float z,
-// particle) keys in LDS), written as Rs[cell] = position and loc[particle] = cell; cells beyond N stay empty.
-// One workgroup per replica.  The sweep kernel keeps R and Rs both current, so this reads R only.
+// Order of the cells for sweep_kernel_mb.  Cell = slot * 64 + lane; a group = 4 slots = 256 cells.
+//  1. the particles of a replica sorted by z (bitonic sort of (float z, particle) keys in LDS): group g holds
+//     ranks 256 g .. 256 g + 255, so its z range is as narrow as the configuration allows;
+//  2. inside every full group, sorted along a Morton curve in (x, y) and dealt to the lanes round-robin, the deal
+//     of group g starting at lane 16 (g mod 4): the candidates of one probe are close in (x, y) and spread over
+//     three or four consecutive groups, so they land in different lanes and the kernel needs one evaluation
+//     round per probe instead of one per candidate of the fullest lane.
+// Written as Rs[cell] = position and loc[particle] = cell; a partial last group keeps z order, so the cells beyond N
+// are the empty ones.  One workgroup per replica.  The sweep kernel keeps R and Rs both current: this reads R only.
+__device__ inline unsigned spread8(unsigned v)
+{
+    v &= 0xffu;
+    v = (v | (v << 4)) & 0x0f0fu;
+    v = (v | (v << 2)) & 0x3333u;
+    v = (v | (v << 1)) & 0x5555u;
+    return v;
+}
+
+template <int CELLS, bool ASCENDING_AT>
+__device__ inline void bitonic_lds(unsigned long long *key, int kmax)
+{
+    for (int k = 2; k <= kmax; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = threadIdx.x; t < CELLS / 2; t += 256) {
+                const int i = 2 * t - (t & (j - 1)); // lower index of the pair (bit j clear)
+                const int q = i + j;
+                const unsigned long long a = key[i], b = key[q];
+                const bool up = ((i & k) == 0) || (ASCENDING_AT && k == kmax);
+                if ((a > b) == up) { key[i] = b; key[q] = a; }
+            }
+            __syncthreads();
+        }
+}
+
 template <int CELLS>
 __global__ void __launch_bounds__(256) zsort_kernel(const double *__restrict__ R, double *__restrict__ Rs,
-                                                    unsigned short *__restrict__ loc, int N)
+                                                    unsigned short *__restrict__ loc, int N, double toFix)
 {
     __shared__ unsigned long long key[CELLS];
     const double *Rr = R + (size_t)blockIdx.x * 3 * N;
@@ -119,19 +154,26 @@ __global__ void __launch_bounds__(256) zsort_kernel(const double *__restrict__ R
         key[n] = k;
     }
     __syncthreads();
-    for (int k = 2; k <= CELLS; k <<= 1)
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int t = threadIdx.x; t < CELLS / 2; t += 256) {
-                const int i = 2 * t - (t & (j - 1)); // lower index of the pair (bit j clear)
-                const int q = i + j;
-                const unsigned long long a = key[i], b = key[q];
-                const bool up = ((i & k) == 0);
-                if ((a > b) == up) { key[i] = b; key[q] = a; }
-            }
-            __syncthreads();
+    bitonic_lds<CELLS, false>(key, CELLS);
+    const int full = N >> 8; // groups with 256 particles
+    for (int p = threadIdx.x; p < CELLS; p += 256) {
+        const unsigned long long k = key[p];
+        if (k == ~0ull) continue;
+        const unsigned n = (unsigned)k;
+        unsigned sub = (unsigned)(p & 255); // a partial group keeps z order
+        if ((p >> 8) < full) {
+            const unsigned ix = ((unsigned)(int)rint(Rr[3 * n] * toFix) + 0x8000u) >> 8;     // 8 bits of the wrapped x
+            const unsigned iy = ((unsigned)(int)rint(Rr[3 * n + 1] * toFix) + 0x8000u) >> 8;
+            sub = spread8(ix) | (spread8(iy) << 1);
         }
-    for (int c = threadIdx.x; c < CELLS; c += 256) {
-        const unsigned long long k = key[c];
+        key[p] = ((unsigned long long)(p >> 8) << 48) | ((unsigned long long)sub << 32) | n;
+    }
+    __syncthreads();
+    bitonic_lds<CELLS, true>(key, 256);
+    for (int p = threadIdx.x; p < CELLS; p += 256) {
+        const unsigned long long k = key[p];
+        const int g = p >> 8, r = p & 255;
+        const int c = g < full ? (4 * g + (r >> 6)) * 64 + ((r + 16 * (g & 3)) & 63) : p;
         double *d = Rs + ((size_t)blockIdx.x * CELLS + c) * 3;
         if (k != ~0ull) {
             const unsigned n = (unsigned)k;
@@ -173,7 +215,7 @@ const char *ma_kernel_name(int S, int N)
 
 // wtab: [M2 + 1][4] doubles on the device, built by the caller (smcx_api.hip)
 hipError_t launch_sweeps_ma(const SweepArgs &s, const DevCtx &c, int S, const double *wtab, int nsweeps, double A,
-                            double toFix, double zFix, double zsafe, int negC, hipStream_t st)
+                            double toFix, double zFix, double zsafe, int negC, hipStream_t st, SweepTimer *tm)
 {
     MaArgs a;
     a.R = s.R; a.displ = s.displ; a.uni = s.uni; a.offs = s.offs; a.obs = s.obs; a.rec = s.rec;
@@ -196,15 +238,24 @@ hipError_t launch_sweeps_ma(const SweepArgs &s, const DevCtx &c, int S, const do
         // widen inside a launch
         static const int every = [] { const char *e = getenv("SMCX_RESORT"); int v = e ? atoi(e) : 1; return v > 0 ? v : 1; }();
         for (int sw = 0; sw < nsweeps; sw += every) {
-            hipLaunchKernelGGL(zsort_kernel<64 * 64>, dim3(c.nrep), dim3(256), 0, st, (const double *)s.R, c.Rs, c.loc, s.N);
+            hipLaunchKernelGGL(zsort_kernel<64 * 64>, dim3(c.nrep), dim3(256), 0, st, (const double *)s.R, c.Rs, c.loc, s.N, toFix);
             a.sw0 = sw; a.nsweeps = nsweeps - sw < every ? nsweeps - sw : every;
+            hipError_t rc = tm ? tm->mark(st) : hipSuccess;
+            if (rc != hipSuccess) return rc;
             hipLaunchKernelGGL(sweep_kernel_mb64, dim3(c.nrep), dim3(64), mb_lds_bytes(64), st, a);
+            rc = hipGetLastError();
+            if (rc == hipSuccess && tm) rc = tm->mark(st);
+            if (rc != hipSuccess) return rc;
         }
-        return hipGetLastError();
+        return hipSuccess;
     }
     void (*f)(MaArgs) = S == 64 ? sweep_kernel_ma64 : S == 32 ? sweep_kernel_ma32 : sweep_kernel_ma16;
+    hipError_t rc = tm ? tm->mark(st) : hipSuccess;
+    if (rc != hipSuccess) return rc;
     hipLaunchKernelGGL(f, dim3(c.nrep), dim3(64), ma_lds_bytes(S), st, a);
-    return hipGetLastError();
+    rc = hipGetLastError();
+    if (rc == hipSuccess && tm) rc = tm->mark(st);
+    return rc;
 }
 
 } // namespace smcx

@@ -628,7 +628,8 @@ void mi_bound_values(double L, double Lz, double cutoff2, double *thr, double *u
     *thr = -(double)m.negC * u * u; *u2 = u * u; *toFix = m.toFix; *zsafe = m.zsafe; *uz = 1.0 / m.zFix; *negC = m.negC;
 }
 
-hipError_t launch_sweeps_mi(const SweepArgs &a, const DevCtx &c, int S, int nsweeps, double A, hipStream_t st)
+hipError_t launch_sweeps_mi(const SweepArgs &a, const DevCtx &c, int S, int nsweeps, double A, hipStream_t st,
+                            SweepTimer *tm)
 {
     const int zs = mi_zshift(c.L, c.Lz);
     sweep_mi_fn f = zs ? lookup_mi(S, zs) : nullptr;
@@ -636,13 +637,17 @@ hipError_t launch_sweeps_mi(const SweepArgs &a, const DevCtx &c, int S, int nswe
     if (!f || !mi_bound(c.L, c.Lz, c.cutoff2, zs, &m)) return hipErrorInvalidValue;
     // 64 particles per lane with the standard z unit: the hand-scheduled form of this kernel
     if (zs == 4 && c.wtab && ma_supported(S, 1, c.N, (c.flags & 0x1u) ? c.M2 : 0))
-        return launch_sweeps_ma(a, c, S, c.wtab, nsweeps, A, m.toFix, m.zFix, m.zsafe, m.negC, st);
+        return launch_sweeps_ma(a, c, S, c.wtab, nsweeps, A, m.toFix, m.zFix, m.zsafe, m.negC, st, tm);
     MiWalls wl;
     wl.on = (c.flags & 0x1u) ? 1 : 0; wl.M = c.M; wl.M2 = c.M2;
     wl.dw = c.L / c.M; wl.Lz = c.Lz; wl.invLz = c.invLz; wl.halfLz = c.halfLz;
     wl.Wx = c.W; // smcx_create / smcx_upload keep a0, b0 behind the 2 M2 site strengths
+    hipError_t rc = tm ? tm->mark(st) : hipSuccess;
+    if (rc != hipSuccess) return rc;
     hipLaunchKernelGGL(f, dim3(c.nrep), dim3(64), 0, st, a, wl, nsweeps, A, m);
-    return hipGetLastError();
+    rc = hipGetLastError();
+    if (rc == hipSuccess && tm) rc = tm->mark(st);
+    return rc;
 }
 
 } // namespace smcx
