@@ -91,9 +91,12 @@ S = dict(Rg=0, displ=2, uni=4, dK=6, uK=8, wtab=10, rec=12, clk=14,
 if ZB:
     # displ/uni/rec/clk are re-derived from the kernel arguments where they are used; their registers hold
     # Rs, the cells of particles n and n+1, the probes' packed x,y and the compact copy of particle row*64 + 64
-    for k in ('displ', 'uni', 'rec', 'clk'):
+    # ... n0, vbase and cbase live in temporaries where a run starts; the lanes of the wall sites, the plane and
+    # the side pair are chosen per probe among the lanes without a candidate (wallM/planeM = probe A's, wallB/
+    # planeB = probe B's, sideL = the side pair's lane)
+    for k in ('displ', 'uni', 'rec', 'clk', 'n0', 'vbase', 'cbase', 'sideM'):
         del S[k]
-    S.update(Rs=2, locA=4, locB=5, axys=12, bxys=13, nxy=14, nzl=15)
+    S.update(Rs=2, locA=4, locB=5, axys=12, bxys=13, nxy=14, nzl=15, first=65, planeB=48, sideL=64, wallB=86)
 
 
 def s(name, i=0): return "s%d" % (S[name] + i)
@@ -133,7 +136,7 @@ s_waitcnt lgkmcnt(0)
 s_mov_b32 {s('N')}, {st(4)}
 s_mov_b32 {s('nsw')}, {st(6)}
 s_mov_b32 {s('negC')}, {st(7)}
-s_mul_i32 {s('cbase')}, {REP}, {st(5)}
+{'' if ZB else f"s_mul_i32 {s('cbase')}, {REP}, {st(5)}"}
 s_mov_b32 {s('neg24')}, 0
 s_mov_b32 {s('neg24',1)}, 0xc0380000
 // Rg = R + rep * N * 24 ; rec += rep * chunk * 16 ; clk += rep * 32
@@ -169,13 +172,25 @@ else:
     s_cmp_eq_u32 {st(3)}, 0
     s_cbranch_scc1 L_e0
     s_load_dwordx2 {stp(4)}, {KARG}, {K_REC}
-    s_add_u32 {st(0)}, {s('cbase')}, {st(3)}
+    s_load_dword {st(0)}, {KARG}, {K_INTS + 4}
+    s_waitcnt lgkmcnt(0)
+    s_mul_i32 {st(0)}, {st(0)}, {REP}
+    s_add_u32 {st(0)}, {st(0)}, {st(3)}
     s_sub_u32 {st(0)}, {st(0)}, 1
     s_lshl_b32 {st(0)}, {st(0)}, 4
     s_waitcnt lgkmcnt(0)
     s_load_dwordx2 {sp('E')}, {stp(4)}, {st(0)}
     s_waitcnt lgkmcnt(0)
     L_e0:
+    """)
+
+
+def cbase_to(dst):
+    """zb: dst (s) <- rep * chunk, the replica's first row in the per-sweep arrays (the other kernels keep it in a register)"""
+    E(f"""
+    s_load_dword {dst}, {KARG}, {K_INTS + 4}
+    s_waitcnt lgkmcnt(0)
+    s_mul_i32 {dst}, {dst}, {REP}
     """)
 
 
@@ -208,18 +223,23 @@ v_mov_b32 v19, {st(7)}
 s_mov_b64 exec, 1
 global_store_dwordx4 v14, v[16:19], {CLK0}
 s_mov_b64 exec, -1
-// masks of the special lanes: wall sites + plane = lanes 0..M2 (none if M2 < 0), plane = lane M2, side pair = lane 30
-s_mov_b64 {sp('wallM')}, 0
-s_mov_b64 {sp('planeM')}, 0
-s_cmp_lt_i32 {s('M2')}, 0
-s_cbranch_scc1 L_nowalls
-s_add_u32 {st(2)}, {s('M2')}, 1
-s_lshl_b64 {sp('wallM')}, 1, {st(2)}
-s_sub_u32 {s('wallM')}, {s('wallM')}, 1
-s_lshl_b64 {sp('planeM')}, 1, {s('M2')}
-L_nowalls:
-s_mov_b32 {s('sideM')}, 0x40000000
-s_mov_b32 {s('sideM',1)}, 0
+""")
+if not ZB:
+    E(f"""
+    // masks of the special lanes: wall sites + plane = lanes 0..M2 (none if M2 < 0), plane = lane M2, side pair = lane 30
+    s_mov_b64 {sp('wallM')}, 0
+    s_mov_b64 {sp('planeM')}, 0
+    s_cmp_lt_i32 {s('M2')}, 0
+    s_cbranch_scc1 L_nowalls
+    s_add_u32 {st(2)}, {s('M2')}, 1
+    s_lshl_b64 {sp('wallM')}, 1, {st(2)}
+    s_sub_u32 {s('wallM')}, {s('wallM')}, 1
+    s_lshl_b64 {sp('planeM')}, 1, {s('M2')}
+    L_nowalls:
+    s_mov_b32 {s('sideM')}, 0x40000000
+    s_mov_b32 {s('sideM',1)}, 0
+    """)
+E(f"""
 v_lshlrev_b32 {v('zaddr')}, 2, {LANE}
 v_mov_b32 {v('uns0')}, 0
 v_mov_b32 {v('uns1')}, 0
@@ -315,7 +335,6 @@ if ZB:
     v_lshlrev_b32 v14, 3, {LANE}
     ds_read_b64 v[16:17], v14 offset:{LDS_GB}
     s_waitcnt lgkmcnt(0)
-    s_mov_b32 {s('M2')}, {st(0)}                // M2 has done its work (the lane masks): the register holds RZ from here on
     v_subrev_u32 {v('gloR')}, {st(0)}, v16
     v_add_u32 {v('ghiR')}, {st(0)}, v17
     v_cmp_gt_i32 vcc, v16, v17
@@ -490,27 +509,19 @@ if not ZB:
 else:
     E(f"""
     L_sweep:
-    s_load_dwordx2 {stp(2)}, {KARG}, {K_OFFS}
-    s_add_u32 {st(0)}, {s('cbase')}, {s('sw')}
-    s_lshl_b32 {st(1)}, {st(0)}, 2
-    s_waitcnt lgkmcnt(0)
-    s_load_dword {s('n0')}, {stp(2)}, {st(1)}
     s_mov_b32 {s('jacc')}, 0
     s_mov_b32 {s('run')}, 0
-    s_waitcnt lgkmcnt(0)
     """)
-E(f"""
-L_run:
-s_sub_u32 {st(0)}, {s('N')}, {s('n0')}
-s_cmp_eq_u32 {s('run')}, 0
-s_cselect_b32 {s('first')}, {s('n0')}, 0
-s_cselect_b32 {s('len')}, {st(0)}, {s('n0')}
-s_cselect_b32 {s('vbase')}, 0, {st(0)}
-s_cmp_eq_u32 {s('len')}, 0
-s_cbranch_scc1 L_run_next
-""")
 if not ZB:
     E(f"""
+    L_run:
+    s_sub_u32 {st(0)}, {s('N')}, {s('n0')}
+    s_cmp_eq_u32 {s('run')}, 0
+    s_cselect_b32 {s('first')}, {s('n0')}, 0
+    s_cselect_b32 {s('len')}, {st(0)}, {s('n0')}
+    s_cselect_b32 {s('vbase')}, 0, {st(0)}
+    s_cmp_eq_u32 {s('len')}, 0
+    s_cbranch_scc1 L_run_next
     L_rot_to:
     s_lshr_b32 {st(7)}, {s('first')}, 6
     s_cmp_eq_u32 {s('rot')}, {st(7)}
@@ -531,21 +542,33 @@ if not ZB:
     s_addc_u32 {s('uK',1)}, {s('uni',1)}, 0
     """)
 else:
-    E(f"s_lshr_b32 {s('rot')}, {s('first')}, 6")
-    fill_p0("r1")
+    # a run starts: st(0) = cbase + sw, n0 = offs[cbase + sw], first / len of this run, then
+    # dK = displ + ((cbase + sw) * N + first) * 24 ; uK = uni + ((cbase + sw) * N + vbase) * 8 ; then the row
+    E("L_run:")
+    cbase_to(st(0))
     E(f"""
-    s_and_b32 {s('tl')}, {s('first')}, 63
-    s_sub_u32 {s('tl')}, {s('tl')}, 1
-    // dK = displ + ((cbase + sw) * N + first) * 24 ; uK = uni + ((cbase + sw) * N + vbase) * 8
+    s_load_dwordx2 {stp(2)}, {KARG}, {K_OFFS}
     s_load_dwordx4 {st4(4)}, {KARG}, {K_DISPL}
-    s_add_u32 {st(0)}, {s('cbase')}, {s('sw')}
+    s_add_u32 {st(0)}, {st(0)}, {s('sw')}
+    s_lshl_b32 {st(1)}, {st(0)}, 2
+    s_waitcnt lgkmcnt(0)
+    s_load_dword {st(1)}, {stp(2)}, {st(1)}
+    s_waitcnt lgkmcnt(0)
+    // st(1) = n0 ; st(2) = N - n0
+    s_sub_u32 {st(2)}, {s('N')}, {st(1)}
+    s_cmp_eq_u32 {s('run')}, 0
+    s_cselect_b32 {s('first')}, {st(1)}, 0
+    s_cselect_b32 {s('len')}, {st(2)}, {st(1)}
+    s_cselect_b32 {st(1)}, 0, {st(2)}
+    s_cmp_eq_u32 {s('len')}, 0
+    s_cbranch_scc1 L_run_next
+    // st(1) = vbase
     s_mul_i32 {st(2)}, {s('N')}, 8
     s_mul_hi_u32 {st(3)}, {st(2)}, {st(0)}
     s_mul_i32 {st(2)}, {st(2)}, {st(0)}
-    s_waitcnt lgkmcnt(0)
     s_add_u32 {s('uK')}, {st(6)}, {st(2)}
     s_addc_u32 {s('uK',1)}, {st(7)}, {st(3)}
-    s_lshl_b32 {st(1)}, {s('vbase')}, 3
+    s_lshl_b32 {st(1)}, {st(1)}, 3
     s_add_u32 {s('uK')}, {s('uK')}, {st(1)}
     s_addc_u32 {s('uK',1)}, {s('uK',1)}, 0
     s_mul_i32 {st(6)}, {s('N')}, 24
@@ -556,6 +579,12 @@ else:
     s_mul_i32 {st(1)}, {s('first')}, 24
     s_add_u32 {s('dK')}, {s('dK')}, {st(1)}
     s_addc_u32 {s('dK',1)}, {s('dK',1)}, 0
+    s_lshr_b32 {s('rot')}, {s('first')}, 6
+    """)
+    fill_p0("r1")
+    E(f"""
+    s_and_b32 {s('tl')}, {s('first')}, 63
+    s_sub_u32 {s('tl')}, {s('tl')}, 1
     """)
 E(f"""
 s_mov_b32 {s('i')}, -1
@@ -853,9 +882,11 @@ def wall_dz(tag, pz_is_sgpr, pz):
     """)
 
 
-def body(tag, P, X, C, items, round0):
+def body(tag, P, X, C, items, round0, wl=None, pl=None):
     """the fp64 body for the lanes in `items` (s pair): d = probe - X, the walls' dz, signed minimum image,
     the plane's rules, cutoff test, lj_acc's sequence (SMC.c:567-578, 601-614, 740-761, 787-809)"""
+    wl = wl or sp('wallM')
+    pl = pl or sp('planeM')
     E(f"""
     s_mov_b64 exec, {items}
     v_add_f64 {vp('D',0)}, {P[0]}, -v[{X}:{X+1}]
@@ -864,7 +895,7 @@ def body(tag, P, X, C, items, round0):
     """)
     if round0:
         E(f"""
-        s_and_b64 exec, {items}, {sp('wallM')}
+        s_and_b64 exec, {items}, {wl}
         v_mov_b32 {v('D',4)}, {v('wdz')}
         v_mov_b32 {v('D',5)}, {v('wdz',1)}
         s_mov_b64 exec, {items}
@@ -879,7 +910,7 @@ def body(tag, P, X, C, items, round0):
     """)
     if round0:
         E(f"""
-        s_and_b64 exec, {items}, {sp('planeM')}
+        s_and_b64 exec, {items}, {pl}
         v_mov_b32 {v('M',0)}, 0
         v_mov_b32 {v('M',1)}, 0
         v_mov_b32 {v('M',2)}, 0
@@ -893,7 +924,7 @@ def body(tag, P, X, C, items, round0):
     v_cmp_gt_f64 vcc, {sp('cut2')}, {vp('dr2')}
     """)
     if round0:
-        E(f"s_or_b64 vcc, vcc, {sp('planeM')}")
+        E(f"s_or_b64 vcc, vcc, {pl}")
     E(f"""
     s_and_b64 exec, exec, vcc
     s_cbranch_execz L_nolj_{tag}
@@ -949,23 +980,29 @@ def reduce4(dst):
         """)
 
 
-def probe(tag, P, pz_sgpr, pz, w0, w1, X, C, have, side, wait):
+def probe(tag, P, pz_sgpr, pz, w0, w1, X, C, have, side, wait, wl=None, pl=None):
     """a whole probe: round 0 (specials + the first candidates, already requested into X / `have`), then
     further rounds while any lane still has a candidate.  `wait`: the s_waitcnt that covers round 0's loads"""
+    wl = wl or sp('wallM')
+    pl = pl or sp('planeM')
     for j in range(4):
         E(f"v_mov_b64 {vp('acc', j)}, 0")
-    E(f"s_cmp_lg_u64 {sp('wallM')}, 0")
+    E(f"s_cmp_lg_u64 {wl}, 0")
     E(f"s_cbranch_scc0 L_nw_{tag}")
     wall_dz(tag, pz_sgpr, pz)
     E(f"L_nw_{tag}:")
-    E(f"s_or_b64 {stp(6)}, {have}, {sp('wallM')}")
+    E(f"s_or_b64 {stp(6)}, {have}, {wl}")
     if side:
         E(f"s_cmp_eq_u32 {s('hasA')}, 0")
         E(f"s_cbranch_scc1 L_noside_{tag}")
-        E(f"s_or_b64 {stp(6)}, {stp(6)}, {sp('sideM')}")
+        if ZB:
+            E(f"s_lshl_b64 {stp(0)}, 1, {s('sideL')}")
+            E(f"s_or_b64 {stp(6)}, {stp(6)}, {stp(0)}")
+        else:
+            E(f"s_or_b64 {stp(6)}, {stp(6)}, {sp('sideM')}")
         E(f"L_noside_{tag}:")
     E(wait)
-    body(tag + "r0", P, X, C, stp(6), True)
+    body(tag + "r0", P, X, C, stp(6), True, wl, pl)
     E(f"""
     L_more_{tag}:
     v_cmp_ne_u64 vcc, 0, v[{w0}:{w1}]
@@ -978,6 +1015,76 @@ def probe(tag, P, pz_sgpr, pz, w0, w1, X, C, have, side, wait):
     body(tag + "rm", P, X, C, stp(6), False)
     E(f"s_branch L_more_{tag}")
     E(f"L_done_{tag}:")
+
+
+def assign_specials(tag, w0, w1, X, C, wl, pl, with_side, have):
+    """zb, round 0 of a probe: every lane with a candidate takes its lowest one (load of its fp64 position asked
+    for; `have` <- those lanes); the wall sites, the plane and -- for probe B after a move -- the side pair go to
+    the first lanes WITHOUT a candidate (rank among them = row of the wall table), so no candidate waits for a
+    second round behind them.  With too few free lanes: the fixed lanes 0..M2 (and 30), as in sweep_kernel_ma."""
+    wlo, whi = (int(x) for x in wl[2:-1].split(":"))
+    E(f"""
+    v_cmp_ne_u64 vcc, 0, v[{w0}:{w1}]
+    s_add_u32 {st(3)}, {s('M2')}, 1
+    s_not_b64 {stp(0)}, vcc
+    s_bcnt1_i32_b64 {st(2)}, {stp(0)}
+    {f"s_add_u32 {st(6)}, {st(3)}, {s('hasA')}" if with_side else f"s_mov_b32 {st(6)}, {st(3)}"}
+    s_cmp_lt_u32 {st(2)}, {st(6)}
+    s_cbranch_scc1 L_sps_{tag}
+    v_mbcnt_lo_u32_b32 v48, {st(0)}, 0
+    v_mbcnt_hi_u32_b32 v48, {st(1)}, v48
+    s_mov_b64 {have}, vcc
+    v_cmp_gt_u32 {wl}, {st(3)}, v48
+    v_cmp_eq_u32 {pl}, {s('M2')}, v48
+    """)
+    if with_side:
+        E(f"""
+        v_cmp_eq_u32 {stp(4)}, {st(3)}, v48
+        s_and_b64 {stp(4)}, {stp(4)}, {stp(0)}
+        s_ff1_i32_b64 {s('sideL')}, {stp(4)}
+        """)
+    E(f"""
+    s_and_b64 {wl}, {wl}, {stp(0)}
+    s_and_b64 {pl}, {pl}, {stp(0)}
+    s_branch L_spj_{tag}
+    L_sps_{tag}:
+    s_lshl_b64 {wl}, 1, {st(3)}
+    s_sub_u32 s{wlo}, s{wlo}, 1
+    s_subb_u32 s{whi}, s{whi}, 0
+    s_lshl_b64 {pl}, 1, {s('M2')}
+    s_cmp_lt_i32 {s('M2')}, 0
+    s_cselect_b64 {pl}, 0, {pl}
+    s_mov_b64 {stp(4)}, {wl}
+    {f"s_mov_b32 {s('sideL')}, 30" if with_side else ""}
+    {f"s_or_b32 {st(4)}, {st(4)}, 0x40000000" if with_side else ""}
+    s_andn2_b64 {have}, vcc, {stp(4)}
+    v_mov_b32 v48, {LANE}
+    L_spj_{tag}:
+    s_mov_b64 exec, {have}
+    v_ffbl_b32 v44, v{w0}
+    v_ffbl_b32 v45, v{w1}
+    v_lshl_add_u64 v[46:47], v[{w0}:{w1}], 0, -1
+    v_or_b32 v45, 32, v45
+    v_min_u32 v44, v44, v45
+    v_and_b32 v{w0}, v{w0}, v46
+    v_and_b32 v{w1}, v{w1}, v47
+    v_lshl_or_b32 v44, v44, 6, {LANE}
+    v_cmp_gt_u32 vcc, {s('N')}, v44
+    v_mul_u32_u24 v45, 24, v44
+    s_and_b64 exec, exec, vcc
+    global_load_dwordx4 v[{X}:{X+3}], v45, {SRC}
+    global_load_dwordx2 v[{X+4}:{X+5}], v45, {SRC} offset:16
+    s_mov_b64 {have}, exec
+    s_mov_b64 exec, -1
+    """)
+    coeff_one(C)
+    E(f"""
+    s_mov_b64 exec, {wl}
+    v_lshlrev_b32 v49, 5, v48
+    global_load_dwordx4 v[{X}:{X+3}], v49, {sp('wtab')}
+    global_load_dwordx4 v[{C}:{C+3}], v49, {sp('wtab')} offset:16
+    s_mov_b64 exec, -1
+    """)
 
 
 XA_, CA_, XB_, CB_ = 30, 26, 20, 10   # round-0 data: A in the D registers (d = p - X in place), B in v20..25; coefficients
@@ -1011,8 +1118,11 @@ else:
     v_and_b32 {v('wa0')}, -2, {v('wa0')}
     s_mov_b64 exec, -1
     """)
-pick_fetch(V['wa0'], V['wa1'], XA_, sp('wallM'), sp('haveA'))
-wall_fetch(XA_, CA_)
+if ZB:
+    assign_specials("A", V['wa0'], V['wa1'], XA_, CA_, sp('wallM'), sp('planeM'), False, sp('haveA'))
+else:
+    pick_fetch(V['wa0'], V['wa1'], XA_, sp('wallM'), sp('haveA'))
+    wall_fetch(XA_, CA_)
 E("L_nofa:")
 if ZB:
     screen_ranged("B", s('bxys'), s('bzz'), v('wb0'), v('wb1'))
@@ -1040,15 +1150,12 @@ if ZB:
     # not neighbours of B: the particle it stands for, and the moving particle n, which reaches B through the side pair
     excl(v('wb0'), v('wb1'), s('locB'))
     E(f"""
-    s_mov_b64 {stp(6)}, {sp('wallM')}
     s_cmp_eq_u32 {s('hasA')}, 0
     s_cbranch_scc1 L_fb1
     """)
     excl(v('wb0'), v('wb1'), s('locA'))
     E(f"""
-    s_or_b64 {stp(6)}, {sp('wallM')}, {sp('sideM')}
     L_fb1:
-    s_mov_b64 {stp(0)}, {stp(6)}
     // probe A's data has had the whole second pass to arrive; B's travels while probe A is evaluated
     s_waitcnt vmcnt(0)
     """)
@@ -1077,8 +1184,11 @@ else:
     // probe A's data has had the whole second pass to arrive; B's travels while probe A is evaluated
     s_waitcnt vmcnt(0)
     """)
-pick_fetch(V['wb0'], V['wb1'], XB_, stp(0), sp('haveB'))
-wall_fetch(XB_, CB_)
+if ZB:
+    assign_specials("B", V['wb0'], V['wb1'], XB_, CB_, sp('wallB'), sp('planeB'), True, sp('haveB'))
+else:
+    pick_fetch(V['wb0'], V['wb1'], XB_, stp(0), sp('haveB'))
+    wall_fetch(XB_, CB_)
 E(f"""
 // probe B's fp64 position from the LDS cache: row = cross ? 64 : tl + 1
 s_cmp_eq_u32 {s('cross')}, 1
@@ -1220,9 +1330,11 @@ else:
     ds_write_b16 {v('S6')}, {v('T',1)}
     s_lshr_b32 {st(1)}, {st(1)}, 2
     s_lshl_b64 {stp(2)}, 1, {st(1)}
+    s_load_dword {st(6)}, {KARG}, {K_RZ}
     s_sext_i32_i16 {st(0)}, {s('az16')}
-    s_sub_i32 {st(4)}, {st(0)}, {s('M2')}
-    s_add_i32 {st(5)}, {st(0)}, {s('M2')}
+    s_waitcnt lgkmcnt(0)
+    s_sub_i32 {st(4)}, {st(0)}, {st(6)}
+    s_add_i32 {st(5)}, {st(0)}, {st(6)}
     s_mov_b64 exec, {stp(2)}
     v_min_i32 {v('gloR')}, {st(4)}, {v('gloR')}
     v_max_i32 {v('ghiR')}, {st(5)}, {v('ghiR')}
@@ -1251,7 +1363,8 @@ s_cmp_eq_u32 {s('hasA')}, 0
 s_cbranch_scc1 L_nosrc
 s_mul_i32 {st(0)}, {s('tl')}, 24
 v_mov_b32 {v('T')}, {st(0)}
-s_mov_b64 exec, {sp('sideM')}
+{f"s_lshl_b64 {stp(2)}, 1, {s('sideL')}" if ZB else ""}
+s_mov_b64 exec, {stp(2) if ZB else sp('sideM')}
 ds_read_b64 v[{XB_}:{XB_+1}], {v('T')} offset:{LDS_P0}
 ds_read_b64 v[{XB_+2}:{XB_+3}], {v('T')} offset:{LDS_P0 + 8}
 ds_read_b64 v[{XB_+4}:{XB_+5}], {v('T')} offset:{LDS_P0 + 16}
@@ -1262,7 +1375,8 @@ global_load_dwordx2 {vp('DdV')}, {v('S6')}, {sp('dK')}
 s_waitcnt lgkmcnt(0)
 """)
 BP = ["v[14:15]", "v[16:17]", "v[18:19]"]
-probe("B", BP, False, "v[18:19]", V['wb0'], V['wb1'], XB_, CB_, sp('haveB'), True, "s_waitcnt vmcnt(1)")
+probe("B", BP, False, "v[18:19]", V['wb0'], V['wb1'], XB_, CB_, sp('haveB'), True, "s_waitcnt vmcnt(1)",
+      sp('wallB') if ZB else None, sp('planeB') if ZB else None)
 reduce4(vp('FmV'))
 E(f"""
 // ---- proposal of particle n+1 in row layout (SMC.c:307-316): q = p + (Fm A/T + displ)
@@ -1356,11 +1470,14 @@ if not ZB:
 else:
     E(f"""
     s_load_dwordx2 {stp(2)}, {KARG}, {K_REC}
-    s_add_u32 {st(0)}, {s('cbase')}, {s('sw')}
+    s_load_dword {st(0)}, {KARG}, {K_INTS + 4}
+    s_waitcnt lgkmcnt(0)
+    s_mul_i32 {st(0)}, {st(0)}, {REP}
+    s_add_u32 {st(0)}, {st(0)}, {s('sw')}
     s_lshl_b32 {st(0)}, {st(0)}, 4
     v_mov_b32 v18, {st(0)}
     s_mov_b64 exec, 1
-    s_waitcnt lgkmcnt(0)
+    s_nop 0
     global_store_dwordx4 v18, v[14:17], {stp(2)}
     s_mov_b64 exec, -1
     """)
