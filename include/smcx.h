@@ -209,6 +209,12 @@ int smcx_screen_bound(const smcx_params *p, int lds_z, double *thr, double *u2, 
  * -(T << 2 zshift) of the x,y dot product; SMCX_ERR_UNSUPPORTED when no built z unit covers the box */
 int smcx_screen_bound_int(const smcx_params *p, double *thr, double *u2, double *to_fixed, double *zsafe,
                           double *uz, int32_t *neg_c, int32_t *zshift);
+/* the same for the byte screen of sweep_kernel_mc64 (one 32-bit word per particle: z as int16, x and y as
+ * int8, all in units of L/256; v_sub_u32 + v_dot4_i32_i8): to_fixed = 256/L, zsafe = |z| the int16 holds,
+ * neg_t = the accumulator start -T of the four squared bytes, reach_z = |dz| in units a pair inside the
+ * cutoff can have (what a group's z range is widened by); SMCX_ERR_UNSUPPORTED when the unit does not
+ * resolve the cutoff (fewer than 16 units) or the box is taller than the int16 */
+int smcx_screen_bound_byte(const smcx_params *p, double *to_fixed, double *zsafe, int32_t *neg_t, int32_t *reach_z);
 
 /* Teacher-forced evaluator (stateless; tests and debugging): for each of nrep
  * replicas evaluates what SMC.c:300-304 and 319-321 evaluate for particle

@@ -58,7 +58,7 @@ EXPORTS = [
     "smcx_export_observables_device", "smcx_last_kernel_ms", "smcx_last_run_ms", "smcx_geometry", "smcx_eval_moves",
     "smcx_rng_seed", "smcx_one_particle_moves",
     "smcx_cluster_counts", "smcx_cluster_update", "smcx_cluster_analysis", "smcx_kernel_form", "smcx_screen_bound",
-    "smcx_screen_bound_int", "smcx_last_clock",
+    "smcx_screen_bound_int", "smcx_screen_bound_byte", "smcx_last_clock",
 ]
 
 
@@ -156,6 +156,16 @@ def screen_bound_int(p):
     if rc != OK:
         raise SmcxError(rc, "smcx_screen_bound_int")
     return tuple(x.value for x in v) + (nc.value, zs.value)
+
+
+def screen_bound_byte(p):
+    """(to_fixed, zsafe, neg_t, reach_z) of the byte screen (sweep_kernel_mc64) for the box of p"""
+    tf, zs = C.c_double(), C.c_double()
+    nt, rz = C.c_int32(), C.c_int32()
+    rc = _lib().smcx_screen_bound_byte(C.byref(p), C.byref(tf), C.byref(zs), C.byref(nt), C.byref(rz))
+    if rc != OK:
+        raise SmcxError(rc, "smcx_screen_bound_byte")
+    return tf.value, zs.value, nt.value, rz.value
 
 
 def rng_seed(seed):

@@ -49,10 +49,19 @@ assert NS in (16, 32, 64)
 # "zb": z-binned storage.  The register/LDS cells hold the particles in the order of a z sort done before the
 # launch (Rs = positions in cell order, loc = cell of each particle); a probe screens only the 4-slot groups
 # whose z range (kept per group, widened by accepted moves) can reach it.
-ZBC = len(sys.argv) > 3 and sys.argv[3] == "zbc"        # diagnostic: every pass also runs the full screen and counts
-ZB = ZBC or (len(sys.argv) > 3 and sys.argv[3] == "zb")   # the bits the ranged pass lacks (must be none)
+MODE = sys.argv[3] if len(sys.argv) > 3 else ""
+ZBC = MODE == "zbc"                                       # diagnostic: every pass also runs the full screen and counts
+                                                          # the bits the ranged pass lacks (must be none)
+# "z8": zb with ONE 32-bit word per cell -- z as int16 in bits 0..15, x and y as int8 in bits 16..23 / 24..31, all
+# in units of L/256 -- screened by v_sub_u32 + v_dot4_i32_i8 + v_alignbit_b32 (3 instructions per slot and
+# probe, no z words in LDS).  The byte-wise squares alias |dz| >= 128 units; such cells are far outside the
+# cutoff, cost at most a wasted evaluation, and the group ranges keep them out of the passes anyway.
+# "z8c": its diagnostic build: the fp64 cutoff test of every cell beside every pass, counting unflagged pairs.
+Z8C = MODE == "z8c"
+Z8 = Z8C or MODE == "z8"
+ZB = ZBC or Z8 or MODE == "zb"
 NG = NS // 4                                              # 4-slot groups
-LDS_P0 = (NS // 2) * 256                                  # after the int16 z words
+LDS_P0 = 0 if Z8 else (NS // 2) * 256                     # after the int16 z words
 LDS_GB = LDS_P0                                           # zb: (min, max) z of each group while the copies are built (p0 is filled afterwards)
 LDS_CNT = LDS_P0 + 65 * 24 + 8                            # zbc: per lane (candidates, bits missing from the ranged pass)
 LANE, KARG, REP = "%0", "%1", "%2"
@@ -253,9 +262,9 @@ if ZB:
     v_mov_b32 v16, 0x7fffffff
     v_mov_b32 v17, 0x80000000
     ds_write_b64 v14, v[16:17] offset:{LDS_GB}
-    {f"v_mov_b32 v16, 0" if ZBC else ""}
-    {f"v_mov_b32 v17, 0" if ZBC else ""}
-    {f"ds_write_b64 v14, v[16:17] offset:{LDS_CNT}" if ZBC else ""}
+    {f"v_mov_b32 v16, 0" if ZBC or Z8C else ""}
+    {f"v_mov_b32 v17, 0" if ZBC or Z8C else ""}
+    {f"ds_write_b64 v14, v[16:17] offset:{LDS_CNT}" if ZBC or Z8C else ""}
     s_waitcnt lgkmcnt(0)
     """)
 
@@ -294,8 +303,9 @@ v_rndne_f64 v[22:23], v[22:23]
 v_rndne_f64 v[24:25], v[24:25]
 v_cvt_i32_f64 v22, v[22:23]
 v_cvt_i32_f64 v24, v[24:25]
-v_and_b32 v22, 0xffff, v22
-v_lshl_or_b32 v22, v24, 16, v22
+{"v_and_b32 v22, 0xff, v22" if Z8 else "v_and_b32 v22, 0xffff, v22"}
+{"v_and_b32 v24, 0xff, v24" if Z8 else ""}
+{"v_lshl_or_b32 v22, v24, 8, v22" if Z8 else "v_lshl_or_b32 v22, v24, 16, v22"}
 // z -> int16 in units uz, clamped to +-32767; padding slots hold 0x7fff ; unsafe = real && !(|z| < zsafe)
 v_mul_f64 v[24:25], v[20:21], {sp('zFix')}
 v_rndne_f64 v[24:25], v[24:25]
@@ -307,13 +317,24 @@ v_cmp_nlt_f64 {stp(4)}, |v[20:21]|, {sp('zsafe')}
 s_and_b64 {stp(4)}, {stp(4)}, vcc
 v_cndmask_b32 v22, 0, v22, vcc
 v_cndmask_b32 v24, v25, v24, vcc
-s_lshr_b32 {st(6)}, {st(0)}, 1
-s_lshl_b32 {st(6)}, {st(6)}, 8
-s_and_b32 {st(7)}, {st(0)}, 1
-s_lshl_b32 {st(7)}, {st(7)}, 1
-s_add_u32 {st(6)}, {st(6)}, {st(7)}
-v_add_u32 v26, {st(6)}, {v('zaddr')}
-ds_write_b16 v26, v24
+""")
+if Z8:
+    # word = z16 | x8 << 16 | y8 << 24
+    E(f"""
+    v_and_b32 v26, 0xffff, v24
+    v_lshl_or_b32 v22, v22, 16, v26
+    """)
+else:
+    E(f"""
+    s_lshr_b32 {st(6)}, {st(0)}, 1
+    s_lshl_b32 {st(6)}, {st(6)}, 8
+    s_and_b32 {st(7)}, {st(0)}, 1
+    s_lshl_b32 {st(7)}, {st(7)}, 1
+    s_add_u32 {st(6)}, {st(6)}, {st(7)}
+    v_add_u32 v26, {st(6)}, {v('zaddr')}
+    ds_write_b16 v26, v24
+    """)
+E(f"""
 {zb_range_update}
 v_lshrrev_b64 v[{V['uns0']}:{V['uns1']}], 1, v[{V['uns0']}:{V['uns1']}]
 v_cndmask_b32 v27, 0, 1, {stp(4)}
@@ -357,8 +378,9 @@ def compact_row(xyd, zld, locv):
     v_rndne_f64 v[28:29], v[28:29]
     v_cvt_i32_f64 v26, v[26:27]
     v_cvt_i32_f64 v28, v[28:29]
-    v_and_b32 v26, 0xffff, v26
-    v_lshl_or_b32 {xyd}, v28, 16, v26
+    {"v_and_b32 v26, 0xff, v26" if Z8 else "v_and_b32 v26, 0xffff, v26"}
+    {"v_and_b32 v28, 0xff, v28" if Z8 else ""}
+    {f"v_lshl_or_b32 {xyd}, v28, 8, v26" if Z8 else f"v_lshl_or_b32 {xyd}, v28, 16, v26"}
     v_mul_f64 v[28:29], v[20:21], {sp('zFix')}
     v_rndne_f64 v[28:29], v[28:29]
     v_cvt_i32_f64 v28, v[28:29]
@@ -368,6 +390,7 @@ def compact_row(xyd, zld, locv):
     v_and_b32 v28, 0xffff, v28
     v_cmp_nlt_f64 vcc, |v[20:21]|, {sp('zsafe')}
     v_cndmask_b32 v29, 0, 1, vcc
+    {f"v_lshl_or_b32 {xyd}, {xyd}, 16, v28" if Z8 else ""}
     v_lshl_or_b32 v28, v29, 16, v28
     v_lshl_or_b32 {zld}, {locv}, 17, v28
     """)
@@ -660,8 +683,8 @@ else:
   L_bjoin:
   s_bfe_u32 {s('ub')}, {st(1)}, 0x10010
   s_lshr_b32 {s('locB')}, {st(1)}, 17
-  s_and_b32 {st(1)}, {st(1)}, 0xffff
-  s_mul_i32 {s('bzz')}, {st(1)}, 0x10001
+  {"" if Z8 else f"s_and_b32 {st(1)}, {st(1)}, 0xffff"}
+  {"" if Z8 else f"s_mul_i32 {s('bzz')}, {st(1)}, 0x10001"}
   L_nob1:
   """)
 
@@ -792,12 +815,155 @@ def zbc_check(pzz, w0, w1):
     """)
 
 
+def screen_group8(k0, p, w):
+    """z8: one probe against slots k0..k0+3: 12 instructions (the dot4 results are read four instructions later)"""
+    a = ["v%d" % (V['t'] + j) for j in range(4)]
+    X = [xy(k0 + 3), xy(k0 + 2), xy(k0 + 1), xy(k0)]
+    for j in range(4):
+        E(f"v_sub_u32 {a[j]}, {p}, {X[j]}")
+    for j in range(4):
+        E(f"v_dot4_i32_i8 {a[j]}, {a[j]}, {a[j]}, {s('negC')}")
+    for j in range(4):
+        E(f"v_alignbit_b32 {w}, {w}, {a[j]}, 31")
+
+
+def screen_ranged8(tag, pws, w0, w1):
+    """z8: as screen_ranged, without z words to fetch: the computed jump lands on the highest group in reach"""
+    w = lambda g: w1 if 4 * g >= 32 else w0
+    E(f"""
+    v_mov_b32 {w0}, 0
+    v_mov_b32 {w1}, 0
+    s_sext_i32_i16 {st(0)}, {pws}
+    v_mov_b32 {v('pxy')}, {pws}
+    v_cmp_ge_i32 vcc, {st(0)}, {v('gloR')}
+    v_cmp_le_i32 {stp(2)}, {st(0)}, {v('ghiR')}
+    s_and_b32 {st(1)}, vcc_lo, {st(2)}
+    s_cmp_eq_u32 {st(1)}, 0
+    s_cbranch_scc1 L_sdone_{tag}
+    s_ff1_i32_b32 {st(4)}, {st(1)}
+    s_flbit_i32_b32 {st(5)}, {st(1)}
+    s_getpc_b64 {stp(2)}
+    L_spc_{tag}:
+    s_mul_i32 {st(5)}, {st(5)}, L_sg{NG-2}_{tag}-L_sg{NG-1}_{tag}
+    s_add_u32 {st(5)}, {st(5)}, L_sg{NG-1}_{tag}-L_spc_{tag}-{32 - NG}*(L_sg{NG-2}_{tag}-L_sg{NG-1}_{tag})
+    s_add_u32 {st(2)}, {st(2)}, {st(5)}
+    s_addc_u32 {st(3)}, {st(3)}, 0
+    s_setpc_b64 {stp(2)}
+    """)
+    # blocks in descending group order; flbit = 31 - highest group, so block g sits (flbit - (32 - NG)) blocks in
+    for g in range(NG - 1, -1, -1):
+        E(f"L_sg{g}_{tag}:")
+        screen_group8(4 * g, v('pxy'), w(g))
+        if g > 0:
+            E(f"s_cmp_eq_u32 {st(4)}, {g}")
+            E(f"s_cbranch_scc1 L_sfin_{tag}")
+    E(f"""
+    L_sfin_{tag}:
+    s_lshl_b32 {st(0)}, {st(4)}, 2
+    v_lshlrev_b32 {w0}, {st(0)}, {w0}
+    """)
+    if NS == 64:
+        E(f"""
+        s_sub_u32 {st(1)}, {st(4)}, 8
+        s_max_i32 {st(1)}, {st(1)}, 0
+        s_lshl_b32 {st(1)}, {st(1)}, 2
+        v_lshlrev_b32 {w1}, {st(1)}, {w1}
+        """)
+    E(f"L_sdone_{tag}:")
+
+
+def z8c_check(tag, P_sgpr, w0, w1, locs, guard):
+    """diagnostic (z8c): the fp64 cutoff test (minimum image in x, y; SMC.c:567-578) of the probe against EVERY cell,
+    from the positions in memory.  Counts, in LDS words of lane 0: pairs inside the cutoff, candidate bits, and
+    pairs inside the cutoff whose bit is not set (the cells in `locs` are excluded by construction).
+    Runs after the exclusions and before the first candidates are taken out of w."""
+    E(f"""
+    s_cmp_eq_u32 {guard}, 0
+    s_cbranch_scc1 L_ck_end_{tag}
+    """)
+    if P_sgpr:
+        for j in range(6):
+            E(f"v_mov_b32 v{20 + j}, {s('Q', j)}")
+    else:
+        E(f"""
+        s_cmp_eq_u32 {s('cross')}, 1
+        s_cselect_b32 {st(0)}, 64, {s('lb')}
+        s_mul_i32 {st(0)}, {st(0)}, 24
+        v_mov_b32 v36, {st(0)}
+        ds_read_b64 v[20:21], v36 offset:{LDS_P0}
+        ds_read_b64 v[22:23], v36 offset:{LDS_P0 + 8}
+        ds_read_b64 v[24:25], v36 offset:{LDS_P0 + 16}
+        s_waitcnt lgkmcnt(0)
+        """)
+    E(f"""
+    v_bcnt_u32_b32 v46, {w0}, 0
+    v_bcnt_u32_b32 v46, {w1}, v46
+    v_mov_b32 v47, 0
+    s_mov_b32 {st(7)}, 0
+    L_ck_{tag}:
+    v_lshl_or_b32 v36, {st(7)}, 6, {LANE}
+    v_cmp_gt_u32 vcc, {s('N')}, v36
+    v_mul_u32_u24 v37, 24, v36
+    s_mov_b64 {stp(0)}, vcc
+    s_mov_b64 exec, vcc
+    global_load_dwordx4 v[14:17], v37, {sp('Rs')}
+    global_load_dwordx2 v[18:19], v37, {sp('Rs')} offset:16
+    s_waitcnt vmcnt(0)
+    s_mov_b64 exec, -1
+    v_add_f64 v[38:39], v[20:21], -v[14:15]
+    v_add_f64 v[40:41], v[22:23], -v[16:17]
+    v_add_f64 v[42:43], v[24:25], -v[18:19]
+    v_mul_f64 v[14:15], v[38:39], {sp('invL')}
+    v_mul_f64 v[16:17], v[40:41], {sp('invL')}
+    v_rndne_f64 v[14:15], v[14:15]
+    v_rndne_f64 v[16:17], v[16:17]
+    v_fma_f64 v[38:39], -v[14:15], {sp('L')}, v[38:39]
+    v_fma_f64 v[40:41], -v[16:17], {sp('L')}, v[40:41]
+    v_mul_f64 v[14:15], v[38:39], v[38:39]
+    v_fma_f64 v[14:15], v[40:41], v[40:41], v[14:15]
+    v_fma_f64 v[14:15], v[42:43], v[42:43], v[14:15]
+    v_cmp_gt_f64 {stp(2)}, {sp('cut2')}, v[14:15]
+    s_and_b64 {stp(2)}, {stp(2)}, {stp(0)}
+    """)
+    for loc in locs:      # (register, guard) pairs: the cell is not a neighbour when guard != 0
+        E(f"""
+        v_cmp_ne_u32 {stp(4)}, {loc[0]}, v36
+        s_cmp_eq_u32 {loc[1]}, 0
+        s_cselect_b64 {stp(4)}, -1, {stp(4)}
+        s_and_b64 {stp(2)}, {stp(2)}, {stp(4)}
+        """)
+    E(f"""
+    v_lshrrev_b64 v[44:45], {st(7)}, v[{w0[1:]}:{w1[1:]}]
+    v_and_b32 v44, 1, v44
+    v_cmp_eq_u32 {stp(4)}, 1, v44
+    s_andn2_b64 {stp(4)}, {stp(2)}, {stp(4)}
+    s_bcnt1_i32_b64 {st(0)}, {stp(2)}
+    s_bcnt1_i32_b64 {st(1)}, {stp(4)}
+    s_lshl_b32 {st(1)}, {st(1)}, 16
+    s_add_u32 {st(0)}, {st(0)}, {st(1)}
+    v_add_u32 v47, {st(0)}, v47
+    s_add_u32 {st(7)}, {st(7)}, 1
+    s_cmp_lt_u32 {st(7)}, {NS}
+    s_cbranch_scc1 L_ck_{tag}
+    // lane 0: inside += v47 & 0xffff ; missed += v47 >> 16 ; every lane: candidate bits
+    v_and_b32 v44, 0xffff, v47
+    v_lshrrev_b32 v45, 16, v47
+    v_mov_b32 v36, 0
+    ds_add_u32 v36, v46 offset:{LDS_CNT + 4}
+    s_mov_b64 exec, 1
+    ds_add_u32 v36, v44 offset:{LDS_CNT}
+    ds_add_u32 v36, v45 offset:{LDS_CNT + 8}
+    s_mov_b64 exec, -1
+    s_waitcnt lgkmcnt(0)
+    L_ck_end_{tag}:
+    """)
+
+
 def excl(w0, w1, loc):
     """zb: the particle in cell `loc` (s: slot << 6 | lane) is not a candidate"""
     E(f"""
-    s_and_b32 {st(0)}, {loc}, 63
     s_lshr_b32 {st(1)}, {loc}, 6
-    s_lshl_b64 {stp(2)}, 1, {st(0)}
+    s_lshl_b64 {stp(2)}, 1, {loc}
     s_lshl_b64 {stp(4)}, 1, {st(1)}
     s_not_b64 {stp(4)}, {stp(4)}
     s_mov_b64 exec, {stp(2)}
@@ -1090,7 +1256,9 @@ def assign_specials(tag, w0, w1, X, C, wl, pl, with_side, have):
 XA_, CA_, XB_, CB_ = 30, 26, 20, 10   # round-0 data: A in the D registers (d = p - X in place), B in v20..25; coefficients
 
 # ---------------------------------------------------------------------------------------------- screen + fetch, probe A first
-if ZB:
+if Z8:
+    screen_ranged8("A", s('axys'), v('wa0'), v('wa1'))
+elif ZB:
     screen_ranged("A", s('axys'), s('azz'), v('wa0'), v('wa1'))
     if ZBC:
         zbc_check(s('azz'), v('wa0'), v('wa1'))
@@ -1118,13 +1286,17 @@ else:
     v_and_b32 {v('wa0')}, -2, {v('wa0')}
     s_mov_b64 exec, -1
     """)
+if Z8C:
+    z8c_check("A", True, v('wa0'), v('wa1'), [(s('locA'), "1")], s('hasA'))
 if ZB:
     assign_specials("A", V['wa0'], V['wa1'], XA_, CA_, sp('wallM'), sp('planeM'), False, sp('haveA'))
 else:
     pick_fetch(V['wa0'], V['wa1'], XA_, sp('wallM'), sp('haveA'))
     wall_fetch(XA_, CA_)
 E("L_nofa:")
-if ZB:
+if Z8:
+    screen_ranged8("B", s('bxys'), v('wb0'), v('wb1'))
+elif ZB:
     screen_ranged("B", s('bxys'), s('bzz'), v('wb0'), v('wb1'))
     if ZBC:
         zbc_check(s('bzz'), v('wb0'), v('wb1'))
@@ -1184,6 +1356,8 @@ else:
     // probe A's data has had the whole second pass to arrive; B's travels while probe A is evaluated
     s_waitcnt vmcnt(0)
     """)
+if Z8C:
+    z8c_check("B", False, v('wb0'), v('wb1'), [(s('locB'), "1"), (s('locA'), s('hasA'))], s('hasB'))
 if ZB:
     assign_specials("B", V['wb0'], V['wb1'], XB_, CB_, sp('wallB'), sp('planeB'), True, sp('haveB'))
 else:
@@ -1304,9 +1478,8 @@ else:
     ds_write_b64 {v('S6')}, v[50:51] offset:{LDS_P0}
     ds_write_b64 {v('S6')}, v[52:53] offset:{LDS_P0 + 8}
     ds_write_b64 {v('S6')}, v[54:55] offset:{LDS_P0 + 16}
-    s_and_b32 {st(0)}, {s('locA')}, 63
     s_lshr_b32 {st(1)}, {s('locA')}, 6
-    s_lshl_b64 {stp(2)}, 1, {st(0)}
+    s_lshl_b64 {stp(2)}, 1, {s('locA')}
     s_lshl_b64 {stp(4)}, 1, {st(1)}
     s_not_b64 {stp(6)}, {stp(4)}
     s_cmp_eq_u32 {s('ua')}, 0
@@ -1320,18 +1493,23 @@ else:
     s_set_gpr_idx_off
     v_or_b32 {v('uns0')}, {st(4)}, {v('uns0')}
     v_or_b32 {v('uns1')}, {st(5)}, {v('uns1')}
-    s_lshr_b32 {st(2)}, {st(1)}, 1
-    s_lshl_b32 {st(2)}, {st(2)}, 8
-    s_and_b32 {st(3)}, {st(1)}, 1
-    s_lshl_b32 {st(3)}, {st(3)}, 1
-    s_add_u32 {st(2)}, {st(2)}, {st(3)}
-    v_add_u32 {v('S6')}, {st(2)}, {v('zaddr')}
-    v_mov_b32 {v('T',1)}, {s('az16')}
-    ds_write_b16 {v('S6')}, {v('T',1)}
+""")
+    if not Z8:
+        E(f"""
+        s_lshr_b32 {st(2)}, {st(1)}, 1
+        s_lshl_b32 {st(2)}, {st(2)}, 8
+        s_and_b32 {st(3)}, {st(1)}, 1
+        s_lshl_b32 {st(3)}, {st(3)}, 1
+        s_add_u32 {st(2)}, {st(2)}, {st(3)}
+        v_add_u32 {v('S6')}, {st(2)}, {v('zaddr')}
+        v_mov_b32 {v('T',1)}, {s('az16')}
+        ds_write_b16 {v('S6')}, {v('T',1)}
+        """)
+    E(f"""
     s_lshr_b32 {st(1)}, {st(1)}, 2
     s_lshl_b64 {stp(2)}, 1, {st(1)}
     s_load_dword {st(6)}, {KARG}, {K_RZ}
-    s_sext_i32_i16 {st(0)}, {s('az16')}
+    s_sext_i32_i16 {st(0)}, {s('axys') if Z8 else s('az16')}
     s_waitcnt lgkmcnt(0)
     s_sub_i32 {st(4)}, {st(0)}, {st(6)}
     s_add_i32 {st(5)}, {st(0)}, {st(6)}
@@ -1424,11 +1602,24 @@ v_readlane_b32 {s('Q',5)}, {v('D',1)}, 48
 v_readlane_b32 {st(0)}, {v('D',4)}, 16
 v_readlane_b32 {st(1)}, {v('D',4)}, 32
 v_readlane_b32 {st(2)}, {v('D',5)}, 48
-s_and_b32 {st(0)}, {st(0)}, 0xffff
-s_lshl_b32 {st(1)}, {st(1)}, 16
-s_or_b32 {st(0)}, {st(0)}, {st(1)}
-s_and_b32 {s('az16')}, {st(2)}, 0xffff
-s_mul_i32 {s('azz')}, {s('az16')}, 0x10001
+""")
+if Z8:
+    E(f"""
+    s_and_b32 {st(0)}, {st(0)}, 0xff
+    s_lshl_b32 {st(1)}, {st(1)}, 8
+    s_and_b32 {st(1)}, {st(1)}, 0xff00
+    s_or_b32 {st(0)}, {st(0)}, {st(1)}
+    s_pack_ll_b32_b16 {st(0)}, {st(2)}, {st(0)}
+    """)
+else:
+    E(f"""
+    s_and_b32 {st(0)}, {st(0)}, 0xffff
+    s_lshl_b32 {st(1)}, {st(1)}, 16
+    s_or_b32 {st(0)}, {st(0)}, {st(1)}
+    s_and_b32 {s('az16')}, {st(2)}, 0xffff
+    s_mul_i32 {s('azz')}, {s('az16')}, 0x10001
+    """)
+E(f"""
 {f"s_mov_b32 {s('axys')}, {st(0)}" if ZB else f"v_mov_b32 {v('axy')}, {st(0)}"}
 """)
 E(f"s_cmp_eq_u32 {s('cross')}, 1")
@@ -1486,6 +1677,28 @@ s_add_u32 {s('sw')}, {s('sw')}, 1
 s_cmp_lt_u32 {s('sw')}, {s('nsw')}
 s_cbranch_scc1 L_sweep
 """)
+if Z8C:
+    E(f"""
+    v_mov_b32 v25, 0
+    ds_read_b32 v22, v25 offset:{LDS_CNT}
+    ds_read_b32 v23, v25 offset:{LDS_CNT + 4}
+    ds_read_b32 v24, v25 offset:{LDS_CNT + 8}
+    s_load_dwordx2 {stp(2)}, {KARG}, {K_DBG}
+    v_mov_b32 v30, 0
+    v_mov_b32 v27, 0
+    s_waitcnt lgkmcnt(0)
+    s_mov_b64 exec, 1
+    v_mov_b32 v26, v22
+    global_atomic_add_x2 v30, v[26:27], {stp(2)}
+    v_mov_b32 v28, v23
+    v_mov_b32 v29, 0
+    global_atomic_add_x2 v30, v[28:29], {stp(2)} offset:8
+    v_mov_b32 v32, v24
+    v_mov_b32 v33, 0
+    global_atomic_add_x2 v30, v[32:33], {stp(2)} offset:16
+    s_mov_b64 exec, -1
+    s_waitcnt vmcnt(0)
+    """)
 if ZBC:
     E(f"""
     v_lshlrev_b32 v25, 3, {LANE}
@@ -1523,6 +1736,6 @@ with open(sys.argv[1] if len(sys.argv) > 1 else "smcx_sweep_ma_body.inc", "w") a
     f.write("// generated by gen_sweep_ma.py -- do not edit\n")
     for ln in out:
         # labels are per variant: the three bodies are assembled into one object
-        ln = re.sub(r"\bL_(\w+)", r"L%d%s_\1" % (NS, "z" if ZB else ""), ln)
+        ln = re.sub(r"\bL_(\w+)", r"L%d%s_\1" % (NS, MODE), ln)
         f.write('"%s\\n\\t"\n' % ln)
 print("%d lines" % len(out), file=sys.stderr)

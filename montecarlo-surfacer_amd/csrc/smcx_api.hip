@@ -363,6 +363,16 @@ extern "C" int smcx_screen_bound_int(const smcx_params *p, double *thr, double *
     return zs ? SMCX_OK : SMCX_ERR_UNSUPPORTED;
 }
 
+extern "C" int smcx_screen_bound_byte(const smcx_params *p, double *to_fixed, double *zsafe, int32_t *neg_t, int32_t *reach_z)
+{
+    if (!p || !to_fixed || !zsafe || !neg_t || !reach_z) return SMCX_ERR_PARAM;
+    if (!(p->L > 0) || !(p->Lz > 0) || !(p->cutoff > 0)) return SMCX_ERR_PARAM;
+    int nt = 0, rz = 0;
+    mc_bound_values(p->L, p->cutoff * p->cutoff, to_fixed, zsafe, &nt, &rz);
+    *neg_t = nt; *reach_z = rz;
+    return mc_box_supported(p->L, p->Lz, p->cutoff * p->cutoff) ? SMCX_OK : SMCX_ERR_UNSUPPORTED;
+}
+
 extern "C" int smcx_kernel_form(const smcx_handle *hh, int *form, char *name, int len)
 {
     if (!hh) return SMCX_ERR_PARAM;
@@ -371,7 +381,7 @@ extern "C" int smcx_kernel_form(const smcx_handle *hh, int *form, char *name, in
     if (form) *form = mx ? 2 : 1;
     const bool mi = mx && mi_supported(h.S, h.WPR, h.p.L, h.p.Lz, h.p.cutoff * h.p.cutoff);
     if (name && len > 0)
-        std::snprintf(name, (size_t)len, "%s", mi ? mi_kernel_name(h.S, h.p.N, h.p.L, h.p.Lz)
+        std::snprintf(name, (size_t)len, "%s", mi ? mi_kernel_name(h.S, h.p.N, h.p.L, h.p.Lz, h.p.cutoff * h.p.cutoff)
                                                   : mx ? mx_kernel_name(h.S, h.WPR, h.p.Lz) : fp64_kernel_name(h.S, h.WPR));
     return SMCX_OK;
 }

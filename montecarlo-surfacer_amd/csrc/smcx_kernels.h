@@ -37,7 +37,7 @@ hipError_t launch_sweeps_mx(const SweepArgs &a, const DevCtx &c, int S, int WPR,
 
 // integer-screen sweep kernel for one wavefront per replica (smcx_sweep_mi.hip)
 bool mi_supported(int S, int WPR, double L, double Lz, double cutoff2);
-const char *mi_kernel_name(int S, int N, double L, double Lz);
+const char *mi_kernel_name(int S, int N, double L, double Lz, double cutoff2);
 void mi_bound_values(double L, double Lz, double cutoff2, double *thr, double *u2, double *toFix, double *zsafe,
                      double *uz, int *negC, int *zshift);
 hipError_t launch_sweeps_mi(const SweepArgs &a, const DevCtx &c, int S, int nsweeps, double A, hipStream_t st,
@@ -47,6 +47,9 @@ hipError_t launch_sweeps_mi(const SweepArgs &a, const DevCtx &c, int S, int nswe
 bool ma_supported(int S, int WPR, int N, int M2);
 const char *ma_kernel_name(int S, int N);
 bool mb_supported(int S, int WPR, int N, int M2);
+bool mc_supported(int S, int WPR, int N, int M2, double L, double Lz, double cutoff2);
+bool mc_box_supported(double L, double Lz, double cutoff2);
+void mc_bound_values(double L, double cutoff2, double *toFix, double *zsafe, int *negT, int *RZ);
 hipError_t launch_sweeps_ma(const SweepArgs &s, const DevCtx &c, int S, const double *wtab, int nsweeps, double A,
                             double toFix, double zFix, double zsafe, int negC, hipStream_t st, SweepTimer *tm);
 

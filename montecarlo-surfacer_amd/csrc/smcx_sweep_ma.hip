@@ -104,6 +104,28 @@ __global__ void __launch_bounds__(64, 4) sweep_kernel_mb64(MaArgs a)
         : "memory", "vcc", "scc", "m0", SMCX_MA_SGPRS, SMCX_MA_V127);
 }
 
+// byte form (gen_sweep_ma.py ... z8): one word per cell, three instructions per slot and probe, no z words in LDS
+__global__ void __launch_bounds__(64, 4) sweep_kernel_mc64(MaArgs a)
+{
+    unsigned lane = threadIdx.x;
+    unsigned long long kp = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
+    unsigned rep = blockIdx.x;
+    asm volatile(
+#ifdef SMCX_CHECK
+#include "smcx_sweep_mcc_body64.inc" // + the fp64 cutoff test of every cell beside every pass, counting unflagged pairs
+#else
+#include "smcx_sweep_mc_body64.inc"
+#endif
+        : "+v"(lane), "+s"(kp), "+s"(rep)
+        :
+        : "memory", "vcc", "scc", "m0", SMCX_MA_SGPRS, SMCX_MA_V127);
+}
+#ifdef SMCX_CHECK
+constexpr unsigned mc_lds_bytes() { return 65u * 24u + 8u + 512u; }
+#else
+constexpr unsigned mc_lds_bytes() { return 65u * 24u; }
+#endif
+
 // Order of the cells for sweep_kernel_mb.  Cell = slot * 64 + lane; a group = 4 slots = 256 cells.
 //  1. the particles of a replica sorted by z (bitonic sort of (float z, particle) keys in LDS): group g holds
 //     ranks 256 g .. 256 g + 255, so its z range is as narrow as the configuration allows;
@@ -191,8 +213,8 @@ bool ma_supported(int S, int WPR, int N, int M2)
 #ifdef SMCX_CHECK
     // the diagnostic build counts the screen's misses in sweep_kernel_mi (same screen, hipcc-scheduled); with
     // SMCX_CHECK_MB=1 it runs sweep_kernel_mb64 instead, whose ranged passes are checked against full ones
-    static const char *chk = getenv("SMCX_CHECK_MB");
-    if (!(chk && chk[0] == '1' && S == 64)) return false;
+    static const char *chk = getenv("SMCX_CHECK_MB"); // 1: sweep_kernel_mb64, 2: sweep_kernel_mc64 (fp64 test of every cell)
+    if (!(chk && (chk[0] == '1' || chk[0] == '2') && S == 64)) return false;
 #endif
     static const char *env = getenv("SMCX_MA"); // SMCX_MA=0: sweep_kernel_mi instead, for A/B measurements
     if (env && env[0] == '0') return false;
@@ -207,9 +229,45 @@ bool mb_supported(int S, int WPR, int N, int M2)
     return S == 64 && ma_supported(S, WPR, N, M2);
 }
 
+// byte form of the z-binned kernel (one word per cell: z int16, x and y int8, unit L/256): the unit must resolve
+// the cutoff (16 units or more) and the box must fit the int16 z.  SMCX_MC=0 keeps sweep_kernel_mb64.
+bool mc_supported(int S, int WPR, int N, int M2, double L, double Lz, double cutoff2)
+{
+#ifdef SMCX_CHECK
+    static const char *chk = getenv("SMCX_CHECK_MB");
+    if (!(chk && chk[0] == '2')) return false;
+#endif
+    static const char *env = getenv("SMCX_MC");
+    if (env && env[0] == '0') return false;
+    return mb_supported(S, WPR, N, M2) && mc_box_supported(L, Lz, cutoff2);
+}
+
+void mc_bound(double L, double cutoff2, double *toFix, double *zsafe, int *negC, int *RZ);
+
+bool mc_box_supported(double L, double Lz, double cutoff2)
+{
+    const double u = L / 256.0, rc = std::sqrt(cutoff2);
+    return rc >= 16.0 * u && 0.5 * Lz < 32000.0 * u && L >= 2.0 * rc;
+}
+
+void mc_bound_values(double L, double cutoff2, double *toFix, double *zsafe, int *negT, int *RZ) { mc_bound(L, cutoff2, toFix, zsafe, negT, RZ); }
+
+// conservative threshold of the byte screen.  With d = packed difference of the two words (borrows leak one unit
+// from z into x and from x into y) and q = rc/u: for a pair inside the cutoff |dx|,|dy| <= |true|/u + 2 (two
+// roundings + borrow), |dz| <= |true|/u + 1, the high z byte contributes <= 1, so the sum of the four squared
+// bytes is < (q + 3)^2 + 1 (Minkowski with (2,2,1)); all bytes stay below 128 since q + 3 < 120.
+void mc_bound(double L, double cutoff2, double *toFix, double *zsafe, int *negC, int *RZ)
+{
+    const double u = L / 256.0, q = std::sqrt(cutoff2) / u;
+    *toFix = 256.0 / L;
+    *zsafe = 32766.0 * u;
+    *negC = -((int)std::floor((q + 3.0) * (q + 3.0)) + 3);
+    *RZ = (int)std::floor(q) + 3; // |dz| in units of a pair inside the cutoff, with the two roundings
+}
+
 const char *ma_kernel_name(int S, int N)
 {
-    if (mb_supported(S, 1, N, 0)) return "smcx::sweep_kernel_mb64";
+    if (mb_supported(S, 1, N, 0)) return "smcx::sweep_kernel_mb64"; // (mc: see ma_kernel_name_box)
     return S == 64 ? "smcx::sweep_kernel_ma64" : S == 32 ? "smcx::sweep_kernel_ma32" : "smcx::sweep_kernel_ma16";
 }
 
@@ -236,13 +294,21 @@ hipError_t launch_sweeps_ma(const SweepArgs &s, const DevCtx &c, int S, const do
         a.Rs = c.Rs; a.loc = c.loc;
         // the cells are re-sorted by z every `every` sweeps (SMCX_RESORT, default 1): the groups' z ranges only
         // widen inside a launch
+        const bool mc = mc_supported(S, 1, s.N, a.M2, c.L, c.Lz, c.cutoff2);
+        if (mc) {
+            mc_bound(c.L, c.cutoff2, &a.toFix, &a.zsafe, &a.negC, &a.RZ);
+            a.zFix = a.toFix;
+        }
         static const int every = [] { const char *e = getenv("SMCX_RESORT"); int v = e ? atoi(e) : 1; return v > 0 ? v : 1; }();
         for (int sw = 0; sw < nsweeps; sw += every) {
             hipLaunchKernelGGL(zsort_kernel<64 * 64>, dim3(c.nrep), dim3(256), 0, st, (const double *)s.R, c.Rs, c.loc, s.N, toFix);
             a.sw0 = sw; a.nsweeps = nsweeps - sw < every ? nsweeps - sw : every;
             hipError_t rc = tm ? tm->mark(st) : hipSuccess;
             if (rc != hipSuccess) return rc;
-            hipLaunchKernelGGL(sweep_kernel_mb64, dim3(c.nrep), dim3(64), mb_lds_bytes(64), st, a);
+            if (mc)
+                hipLaunchKernelGGL(sweep_kernel_mc64, dim3(c.nrep), dim3(64), mc_lds_bytes(), st, a);
+            else
+                hipLaunchKernelGGL(sweep_kernel_mb64, dim3(c.nrep), dim3(64), mb_lds_bytes(64), st, a);
             rc = hipGetLastError();
             if (rc == hipSuccess && tm) rc = tm->mark(st);
             if (rc != hipSuccess) return rc;

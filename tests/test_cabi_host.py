@@ -251,6 +251,81 @@ def test_integer_screen_unsupported_boxes_fall_back(S):
         assert e.value.status == S.ERR_UNSUPPORTED
 
 
+def _emulated_byte_screen(S, p, P, X):
+    """the byte screen of sweep_kernel_mc64 (gen_sweep_ma.py, screen_group8) in numpy with the device's
+    arithmetic: one word per particle (z int16 | x int8 << 16 | y int8 << 24, units of L/256, rint), the 32-bit
+    subtraction with its borrows from z into x and from x into y, v_dot4_i32_i8 of the difference with itself
+    (four signed bytes: low and high byte of dz, dx, dy) on the accumulator -T, sign bit.
+    Returns (candidate flag, exact in-cutoff flag, unsafe flag, |dz| in units)"""
+    to_fixed, zsafe, neg_t, reach_z = S.screen_bound_byte(p)
+
+    def word(A):
+        x = np.rint(A[:, 0] * to_fixed).astype(np.int64) & 0xff
+        y = np.rint(A[:, 1] * to_fixed).astype(np.int64) & 0xff
+        z = np.clip(np.rint(A[:, 2] * to_fixed), -32767, 32767).astype(np.int64) & 0xffff
+        return (z | (x << 16) | (y << 24)).astype(np.uint64), np.clip(np.rint(A[:, 2] * to_fixed), -32767, 32767)
+
+    wp, zp = word(P)
+    wx, zx = word(X)
+    d = (wp - wx) & np.uint64(0xffffffff)
+    acc = np.full(len(d), neg_t, dtype=np.int64)
+    for k in range(4):
+        b = ((d >> np.uint64(8 * k)) & np.uint64(0xff)).astype(np.int64)
+        b = np.where(b >= 128, b - 256, b)
+        acc += b * b
+    cand = acc < 0
+    unsafe = ~(np.abs(X[:, 2]) < zsafe) | ~(np.abs(P[:, 2]) < zsafe)
+    dd = P - X
+    dd[:, 0] -= p.L * np.rint(dd[:, 0] / p.L); dd[:, 1] -= p.L * np.rint(dd[:, 1] / p.L)
+    exact = (dd * dd).sum(axis=1) < p.cutoff ** 2
+    return cand, exact, unsafe, np.abs(zp - zx)
+
+
+@pytest.mark.parametrize("L,Lz", [(33.0, 240.0), (33.0, 60.0), (6.5, 240.0), (12.0, 700.0), (47.9, 240.0)])
+def test_byte_screen_never_misses_a_pair_inside_the_cutoff(S, L, Lz):
+    """the proof obligation of sweep_kernel_mc64's screen, checked on the CPU with the product's own numbers
+    (smcx_screen_bound_byte): 2e6 pairs per box placed within 1e-9 .. 0.3 of the cutoff sphere, across the
+    periodic x,y edges and over the whole z range.  Every pair inside the cutoff must be flagged, and its
+    |dz| in units must stay within reach_z (the amount the kernel widens a group's z range by: a group out of
+    reach holds no neighbour).  The screen stays useful: the flagged volume is below 1.7x the cutoff sphere."""
+    p = S.default_params(4096, 1, L=L, Lz=Lz)
+    rs = np.random.RandomState(int(L * 10 + Lz))
+    n = 2_000_000
+    to_fixed, zsafe, neg_t, reach_z = S.screen_bound_byte(p)
+    u = 1.0 / to_fixed
+    assert zsafe > Lz / 2 and -neg_t < 127 * 127 and (reach_z - 1) * u >= p.cutoff
+    X = np.empty((n, 3))
+    X[:, 0] = rs.uniform(-L / 2, L / 2, n); X[:, 1] = rs.uniform(-L / 2, L / 2, n)
+    X[:, 2] = rs.uniform(-Lz / 2, Lz / 2, n)
+    v = rs.normal(size=(n, 3)); v /= np.linalg.norm(v, axis=1)[:, None]
+    r = p.cutoff * (1.0 + rs.choice([-1, 1], n) * 10.0 ** rs.uniform(-9, np.log10(0.3), n))
+    Pp = X + v * r[:, None]
+    Pp[:, 0] -= L * np.rint(Pp[:, 0] / L); Pp[:, 1] -= L * np.rint(Pp[:, 1] / L)
+    cand, exact, unsafe, dzu = _emulated_byte_screen(S, p, Pp, X)
+    assert exact.sum() > n // 4 and (~exact).sum() > n // 4
+    missed = exact & ~cand & ~unsafe
+    assert not missed.any(), (missed.sum(), Pp[missed][:3], X[missed][:3])
+    assert dzu[exact].max() <= reach_z
+    # tightness: uniformly placed pairs are flagged about as often as the volume ratio of the two spheres says
+    # (|dz| kept below 128 units: further apart the low byte of dz aliases -- cells the z ranges keep out of the
+    # passes, and which cost a wasted evaluation at worst)
+    zs = min(6.0, 60 * u)
+    far = rs.uniform(-1, 1, (400000, 3)) * [L / 2, L / 2, zs]
+    far2 = rs.uniform(-1, 1, (400000, 3)) * [L / 2, L / 2, zs]
+    c2, e2, _, _ = _emulated_byte_screen(S, p, far, far2)
+    assert not (e2 & ~c2).any() and c2.sum() <= 1.7 * e2.sum() + 50
+
+
+def test_byte_screen_unsupported_boxes(S):
+    """a box whose L/256 does not resolve the cutoff, or one narrower than two cutoffs: the engine keeps
+    sweep_kernel_mb64 / sweep_kernel_mi (int16 units of L/65536)"""
+    for kw in (dict(L=100.0, Lz=240.0), dict(L=5.0, Lz=240.0, cutoff=3.0)):
+        p = S.default_params(4096, 1, **kw)
+        with pytest.raises(S.SmcxError) as e:
+            S.screen_bound_byte(p)
+        assert e.value.status == S.ERR_UNSUPPORTED
+
+
 def test_srand_state_agrees_with_oracle_rand(S, O):
     """smcx_rng_seed = srand(): continuing r[i] = r[i-31] + r[i-3] from the exported
     state must give rand()'s outputs."""

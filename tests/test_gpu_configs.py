@@ -139,16 +139,17 @@ def test_screen_ab_against_fp64_kernel_at_scale(S, O, N, lat, nrep, nsw, mx_geom
     order, so they agree to rounding until chaos amplifies it: measured on MI355X at N=4096 the energy
     difference grows about tenfold per sweep from 1e-14 relative (2e-13 after five sweeps, 2e-8 after
     ten) and eventually flips an accept decision.  A pair dropped by the screen would instead shift E
-    by >= 4|V(rc)| = 5e-3 at once.  Required: over the first four sweeps |dE| <= 1e-9 (1 + |E|) for
-    every replica -- seven orders of magnitude below one missed pair --, |dE| < 1e-3 through sweep six
-    (the z-ordered cells of sweep_kernel_mb64 sum in yet another order: 3e-5 at most there, measured) and
-    equal accept counts over those sweeps; over all sweeps at most 2 % of the replicas with a differing
-    accept count.  (The counters of the diagnostic build, below, cover every sweep directly.)"""
+    by >= 4|V(rc)| = 5e-3 at once.  Required: over the first three sweeps |dE| <= 1e-9 (1 + |E|) for
+    every replica -- seven orders of magnitude below one missed pair --, |dE| < 1e-3 through sweep five
+    (the z-ordered cells of sweep_kernel_mb64 / mc64 sum in yet another order: 3e-6 at most after four
+    sweeps, measured over 256 replicas) and equal accept counts over those sweeps; over all sweeps at most
+    2 % of the replicas with a differing accept count.  (The counters of the diagnostic build, below, test
+    every cell on every move directly.)"""
     (Ea, ja), (Eb, jb) = _ab_kernels(S, O, N, lat, nrep, nsw, mx_geom, fp_geom)
-    k = min(nsw, 4)
+    k = min(nsw, 3)
     assert np.all(np.abs(Ea[:, :k + 1] - Eb[:, :k + 1]) <= 1e-9 * (1.0 + np.abs(Ea[:, :k + 1]))), \
         np.abs(Ea[:, :k + 1] - Eb[:, :k + 1]).max()
-    k = min(nsw, 6)
+    k = min(nsw, 5)
     assert np.abs(Ea[:, :k + 1] - Eb[:, :k + 1]).max() < 1e-3
     assert np.array_equal(ja[:, :k], jb[:, :k]) and ja.sum() > 0
     diverged = int((ja != jb).any(axis=1).sum())
@@ -185,7 +186,7 @@ def test_hand_scheduled_kernel_matches_compiled_kernel(S, O, tmp_path, N, lat, n
     w = tmp_path / "mi_worker.py"
     w.write_text(_MI_WORKER)
     out = {}
-    legs = [("ma", {"SMCX_MB": "0"}), ("mi", {"SMCX_MA": "0"})] + ([("mb", {})] if slots == 64 else [])
+    legs = [("ma", {"SMCX_MB": "0"}), ("mi", {"SMCX_MA": "0"})] + ([("mb", {"SMCX_MC": "0"}), ("mc", {})] if slots == 64 else [])
     for tag, env in legs:
         f = str(tmp_path / (tag + ".npz"))
         r = subprocess.run([sys.executable, str(w), ROOT, f, str(N), str(lat[0]), str(lat[1]), str(nrep), str(nsw),
@@ -194,8 +195,9 @@ def test_hand_scheduled_kernel_matches_compiled_kernel(S, O, tmp_path, N, lat, n
         out[tag] = np.load(f)
     assert str(out["ma"]["name"]) == "smcx::sweep_kernel_ma%d" % slots and "sweep_kernel_mi" in str(out["mi"]["name"])
     if slots == 64:
-        # the z-binned form (cells in z order, only the groups in reach screened): the default for this geometry
-        assert str(out["mb"]["name"]) == "smcx::sweep_kernel_mb64"
+        # the z-binned forms (cells in z order, only the groups in reach screened): int16 x,y + int16 z in LDS,
+        # and the default for this box, one word per cell (int8 x, y + int16 z) screened by v_dot4_i32_i8
+        assert str(out["mb"]["name"]) == "smcx::sweep_kernel_mb64" and str(out["mc"]["name"]) == "smcx::sweep_kernel_mc64"
     for tag in out:
         if tag == "mi":
             continue
@@ -273,8 +275,17 @@ with K.Engine(p) as eng:
     f.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
     assert f(eng._h, cnt) == 0
     acc = int(eng.observables()["accepted"].sum())
-print(json.dumps({"name": name, "cand": int(cnt[1]), "miss": int(cnt[2]), "acc": acc}))
+print(json.dumps({"name": name, "inside": int(cnt[0]), "cand": int(cnt[1]), "miss": int(cnt[2]), "acc": acc}))
 """
+
+
+def _run_check_worker(tmp_path, mode, N, lat, nrep, nsw, gl):
+    w = tmp_path / "mbc_worker.py"
+    w.write_text(_MBC_WORKER)
+    r = subprocess.run([sys.executable, str(w), ROOT, str(N), str(lat[0]), str(lat[1]), str(nrep), str(nsw), str(gl)],
+                       env=dict(os.environ, SMCX_CHECK_MB=mode), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return json.loads(r.stdout.strip().splitlines()[-1])
 
 
 @pytest.mark.parametrize("N,lat,nrep,nsw,gl", [(4096, (8, 16), 256, 6, 3), (4000, (10, 10), 64, 4, 1), (2100, (5, 21), 64, 3, 3)])
@@ -284,18 +295,31 @@ def test_ranged_screen_sets_every_bit_of_the_full_screen(tmp_path, N, lat, nrep,
     the same probe and counts the bits of the full result that the ranged result lacks: must be zero over all
     moves -- with re-sorts between the sweeps of a launch (gl = 3: ranges widened by two sweeps of accepted
     moves), a ragged N, and a thin tall start (fcc(5,21): few particles per z range)."""
-    w = tmp_path / "mbc_worker.py"
-    w.write_text(_MBC_WORKER)
-    r = subprocess.run([sys.executable, str(w), ROOT, str(N), str(lat[0]), str(lat[1]), str(nrep), str(nsw), str(gl)],
-                       env=dict(os.environ, SMCX_CHECK_MB="1"), capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stderr[-2000:]
-    d = json.loads(r.stdout.strip().splitlines()[-1])
+    d = _run_check_worker(tmp_path, "1", N, lat, nrep, nsw, gl)
     moves = nrep * nsw * N
     print("N=%d: %d moves, %d candidate bits of the full passes, %d missing from the ranged passes" %
           (N, moves, d["cand"], d["miss"]))
     assert d["name"] == "smcx::sweep_kernel_mb64"
     assert d["miss"] == 0
     assert d["cand"] > moves and d["acc"] > 0
+
+
+@pytest.mark.parametrize("N,lat,nrep,nsw,gl", [(4096, (8, 16), 64, 4, 2), (4000, (10, 10), 32, 3, 1), (2100, (5, 21), 32, 3, 3)])
+def test_byte_screen_kernel_misses_no_pair_inside_the_cutoff(tmp_path, N, lat, nrep, nsw, gl):
+    """sweep_kernel_mc64 (the benchmark's kernel): one word per cell screened by v_dot4_i32_i8, only the groups in
+    z reach.  Its diagnostic build (SMCX_CHECK_MB=2) runs, beside EVERY pass, the fp64 cutoff test with the
+    minimum image of SMC.c:567-578 on EVERY cell from the fp64 positions in memory and counts the pairs inside
+    the cutoff whose bit the pass did not set (the moving particle and the probe's own particle excepted, as
+    in the reference's loop): must be zero; the counts of true pairs and of candidate bits show the check is not
+    vacuous and how tight the screen is (the byte units flag about 1.5x the cutoff sphere)."""
+    d = _run_check_worker(tmp_path, "2", N, lat, nrep, nsw, gl)
+    moves = nrep * nsw * N
+    print("N=%d: %d moves, %d pairs inside the cutoff, %d candidate bits (%.2fx), %d missed" %
+          (N, moves, d["inside"], d["cand"], d["cand"] / max(d["inside"], 1), d["miss"]))
+    assert d["name"] == "smcx::sweep_kernel_mc64"
+    assert d["miss"] == 0
+    assert d["inside"] > moves and d["cand"] >= d["inside"] and d["acc"] > 0
+    assert d["cand"] < 3 * d["inside"] + 40 * moves
 
 
 # ------------------------------------------------------------------ statistics beyond the chaos horizon

@@ -213,7 +213,7 @@ def test_benchmark_kernel_against_oracle_N4096(S, O):
     R0 = O.fcc(8, 16)
     nsw, nrep = 3, 2
     eng, p = make_engine(S, O, R0, nrep, flags=S.FLAGS_REFERENCE | S.FLAG_SERIES, tune_slots=64, tune_waves=1)
-    assert eng.kernel_form == (2, "smcx::sweep_kernel_mb64"), eng.kernel_form
+    assert eng.kernel_form == (2, "smcx::sweep_kernel_mc64"), eng.kernel_form
     eng.run(0, nsw, 1)
     ob = eng.observables()
     Es, jj = eng.series(nsw)
