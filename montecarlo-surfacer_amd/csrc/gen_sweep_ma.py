@@ -621,8 +621,23 @@ v_mov_b32 {v('FmV')}, 0
 v_mov_b32 {v('FmV',1)}, 0
 v_mov_b32 {v('DdV')}, 0
 v_mov_b32 {v('DdV',1)}, 0
-L_move:
 """)
+# rarely executed pieces of the move (zb) are gathered here, jumped over when a run starts
+COLD_AT = None
+if ZB:
+    E("s_branch L_move")
+    COLD_AT = len(out)
+E("L_move:")
+cold = []
+
+
+def COLD(txt):
+    for ln in txt.strip("\n").split("\n"):
+        ln = ln.strip()
+        if ln and not ln.startswith("//"):
+            cold.append(ln)
+
+
 
 # ---------------------------------------------------------------------------------------------- B's compact copy
 if not ZB:
@@ -663,14 +678,8 @@ L_nob1:
 else:
   # zb: from the row registers (lane tl + 1), or the scalar copy of particle row*64 + 64 when the order crosses rows
   E(f"""
-  s_mov_b32 {s('bzz')}, 0
-  s_mov_b32 {s('ub')}, 0
-  s_mov_b32 {s('cross')}, 0
-  s_mov_b32 {s('lb')}, 0
-  s_mov_b32 {s('bxys')}, 0
-  s_mov_b32 {s('locB')}, 0
   s_cmp_eq_u32 {s('hasB')}, 0
-  s_cbranch_scc1 L_nob1
+  s_cbranch_scc1 L_nob0
   s_add_u32 {s('lb')}, {s('tl')}, 1
   s_cmp_eq_u32 {s('tl')}, 63
   s_cselect_b32 {s('lb')}, 0, {s('lb')}
@@ -686,6 +695,16 @@ else:
   {"" if Z8 else f"s_and_b32 {st(1)}, {st(1)}, 0xffff"}
   {"" if Z8 else f"s_mul_i32 {s('bzz')}, {st(1)}, 0x10001"}
   L_nob1:
+  """)
+  COLD(f"""
+  L_nob0:
+  s_mov_b32 {s('bzz')}, 0
+  s_mov_b32 {s('ub')}, 0
+  s_mov_b32 {s('cross')}, 0
+  s_mov_b32 {s('lb')}, 0
+  s_mov_b32 {s('bxys')}, 0
+  s_mov_b32 {s('locB')}, 0
+  s_branch L_nob1
   """)
 
 # ---------------------------------------------------------------------------------------------- screen
@@ -788,9 +807,8 @@ def screen_ranged(tag, pxys, pzz, w0, w1):
     """)
     if NS == 64:
         E(f"""
-        s_sub_u32 {st(1)}, {st(4)}, 8
+        s_sub_u32 {st(1)}, {st(0)}, 32
         s_max_i32 {st(1)}, {st(1)}, 0
-        s_lshl_b32 {st(1)}, {st(1)}, 2
         v_lshlrev_b32 {w1}, {st(1)}, {w1}
         """)
     E(f"L_sdone_{tag}:")
@@ -864,9 +882,8 @@ def screen_ranged8(tag, pws, w0, w1):
     """)
     if NS == 64:
         E(f"""
-        s_sub_u32 {st(1)}, {st(4)}, 8
+        s_sub_u32 {st(1)}, {st(0)}, 32
         s_max_i32 {st(1)}, {st(1)}, 0
-        s_lshl_b32 {st(1)}, {st(1)}, 2
         v_lshlrev_b32 {w1}, {st(1)}, {w1}
         """)
     E(f"L_sdone_{tag}:")
@@ -991,9 +1008,9 @@ def pick_fetch(w0, w1, X, spec_mask, have):
     {"" if ZB else f"v_add_u32 v44, {s('rot')}, v44"}
     {"" if ZB else f"v_and_b32 v44, {NS - 1}, v44"}
     v_lshl_or_b32 v44, v44, 6, {LANE}
-    v_cmp_gt_u32 vcc, {s('N')}, v44
+    {"" if ZB else f"v_cmp_gt_u32 vcc, {s('N')}, v44"}
     v_mul_u32_u24 v45, 24, v44
-    s_and_b64 exec, exec, vcc
+    {"" if ZB else "s_and_b64 exec, exec, vcc"}
     global_load_dwordx4 v[{X}:{X+3}], v45, {SRC}
     global_load_dwordx2 v[{X+4}:{X+5}], v45, {SRC} offset:16
     s_mov_b64 {have}, exec
@@ -1059,7 +1076,12 @@ def body(tag, P, X, C, items, round0, wl=None, pl=None):
     v_add_f64 {vp('D',1)}, {P[1]}, -v[{X+2}:{X+3}]
     v_add_f64 {vp('D',2)}, {P[2]}, -v[{X+4}:{X+5}]
     """)
-    if round0:
+    if round0 and ZB:
+        E(f"""
+        v_cndmask_b32 {v('D',4)}, {v('D',4)}, {v('wdz')}, {wl}
+        v_cndmask_b32 {v('D',5)}, {v('D',5)}, {v('wdz',1)}, {wl}
+        """)
+    elif round0:
         E(f"""
         s_and_b64 exec, {items}, {wl}
         v_mov_b32 {v('D',4)}, {v('wdz')}
@@ -1074,7 +1096,14 @@ def body(tag, P, X, C, items, round0, wl=None, pl=None):
     v_fma_f64 {vp('M',0)}, -{vp('T')}, {sp('L')}, {vp('D',0)}
     v_fma_f64 {vp('M',1)}, -{vp('S6')}, {sp('L')}, {vp('D',1)}
     """)
-    if round0:
+    if round0 and ZB:
+        E(f"""
+        v_cndmask_b32 {v('M',0)}, {v('M',0)}, 0, {pl}
+        v_cndmask_b32 {v('M',1)}, {v('M',1)}, 0, {pl}
+        v_cndmask_b32 {v('M',2)}, {v('M',2)}, 0, {pl}
+        v_cndmask_b32 {v('M',3)}, {v('M',3)}, 0, {pl}
+        """)
+    elif round0:
         E(f"""
         s_and_b64 exec, {items}, {pl}
         v_mov_b32 {v('M',0)}, 0
@@ -1172,8 +1201,8 @@ def probe(tag, P, pz_sgpr, pz, w0, w1, X, C, have, side, wait, wl=None, pl=None)
     E(f"""
     L_more_{tag}:
     v_cmp_ne_u64 vcc, 0, v[{w0}:{w1}]
-    s_cmp_lg_u64 vcc, 0
-    s_cbranch_scc0 L_done_{tag}
+    {"s_cbranch_vccz L_done_" + tag if ZB else "s_cmp_lg_u64 vcc, 0"}
+    {"" if ZB else "s_cbranch_scc0 L_done_" + tag}
     """)
     coeff_one(C)
     pick_fetch(w0, w1, X, "0", stp(6))
@@ -1187,19 +1216,23 @@ def assign_specials(tag, w0, w1, X, C, wl, pl, with_side, have):
     """zb, round 0 of a probe: every lane with a candidate takes its lowest one (load of its fp64 position asked
     for; `have` <- those lanes); the wall sites, the plane and -- for probe B after a move -- the side pair go to
     the first lanes WITHOUT a candidate (rank among them = row of the wall table), so no candidate waits for a
-    second round behind them.  With too few free lanes: the fixed lanes 0..M2 (and 30), as in sweep_kernel_ma."""
+    second round behind them.  With too few free lanes (cold path): the fixed lanes 0..M2 (and 30), as in
+    sweep_kernel_ma.  No test of the cell against N: an empty cell (z = 0x7fff) is never flagged, and the
+    all-flagged words of an unsafe probe are cut to the real cells where they are made."""
     wlo, whi = (int(x) for x in wl[2:-1].split(":"))
+    need = st(6) if with_side else st(3)
     E(f"""
-    v_cmp_ne_u64 vcc, 0, v[{w0}:{w1}]
+    v_cmp_ne_u64 {have}, 0, v[{w0}:{w1}]
     s_add_u32 {st(3)}, {s('M2')}, 1
-    s_not_b64 {stp(0)}, vcc
+    s_not_b64 {stp(0)}, {have}
     s_bcnt1_i32_b64 {st(2)}, {stp(0)}
-    {f"s_add_u32 {st(6)}, {st(3)}, {s('hasA')}" if with_side else f"s_mov_b32 {st(6)}, {st(3)}"}
-    s_cmp_lt_u32 {st(2)}, {st(6)}
+    {f"s_add_u32 {st(6)}, {st(3)}, {s('hasA')}" if with_side else ""}
+    s_cmp_lt_u32 {st(2)}, {need}
     s_cbranch_scc1 L_sps_{tag}
     v_mbcnt_lo_u32_b32 v48, {st(0)}, 0
     v_mbcnt_hi_u32_b32 v48, {st(1)}, v48
-    s_mov_b64 {have}, vcc
+    v_ffbl_b32 v44, v{w0}
+    v_ffbl_b32 v45, v{w1}
     v_cmp_gt_u32 {wl}, {st(3)}, v48
     v_cmp_eq_u32 {pl}, {s('M2')}, v48
     """)
@@ -1212,7 +1245,28 @@ def assign_specials(tag, w0, w1, X, C, wl, pl, with_side, have):
     E(f"""
     s_and_b64 {wl}, {wl}, {stp(0)}
     s_and_b64 {pl}, {pl}, {stp(0)}
-    s_branch L_spj_{tag}
+    L_spj_{tag}:
+    v_lshl_add_u64 v[46:47], v[{w0}:{w1}], 0, -1
+    v_or_b32 v45, 32, v45
+    v_min_u32 v44, v44, v45
+    v_and_b32 v{w0}, v{w0}, v46
+    v_and_b32 v{w1}, v{w1}, v47
+    v_lshl_or_b32 v44, v44, 6, {LANE}
+    v_mul_u32_u24 v45, 24, v44
+    v_lshlrev_b32 v49, 5, v48
+    s_mov_b64 exec, {have}
+    global_load_dwordx4 v[{X}:{X+3}], v45, {SRC}
+    global_load_dwordx2 v[{X+4}:{X+5}], v45, {SRC} offset:16
+    s_mov_b64 exec, -1
+    """)
+    coeff_one(C)
+    E(f"""
+    s_mov_b64 exec, {wl}
+    global_load_dwordx4 v[{X}:{X+3}], v49, {sp('wtab')}
+    global_load_dwordx4 v[{C}:{C+3}], v49, {sp('wtab')} offset:16
+    s_mov_b64 exec, -1
+    """)
+    COLD(f"""
     L_sps_{tag}:
     s_lshl_b64 {wl}, 1, {st(3)}
     s_sub_u32 s{wlo}, s{wlo}, 1
@@ -1223,33 +1277,28 @@ def assign_specials(tag, w0, w1, X, C, wl, pl, with_side, have):
     s_mov_b64 {stp(4)}, {wl}
     {f"s_mov_b32 {s('sideL')}, 30" if with_side else ""}
     {f"s_or_b32 {st(4)}, {st(4)}, 0x40000000" if with_side else ""}
-    s_andn2_b64 {have}, vcc, {stp(4)}
+    s_andn2_b64 {have}, {have}, {stp(4)}
     v_mov_b32 v48, {LANE}
-    L_spj_{tag}:
-    s_mov_b64 exec, {have}
     v_ffbl_b32 v44, v{w0}
     v_ffbl_b32 v45, v{w1}
-    v_lshl_add_u64 v[46:47], v[{w0}:{w1}], 0, -1
-    v_or_b32 v45, 32, v45
-    v_min_u32 v44, v44, v45
-    v_and_b32 v{w0}, v{w0}, v46
-    v_and_b32 v{w1}, v{w1}, v47
-    v_lshl_or_b32 v44, v44, 6, {LANE}
-    v_cmp_gt_u32 vcc, {s('N')}, v44
-    v_mul_u32_u24 v45, 24, v44
-    s_and_b64 exec, exec, vcc
-    global_load_dwordx4 v[{X}:{X+3}], v45, {SRC}
-    global_load_dwordx2 v[{X+4}:{X+5}], v45, {SRC} offset:16
-    s_mov_b64 {have}, exec
-    s_mov_b64 exec, -1
+    s_branch L_spj_{tag}
     """)
-    coeff_one(C)
+
+
+def all_real_cells(w0, w1):
+    """zb, unsafe probe: every REAL cell of this lane is a candidate (cell = slot * 64 + lane < N)"""
     E(f"""
-    s_mov_b64 exec, {wl}
-    v_lshlrev_b32 v49, 5, v48
-    global_load_dwordx4 v[{X}:{X+3}], v49, {sp('wtab')}
-    global_load_dwordx4 v[{C}:{C+3}], v49, {sp('wtab')} offset:16
-    s_mov_b64 exec, -1
+    v_sub_u32 v14, {s('N')}, {LANE}
+    v_add_u32 v14, 63, v14
+    v_ashrrev_i32 v14, 6, v14
+    v_max_i32 v14, 0, v14
+    v_mov_b32 v16, 1
+    v_mov_b32 v17, 0
+    v_lshlrev_b64 v[16:17], v14, v[16:17]
+    v_lshl_add_u64 v[16:17], v[16:17], 0, -1
+    v_cmp_lt_u32 vcc, 63, v14
+    v_cndmask_b32 {w0}, v16, -1, vcc
+    v_cndmask_b32 {w1}, v17, -1, vcc
     """)
 
 
@@ -1272,8 +1321,13 @@ s_cmp_eq_u32 {s('hasA')}, 0
 s_cbranch_scc1 L_nofa
 s_cmp_eq_u32 {s('ua')}, 0
 s_cbranch_scc1 L_ua0
-v_mov_b32 {v('wa0')}, {'-1' if NS >= 32 else '0xffff'}
-v_mov_b32 {v('wa1')}, {'-1' if NS == 64 else '0'}
+""")
+if ZB:
+    all_real_cells(v('wa0'), v('wa1'))
+else:
+    E(f"v_mov_b32 {v('wa0')}, {'-1' if NS >= 32 else '0xffff'}")
+    E(f"v_mov_b32 {v('wa1')}, {'-1' if NS == 64 else '0'}")
+E(f"""
 L_ua0:
 """)
 if ZB:
@@ -1314,8 +1368,13 @@ s_lshl_b32 {st(0)}, {st(0)}, 3
 s_load_dwordx2 {sp('nlu')}, {sp('uK')}, {st(0)}
 s_cmp_eq_u32 {s('ub')}, 0
 s_cbranch_scc1 L_ub0
-v_mov_b32 {v('wb0')}, {'-1' if NS >= 32 else '0xffff'}
-v_mov_b32 {v('wb1')}, {'-1' if NS == 64 else '0'}
+""")
+if ZB:
+    all_real_cells(v('wb0'), v('wb1'))
+else:
+    E(f"v_mov_b32 {v('wb0')}, {'-1' if NS >= 32 else '0xffff'}")
+    E(f"v_mov_b32 {v('wb1')}, {'-1' if NS == 64 else '0'}")
+E(f"""
 L_ub0:
 """)
 if ZB:
@@ -1364,9 +1423,8 @@ else:
     pick_fetch(V['wb0'], V['wb1'], XB_, stp(0), sp('haveB'))
     wall_fetch(XB_, CB_)
 E(f"""
-// probe B's fp64 position from the LDS cache: row = cross ? 64 : tl + 1
-s_cmp_eq_u32 {s('cross')}, 1
-s_cselect_b32 {st(0)}, 64, {s('lb')}
+// probe B's fp64 position from the LDS cache: row = cross ? 64 : tl + 1 (= tl + 1 either way)
+s_add_u32 {st(0)}, {s('tl')}, 1
 s_mul_i32 {st(0)}, {st(0)}, 24
 v_mov_b32 {v('T')}, {st(0)}
 ds_read_b64 v[14:15], {v('T')} offset:{LDS_P0}
@@ -1393,9 +1451,9 @@ v_fma_f64 {vp('D',2)}, {vp('FmV')}, {sp('AoT')}, {vp('DdV')}
 v_mul_f64 {vp('D',2)}, {vp('D',2)}, 0.5
 v_fma_f64 {vp('D',2)}, {vp('D',0)}, {sp('Ao4T')}, {vp('D',2)}
 v_mul_f64 {vp('D',2)}, {vp('D',2)}, {vp('D',1)}
-s_mov_b32 {st(0)}, 0xffff
-s_mov_b32 {st(1)}, 0
-s_mov_b64 exec, {stp(0)}
+{"s_mov_b64 exec, 0xffff" if ZB else f"s_mov_b32 {st(0)}, 0xffff"}
+{"" if ZB else f"s_mov_b32 {st(1)}, 0"}
+{"" if ZB else f"s_mov_b64 exec, {stp(0)}"}
 v_mul_f64 {vp('D',2)}, {vp('D',0)}, 4.0
 s_mov_b64 exec, -1
 // sum over the four rows: lanes ^32, then rows ^1
@@ -1416,8 +1474,8 @@ s_nop 0
 v_add_f64 {vp('D',2)}, {vp('D',2)}, {vp('T')}
 v_mul_f64 {vp('D',2)}, {vp('D',2)}, -{sp('invT')}
 v_cmp_lt_f64 vcc, {sp('lu')}, {vp('D',2)}
-s_cmp_lg_u64 vcc, 0
-s_cbranch_scc0 L_reject
+{"s_cbranch_vccz L_reject" if ZB else "s_cmp_lg_u64 vcc, 0"}
+{"" if ZB else "s_cbranch_scc0 L_reject"}
 // accepted: E += Un - Um = 4 (eA - eB) (row 0 of g), particle n takes the proposal
 v_readlane_b32 {st(0)}, {v('D',0)}, 0
 v_readlane_b32 {st(1)}, {v('D',1)}, 0
@@ -1563,8 +1621,7 @@ v_lshrrev_b32 {v('T')}, 4, {LANE}
 v_add_u32 {v('T')}, -1, {v('T')}
 v_max_i32 {v('T')}, 0, {v('T')}
 v_lshlrev_b32 {v('T')}, 3, {v('T')}
-s_cmp_eq_u32 {s('cross')}, 1
-s_cselect_b32 {st(0)}, 64, {s('lb')}
+s_add_u32 {st(0)}, {s('tl')}, 1
 s_mul_i32 {st(0)}, {st(0)}, 24
 v_add_u32 {v('T',1)}, {st(0)}, {v('T')}
 ds_read_b64 {vp('D',0)}, {v('T',1)} offset:{LDS_P0}
@@ -1573,17 +1630,17 @@ s_mov_b64 {sp('lu')}, {sp('nlu')}
 v_fma_f64 {vp('D',1)}, {vp('FmV')}, {sp('AoT')}, {vp('DdV')}
 v_add_f64 {vp('D',0)}, {vp('D',0)}, {vp('D',1)}
 // wrap x and y (rows 1, 2 = lanes 16..47), fixed point with 65536/L
-s_mov_b32 {st(0)}, 0xffff0000
-s_mov_b32 {st(1)}, 0x0000ffff
-s_mov_b64 exec, {stp(0)}
+{"s_bfm_b64 exec, 32, 16" if ZB else f"s_mov_b32 {st(0)}, 0xffff0000"}
+{"" if ZB else f"s_mov_b32 {st(1)}, 0x0000ffff"}
+{"" if ZB else f"s_mov_b64 exec, {stp(0)}"}
 v_mul_f64 {vp('D',1)}, {vp('D',0)}, {sp('invL')}
 v_rndne_f64 {vp('D',1)}, {vp('D',1)}
 v_fma_f64 {vp('D',0)}, -{vp('D',1)}, {sp('L')}, {vp('D',0)}
 v_mul_f64 {vp('D',1)}, {vp('D',0)}, {sp('toFix')}
 // z (row 3 = lanes 48..63): fixed point with 1/uz; outside the safe range?
-s_mov_b32 {st(0)}, 0
-s_mov_b32 {st(1)}, 0xffff0000
-s_mov_b64 exec, {stp(0)}
+{"s_bfm_b64 exec, 16, 48" if ZB else f"s_mov_b32 {st(0)}, 0"}
+{"" if ZB else f"s_mov_b32 {st(1)}, 0xffff0000"}
+{"" if ZB else f"s_mov_b64 exec, {stp(0)}"}
 v_mul_f64 {vp('D',1)}, {vp('D',0)}, {sp('zFix')}
 v_cmp_nlt_f64 vcc, |{vp('D',0)}|, {sp('zsafe')}
 s_mov_b64 exec, -1
@@ -1732,6 +1789,8 @@ s_mov_b64 exec, -1
 s_waitcnt vmcnt(0) lgkmcnt(0)
 """)
 
+if COLD_AT is not None:
+    out[COLD_AT:COLD_AT] = cold
 with open(sys.argv[1] if len(sys.argv) > 1 else "smcx_sweep_ma_body.inc", "w") as f:
     f.write("// generated by gen_sweep_ma.py -- do not edit\n")
     for ln in out:
