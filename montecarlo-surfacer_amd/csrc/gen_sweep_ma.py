@@ -503,6 +503,16 @@ def rotate(tag):
 
 fill_p0("init")
 
+if Z8:
+    # the nlu pair holds the address the screens' computed jumps are relative to: block NG-1 of probe A's pass
+    # (a label further down: the offset is positive)
+    E(f"""
+    s_getpc_b64 {sp('nlu')}
+    L_jbase:
+    s_add_u32 {s('nlu')}, {s('nlu')}, L_sg{NG-1}_A-L_jbase
+    s_addc_u32 {s('nlu',1)}, {s('nlu',1)}, 0
+    """)
+
 # ---------------------------------------------------------------------------------------------- sweeps, runs
 if not ZB:
     E(f"""
@@ -860,12 +870,10 @@ def screen_ranged8(tag, pws, w0, w1):
     s_cbranch_scc1 L_sdone_{tag}
     s_ff1_i32_b32 {st(4)}, {st(1)}
     s_flbit_i32_b32 {st(5)}, {st(1)}
-    s_getpc_b64 {stp(2)}
-    L_spc_{tag}:
     s_mul_i32 {st(5)}, {st(5)}, L_sg{NG-2}_{tag}-L_sg{NG-1}_{tag}
-    s_add_u32 {st(5)}, {st(5)}, L_sg{NG-1}_{tag}-L_spc_{tag}-{32 - NG}*(L_sg{NG-2}_{tag}-L_sg{NG-1}_{tag})
-    s_add_u32 {st(2)}, {st(2)}, {st(5)}
-    s_addc_u32 {st(3)}, {st(3)}, 0
+    s_add_u32 {st(5)}, {st(5)}, L_sg{NG-1}_{tag}-L_sg{NG-1}_A-{32 - NG}*(L_sg{NG-2}_A-L_sg{NG-1}_A)
+    s_add_u32 {st(2)}, {s('nlu')}, {st(5)}
+    s_addc_u32 {st(3)}, {s('nlu',1)}, 0
     s_setpc_b64 {stp(2)}
     """)
     # blocks in descending group order; flbit = 31 - highest group, so block g sits (flbit - (32 - NG)) blocks in
@@ -1316,7 +1324,7 @@ else:
 E(f"""
 v_or_b32 {v('wa0')}, {v('wa0')}, {v('uns0')}
 v_or_b32 {v('wa1')}, {v('wa1')}, {v('uns1')}
-s_mov_b64 {sp('haveA')}, 0
+{'' if ZB else f"s_mov_b64 {sp('haveA')}, 0"}
 s_cmp_eq_u32 {s('hasA')}, 0
 s_cbranch_scc1 L_nofa
 s_cmp_eq_u32 {s('ua')}, 0
@@ -1359,13 +1367,18 @@ else:
 E(f"""
 v_or_b32 {v('wb0')}, {v('wb0')}, {v('uns0')}
 v_or_b32 {v('wb1')}, {v('wb1')}, {v('uns1')}
-s_mov_b64 {sp('haveB')}, 0
+{'' if ZB else f"s_mov_b64 {sp('haveB')}, 0"}
 s_cmp_eq_u32 {s('hasB')}, 0
 s_cbranch_scc1 L_nofb0
-// log-uniform of move i+1 (scalar load: only now that no screen pass is running on the LDS counter)
-s_add_u32 {st(0)}, {s('i')}, 1
-s_lshl_b32 {st(0)}, {st(0)}, 3
-s_load_dwordx2 {sp('nlu')}, {sp('uK')}, {st(0)}
+""")
+if not Z8:
+    E(f"""
+    // log-uniform of move i+1 (scalar load: only now that no screen pass is running on the LDS counter)
+    s_add_u32 {st(0)}, {s('i')}, 1
+    s_lshl_b32 {st(0)}, {st(0)}, 3
+    s_load_dwordx2 {sp('nlu')}, {sp('uK')}, {st(0)}
+    """)
+E(f"""
 s_cmp_eq_u32 {s('ub')}, 0
 s_cbranch_scc1 L_ub0
 """)
@@ -1592,6 +1605,8 @@ v_add_u32 {v('T')}, -1, {v('T')}
 v_max_i32 {v('T')}, 0, {v('T')}
 v_lshlrev_b32 {v('T')}, 3, {v('T')}
 s_add_u32 {st(1)}, {s('i')}, 1
+{f"s_lshl_b32 {st(0)}, {st(1)}, 3" if Z8 else ""}
+{f"s_load_dwordx2 {sp('lu')}, {sp('uK')}, {st(0)}" if Z8 else ""}
 s_mul_i32 {st(1)}, {st(1)}, 24
 v_add_u32 {v('S6')}, {st(1)}, {v('T')}
 // the side pair's source on lane 30: particle n where the move left it = p0[tl]
@@ -1626,7 +1641,7 @@ s_mul_i32 {st(0)}, {st(0)}, 24
 v_add_u32 {v('T',1)}, {st(0)}, {v('T')}
 ds_read_b64 {vp('D',0)}, {v('T',1)} offset:{LDS_P0}
 s_waitcnt vmcnt(0) lgkmcnt(0)
-s_mov_b64 {sp('lu')}, {sp('nlu')}
+{'' if Z8 else f"s_mov_b64 {sp('lu')}, {sp('nlu')}"}
 v_fma_f64 {vp('D',1)}, {vp('FmV')}, {sp('AoT')}, {vp('DdV')}
 v_add_f64 {vp('D',0)}, {vp('D',0)}, {vp('D',1)}
 // wrap x and y (rows 1, 2 = lanes 16..47), fixed point with 65536/L

@@ -144,34 +144,66 @@ __device__ inline unsigned spread8(unsigned v)
     return v;
 }
 
+// bitonic network over CELLS 32-bit keys, 256 threads x CELLS/256 keys: the compare-exchanges whose partner is
+// inside a thread's own 16 (CELLS = 4096) consecutive keys run in registers, the others through LDS
 template <int CELLS, bool ASCENDING_AT>
-__device__ inline void bitonic_lds(unsigned long long *key, int kmax)
+__device__ inline void bitonic_lds(unsigned *key, int kmax)
 {
-    for (int k = 2; k <= kmax; k <<= 1)
-        for (int j = k >> 1; j > 0; j >>= 1) {
+    constexpr int PT = CELLS / 256; // keys per thread (consecutive)
+    const int base = threadIdx.x * PT;
+    for (int k = 2; k <= kmax; k <<= 1) {
+        int j = k >> 1;
+        for (; j >= PT; j >>= 1) { // partner in another thread's keys
             for (int t = threadIdx.x; t < CELLS / 2; t += 256) {
-                const int i = 2 * t - (t & (j - 1)); // lower index of the pair (bit j clear)
+                const int i = 2 * t - (t & (j - 1));
                 const int q = i + j;
-                const unsigned long long a = key[i], b = key[q];
+                const unsigned a = key[i], b = key[q];
                 const bool up = ((i & k) == 0) || (ASCENDING_AT && k == kmax);
                 if ((a > b) == up) { key[i] = b; key[q] = a; }
             }
             __syncthreads();
         }
+        // j < PT: all partners inside this thread's PT keys
+        unsigned r[PT];
+#pragma unroll
+        for (int e = 0; e < PT; e++) r[e] = key[base + e];
+#pragma unroll
+        for (int jj = PT / 2; jj > 0; jj >>= 1) { // compile-time strides: r[] stays in registers
+            if (jj < k) {
+#pragma unroll
+                for (int e = 0; e < PT; e++) {
+                    if ((e & jj) == 0) {
+                        const int i = base + e;
+                        const bool up = ((i & k) == 0) || (ASCENDING_AT && k == kmax);
+                        const unsigned a = r[e], b = r[e | jj];
+                        const bool sw = (a > b) == up;
+                        r[e] = sw ? b : a; r[e | jj] = sw ? a : b;
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < PT; e++) key[base + e] = r[e];
+        __syncthreads();
+    }
 }
 
+// first keys: z in units of L/256 (what sweep_kernel_mc64 keeps the groups' z ranges in), biased to unsigned, above
+// the 12-bit particle index; second keys: group, Morton code of (x, y), particle
 template <int CELLS>
 __global__ void __launch_bounds__(256) zsort_kernel(const double *__restrict__ R, double *__restrict__ Rs,
                                                     unsigned short *__restrict__ loc, int N, double toFix)
 {
-    __shared__ unsigned long long key[CELLS];
+    static_assert(CELLS <= 4096, "12-bit particle index in the keys");
+    __shared__ unsigned key[CELLS];
     const double *Rr = R + (size_t)blockIdx.x * 3 * N;
+    const double zFix = toFix * (1.0 / 256.0); // 256 / L
     for (int n = threadIdx.x; n < CELLS; n += 256) {
-        unsigned long long k = ~0ull;
+        unsigned k = ~0u;
         if (n < N) {
-            unsigned u = __float_as_uint((float)Rr[3 * n + 2]);
-            u = (u & 0x80000000u) ? ~u : (u | 0x80000000u); // order of the floats as unsigned integers
-            k = ((unsigned long long)u << 32) | (unsigned)n;
+            int zq = (int)rint(Rr[3 * n + 2] * zFix);
+            zq = zq < -32767 ? -32767 : zq > 32767 ? 32767 : zq;
+            k = ((unsigned)(zq + 32768) << 12) | (unsigned)n;
         }
         key[n] = k;
     }
@@ -179,26 +211,26 @@ __global__ void __launch_bounds__(256) zsort_kernel(const double *__restrict__ R
     bitonic_lds<CELLS, false>(key, CELLS);
     const int full = N >> 8; // groups with 256 particles
     for (int p = threadIdx.x; p < CELLS; p += 256) {
-        const unsigned long long k = key[p];
-        if (k == ~0ull) continue;
-        const unsigned n = (unsigned)k;
-        unsigned sub = (unsigned)(p & 255); // a partial group keeps z order
+        const unsigned k = key[p];
+        if (k == ~0u) continue;
+        const unsigned n = k & 0xfffu;
+        unsigned sub = (unsigned)(p & 255) << 8; // a partial group keeps z order
         if ((p >> 8) < full) {
             const unsigned ix = ((unsigned)(int)rint(Rr[3 * n] * toFix) + 0x8000u) >> 8;     // 8 bits of the wrapped x
             const unsigned iy = ((unsigned)(int)rint(Rr[3 * n + 1] * toFix) + 0x8000u) >> 8;
             sub = spread8(ix) | (spread8(iy) << 1);
         }
-        key[p] = ((unsigned long long)(p >> 8) << 48) | ((unsigned long long)sub << 32) | n;
+        key[p] = ((unsigned)(p >> 8) << 28) | (sub << 12) | n;
     }
     __syncthreads();
     bitonic_lds<CELLS, true>(key, 256);
     for (int p = threadIdx.x; p < CELLS; p += 256) {
-        const unsigned long long k = key[p];
+        const unsigned k = key[p];
         const int g = p >> 8, r = p & 255;
         const int c = g < full ? (4 * g + (r >> 6)) * 64 + ((r + 16 * (g & 3)) & 63) : p;
         double *d = Rs + ((size_t)blockIdx.x * CELLS + c) * 3;
-        if (k != ~0ull) {
-            const unsigned n = (unsigned)k;
+        if (k != ~0u) {
+            const unsigned n = k & 0xfffu;
             loc[(size_t)blockIdx.x * N + n] = (unsigned short)c;
             d[0] = Rr[3 * n]; d[1] = Rr[3 * n + 1]; d[2] = Rr[3 * n + 2];
         } else {
