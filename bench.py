@@ -263,7 +263,9 @@ def main():
                                    "algorithmic_bytes_per_launch": algo_bytes_per_launch,
                                    "note": "SURVEY 8d: 24 B x pair-evals; positions are register/LDS-resident, so this "
                                            "exceeds the HBM peak and bounds nothing; measured HBM traffic is in roofline.traffic"},
-            "device_ms": {"sweep_kernels": sweep_ms, "whole_run": run_ms},
+            # whole_run - sweep_kernels = the helpers between the sweep launches: rand() pre-pass with Box-Muller,
+            # the z sort of the cells before every launch of sweep_kernel_mb64 / mc64, bookkeeping
+            "device_ms": {"sweep_kernels": sweep_ms, "whole_run": run_ms, "helpers": run_ms - sweep_ms},
             "observables": {"mean_acceptance": summ["mean_acceptance"], "mean_energy": summ["mean_of_meanE"],
                             "replicas_gathered": int(len(obs["accepted"]))},
         }
@@ -281,9 +283,11 @@ def main():
             base["traffic"] = rl["hbm_bytes_per_sweep_pmc"]["fetch_x2_plus_write"] * (a.steps / max(launches, 1))
         rl.update(base)
         out["roofline"] = rl
-        out["precision"] = ("every energy, force, acceptance test and position is fp64; the int16 (x,y) and "
-                            "fp16/fp32 (z) copies only pre-select pairs with a conservative, proven threshold "
-                            "(DESIGN 4.1b); every pair inside the cutoff is evaluated in fp64")
+        out["precision"] = ("every energy, force, acceptance test and position is fp64; the compact integer copies "
+                            "(sweep_kernel_mc64: int8 x, y and int16 z in units of L/256, one word per particle) only "
+                            "pre-select pairs with a conservative, proven threshold (DESIGN 4.1e; tests: CPU emulation "
+                            "of the screen and the fp64 all-cells diagnostic build); every pair inside the cutoff is "
+                            "evaluated in fp64")
         if world == 1 and kform == 2 and not a.no_cpu:
             # for reference, outside the timed region: the same workload through the all-fp64 sweep kernels
             try:
