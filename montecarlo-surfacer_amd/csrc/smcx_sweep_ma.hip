@@ -120,6 +120,31 @@ __global__ void __launch_bounds__(64, 4) sweep_kernel_mc64(MaArgs a)
         :
         : "memory", "vcc", "scc", "m0", SMCX_MA_SGPRS, SMCX_MA_V127);
 }
+#ifndef SMCX_CHECK
+// 32 and 16 particles per lane (1024 < N <= 2048, 512 < N <= 1024): 8 and 4 groups
+__global__ void __launch_bounds__(64, 5) sweep_kernel_mc32(MaArgs a)
+{
+    unsigned lane = threadIdx.x;
+    unsigned long long kp = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
+    unsigned rep = blockIdx.x;
+    asm volatile(
+#include "smcx_sweep_mc_body32.inc"
+        : "+v"(lane), "+s"(kp), "+s"(rep)
+        :
+        : "memory", "vcc", "scc", "m0", SMCX_MA_SGPRS, SMCX_MA_V95);
+}
+__global__ void __launch_bounds__(64, 6) sweep_kernel_mc16(MaArgs a)
+{
+    unsigned lane = threadIdx.x;
+    unsigned long long kp = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
+    unsigned rep = blockIdx.x;
+    asm volatile(
+#include "smcx_sweep_mc_body16.inc"
+        : "+v"(lane), "+s"(kp), "+s"(rep)
+        :
+        : "memory", "vcc", "scc", "m0", SMCX_MA_SGPRS, SMCX_MA_V79);
+}
+#endif
 #ifdef SMCX_CHECK
 constexpr unsigned mc_lds_bytes() { return 65u * 24u + 8u + 512u; }
 #else
@@ -271,7 +296,15 @@ bool mc_supported(int S, int WPR, int N, int M2, double L, double Lz, double cut
 #endif
     static const char *env = getenv("SMCX_MC");
     if (env && env[0] == '0') return false;
-    return mb_supported(S, WPR, N, M2) && mc_box_supported(L, Lz, cutoff2);
+    static const char *envb = getenv("SMCX_MB"); // SMCX_MB=0 switches both z-ordered forms off
+    if (envb && envb[0] == '0') return false;
+    return ma_supported(S, WPR, N, M2) && mc_box_supported(L, Lz, cutoff2);
+}
+
+// does this geometry / box run a kernel with z-ordered cells (and need Rs, loc)?
+bool zordered_supported(int S, int WPR, int N, int M2, double L, double Lz, double cutoff2)
+{
+    return mb_supported(S, WPR, N, M2) || mc_supported(S, WPR, N, M2, L, Lz, cutoff2);
 }
 
 void mc_bound(double L, double cutoff2, double *toFix, double *zsafe, int *negC, int *RZ);
@@ -319,7 +352,7 @@ hipError_t launch_sweeps_ma(const SweepArgs &s, const DevCtx &c, int S, const do
 #ifdef SMCX_CHECK
     a.dbg = s.dbg;
 #endif
-    if (mb_supported(S, 1, s.N, a.M2) && c.Rs && c.loc) {
+    if (zordered_supported(S, 1, s.N, a.M2, c.L, c.Lz, c.cutoff2) && c.Rs && c.loc) {
         // a slot is flagged only if dz^2 < ceil(C / 4^ZS) (dz in z units, C = -negC): the screen's reach in z
         const long T = ((long)(-negC) + 255) >> 8;
         a.RZ = (int)std::floor(std::sqrt((double)T)) + 1;
@@ -333,12 +366,23 @@ hipError_t launch_sweeps_ma(const SweepArgs &s, const DevCtx &c, int S, const do
         }
         static const int every = [] { const char *e = getenv("SMCX_RESORT"); int v = e ? atoi(e) : 1; return v > 0 ? v : 1; }();
         for (int sw = 0; sw < nsweeps; sw += every) {
-            hipLaunchKernelGGL(zsort_kernel<64 * 64>, dim3(c.nrep), dim3(256), 0, st, (const double *)s.R, c.Rs, c.loc, s.N, toFix);
+            if (S == 64)
+                hipLaunchKernelGGL(zsort_kernel<64 * 64>, dim3(c.nrep), dim3(256), 0, st, (const double *)s.R, c.Rs, c.loc, s.N, toFix);
+            else if (S == 32)
+                hipLaunchKernelGGL(zsort_kernel<32 * 64>, dim3(c.nrep), dim3(256), 0, st, (const double *)s.R, c.Rs, c.loc, s.N, toFix);
+            else
+                hipLaunchKernelGGL(zsort_kernel<16 * 64>, dim3(c.nrep), dim3(256), 0, st, (const double *)s.R, c.Rs, c.loc, s.N, toFix);
             a.sw0 = sw; a.nsweeps = nsweeps - sw < every ? nsweeps - sw : every;
             hipError_t rc = tm ? tm->mark(st) : hipSuccess;
             if (rc != hipSuccess) return rc;
-            if (mc)
+            if (mc && S == 64)
                 hipLaunchKernelGGL(sweep_kernel_mc64, dim3(c.nrep), dim3(64), mc_lds_bytes(), st, a);
+#ifndef SMCX_CHECK
+            else if (mc && S == 32)
+                hipLaunchKernelGGL(sweep_kernel_mc32, dim3(c.nrep), dim3(64), mc_lds_bytes(), st, a);
+            else if (mc)
+                hipLaunchKernelGGL(sweep_kernel_mc16, dim3(c.nrep), dim3(64), mc_lds_bytes(), st, a);
+#endif
             else
                 hipLaunchKernelGGL(sweep_kernel_mb64, dim3(c.nrep), dim3(64), mb_lds_bytes(64), st, a);
             rc = hipGetLastError();

@@ -608,7 +608,8 @@ bool mi_supported(int S, int WPR, double L, double Lz, double cutoff2)
 const char *mi_kernel_name(int S, int N, double L, double Lz, double cutoff2)
 {
     const int zs = mi_zshift(L, Lz);
-    if (zs == 4 && mc_supported(S, 1, N, 0, L, Lz, cutoff2)) return "smcx::sweep_kernel_mc64";
+    if (zs == 4 && mc_supported(S, 1, N, 0, L, Lz, cutoff2))
+        return S == 64 ? "smcx::sweep_kernel_mc64" : S == 32 ? "smcx::sweep_kernel_mc32" : "smcx::sweep_kernel_mc16";
     if (zs == 4 && ma_supported(S, 1, N, 0)) return ma_kernel_name(S, N);
 #define SMCX_MI(s, z, w) if (S == s && zs == z) return "smcx::sweep_kernel_mi<" #s ", " #z ", " #w ">";
     SMCX_MI_TABLE(SMCX_MI)
