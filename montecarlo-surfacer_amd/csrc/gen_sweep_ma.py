@@ -29,6 +29,7 @@ Hazards are padded by the rules hipcc applies on gfx950 (read off its output): 2
 VALU write of an SGPR/VCC and a VALU read of it, 1 before v_readlane / v_readfirstlane of a fresh VGPR,
 2 before DPP or v_permlane*_swap of a fresh VGPR, 1 after v_rcp_f64, 3 after v_dot2 (met by the interleave).
 """
+import os
 import re
 import sys
 
@@ -57,6 +58,9 @@ ZBC = MODE == "zbc"                                       # diagnostic: every pa
 # probe, no z words in LDS).  The byte-wise squares alias |dz| >= 128 units; such cells are far outside the
 # cutoff, cost at most a wasted evaluation, and the group ranges keep them out of the passes anyway.
 # "z8c": its diagnostic build: the fp64 cutoff test of every cell beside every pass, counting unflagged pairs.
+PRIO = True                                               # rotate the wavefronts' issue priority (zb kernels)
+PRIO_MODE = os.environ.get("SMCX_GEN_PRIO_MODE", "rotate")
+PRIO_SHIFT = int(os.environ.get("SMCX_GEN_PRIO_SHIFT", "14"))   # ... every 2^14 ticks of the 100 MHz clock (164 us)
 Z8C = MODE == "z8c"
 Z8 = Z8C or MODE == "z8"
 ZB = ZBC or Z8 or MODE == "zb"
@@ -120,7 +124,7 @@ ONE_HI = "0x3ff00000"
 # kernarg layout (struct MaArgs in smcx_sweep_ma.hip)
 K_R, K_DISPL, K_UNI, K_OFFS, K_OBS, K_REC, K_WTAB, K_CLK = 0x0, 0x8, 0x10, 0x18, 0x20, 0x28, 0x30, 0x38
 K_CONST16, K_CONST8, K_INTS, K_M2 = 0x40, 0x80, 0xa0, 0xb0
-K_RZ, K_RS, K_LOC, K_SW0, K_DBG = 0xb4, 0xb8, 0xc0, 0xc8, 0xd0   # zb
+K_RZ, K_RS, K_LOC, K_SW0, K_DBG, K_PRIO = 0xb4, 0xb8, 0xc0, 0xc8, 0xd0, 0xd8   # zb
 
 # ---------------------------------------------------------------------------------------------- prologue
 E(f"""
@@ -459,6 +463,79 @@ def fill_p0(tag):
     s_mov_b64 exec, -1
     s_waitcnt lgkmcnt(0)
     """)
+    if ZB and PRIO:
+        # The SIMD's arbiter favours the oldest of its four wavefronts: left alone, one replica runs at nearly the
+        # lone-wave rate and finishes after 7 ms while the youngest needs 13 and runs the last third of its sweep
+        # alone on the SIMD.  So at every row (64 moves) a wavefront publishes its progress in a table row shared
+        # by the wavefronts of its SIMD (index from HW_ID / XCC_ID) and takes as its issue priority the number of
+        # its neighbours that are AHEAD of it.  Only speed depends on this table, never a result.
+        E(f"""
+        s_load_dwordx2 {stp(4)}, {KARG}, {K_PRIO}
+        s_getreg_b32 {st(0)}, hwreg(HW_REG_HW_ID)
+        s_getreg_b32 {st(1)}, hwreg(HW_REG_XCC_ID, 0, 4)
+        s_bfe_u32 {st(2)}, {st(0)}, 0x70008
+        s_lshl_b32 {st(2)}, {st(2)}, 4
+        s_bfe_u32 {st(3)}, {st(0)}, 0x20004
+        s_lshl_b32 {st(3)}, {st(3)}, 2
+        s_or_b32 {st(2)}, {st(2)}, {st(3)}
+        s_lshl_b32 {st(1)}, {st(1)}, 11
+        s_or_b32 {st(2)}, {st(2)}, {st(1)}
+        s_lshl_b32 {st(2)}, {st(2)}, 2
+        s_and_b32 {st(3)}, {st(0)}, 3
+        // key = (moves done: sweep index of the chunk x N + moves of this sweep) << 2 | slot
+        s_lshl_b32 {st(6)}, {s('rot')}, 6
+        s_sub_u32 {st(7)}, {s('N')}, {s('len')}
+        s_sub_u32 {st(0)}, 0, {s('first')}
+        s_cmp_eq_u32 {s('run')}, 0
+        s_cselect_b32 {st(7)}, {st(0)}, {st(7)}
+        s_add_u32 {st(6)}, {st(6)}, {st(7)}
+        s_mul_i32 {st(7)}, {s('sw')}, {s('N')}
+        s_add_u32 {st(6)}, {st(6)}, {st(7)}
+        s_lshl_b32 {st(6)}, {st(6)}, 2
+        s_or_b32 {st(6)}, {st(6)}, {st(3)}
+        s_lshl_b32 {st(3)}, {st(3)}, 2
+        s_add_u32 {st(3)}, {st(3)}, {st(2)}
+        v_mov_b32 v14, {st(2)}
+        v_mov_b32 v15, {st(6)}
+        v_mov_b32 v16, {st(3)}
+        s_mov_b64 exec, 1
+        s_waitcnt lgkmcnt(0)
+        global_store_dword v16, v15, {stp(4)} sc0 sc1
+        global_load_dwordx4 v[20:23], v14, {stp(4)} sc0 sc1
+        s_waitcnt vmcnt(0)
+        v_readfirstlane_b32 {st(0)}, v20
+        v_readfirstlane_b32 {st(1)}, v21
+        v_readfirstlane_b32 {st(2)}, v22
+        v_readfirstlane_b32 {st(3)}, v23
+        s_mov_b64 exec, -1
+        s_mov_b32 {st(7)}, 0
+        s_cmp_gt_u32 {st(0)}, {st(6)}
+        s_addc_u32 {st(7)}, {st(7)}, 0
+        s_cmp_gt_u32 {st(1)}, {st(6)}
+        s_addc_u32 {st(7)}, {st(7)}, 0
+        s_cmp_gt_u32 {st(2)}, {st(6)}
+        s_addc_u32 {st(7)}, {st(7)}, 0
+        s_cmp_gt_u32 {st(3)}, {st(6)}
+        s_addc_u32 {st(7)}, {st(7)}, 0
+        s_min_u32 {st(7)}, {st(7)}, 3
+        s_cmp_eq_u32 {st(7)}, 0
+        s_cbranch_scc1 L_pr0_{tag}
+        s_cmp_eq_u32 {st(7)}, 1
+        s_cbranch_scc1 L_pr1_{tag}
+        s_cmp_eq_u32 {st(7)}, 2
+        s_cbranch_scc1 L_pr2_{tag}
+        s_setprio 3
+        s_branch L_pre_{tag}
+        L_pr0_{tag}:
+        s_setprio 0
+        s_branch L_pre_{tag}
+        L_pr1_{tag}:
+        s_setprio 1
+        s_branch L_pre_{tag}
+        L_pr2_{tag}:
+        s_setprio 2
+        L_pre_{tag}:
+        """)
 
 
 def rotate(tag):

@@ -241,7 +241,7 @@ extern "C" int smcx_destroy(smcx_handle *hh)
     hipFree(c.uni); hipFree(c.offs); hipFree(c.obs); hipFree(c.zhist); hipFree(c.Eseries);
     hipFree(c.jjseries); hipFree(c.rec); hipFree(h.d_save); hipFree(h.d_tmp);
     hipFree(c.D); hipFree(c.Mu); hipFree(c.Rbin); hipFree(c.Pseries);
-    hipFree(h.lca_bits); hipFree(h.lca_counts); hipFree(c.clk); hipFree((void *)c.wtab); hipFree(c.Rs); hipFree(c.loc);
+    hipFree(h.lca_bits); hipFree(h.lca_counts); hipFree(c.clk); hipFree((void *)c.wtab); hipFree(c.Rs); hipFree(c.loc); hipFree(c.prio);
 #ifdef SMCX_CHECK
     hipFree(c.dbg);
 #endif
@@ -310,6 +310,8 @@ extern "C" int smcx_create(const smcx_params *p, smcx_handle **out)
         // cell-ordered copy of the positions and the cell of each particle (sweep_kernel_mb64 / mc*)
         CRT(hipMalloc(&c.Rs, nrep * (size_t)h.S * 64 * 3 * sizeof(double)));
         CRT(hipMalloc(&c.loc, nrep * N * sizeof(unsigned short)));
+        CRT(hipMalloc(&c.prio, 16384 * sizeof(unsigned)));
+        CRT(hipMemset(c.prio, 0, 16384 * sizeof(unsigned)));
     }
     CRT(hipMalloc(&h.d_save, nrep * sizeof(double)));
     CRT(hipMalloc(&h.d_tmp, nrep * sizeof(double)));
@@ -634,6 +636,38 @@ extern "C" int smcx_last_clock(smcx_handle *hh, double *ghz, double *wave_cycles
     std::nth_element(cyc.begin(), cyc.begin() + cyc.size() / 2, cyc.end());
     if (ghz) *ghz = f[f.size() / 2];
     if (wave_cycles) *wave_cycles = cyc[cyc.size() / 2];
+    return SMCX_OK;
+}
+
+// spread of the wavefronts' lifetimes in the last sweep launch (100 MHz counter, microseconds): min, median, max,
+// and the span from the first start to the last end
+extern "C" int smcx_debug_wave_spread(smcx_handle *hh, double *out4)
+{
+    if (!hh || !out4) return SMCX_ERR_PARAM;
+    Handle &h = hh->h;
+    if (!h.c.clk) return SMCX_ERR_STATE;
+    HIPCHK(&h, hipSetDevice(h.p.device));
+    std::vector<unsigned long long> st((size_t)h.p.nrep * 4);
+    HIPCHK(&h, hipMemcpy(st.data(), h.c.clk, st.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    std::vector<double> d;
+    unsigned long long t0 = ~0ull, t1 = 0;
+    for (int r = 0; r < h.p.nrep; r++)
+        if (st[4 * r + 3] > st[4 * r + 1]) {
+            d.push_back((double)(st[4 * r + 3] - st[4 * r + 1]) * 0.01);
+            t0 = std::min(t0, st[4 * r + 1]); t1 = std::max(t1, st[4 * r + 3]);
+        }
+    if (d.empty()) return SMCX_ERR_STATE;
+    std::sort(d.begin(), d.end());
+    out4[0] = d.front(); out4[1] = d[d.size() / 2]; out4[2] = d.back(); out4[3] = (double)(t1 - t0) * 0.01;
+    if (getenv("SMCX_SPREAD_DUMP")) { // lifetime percentiles, and the lifetimes in replica order (which replicas are slow?)
+        for (int q : {1, 5, 10, 25, 50, 75, 90, 95, 99}) fprintf(stderr, "p%d %.0f  ", q, d[d.size() * q / 100]);
+        fprintf(stderr, "\n");
+        for (int r = 0; r < h.p.nrep; r += h.p.nrep / 64) fprintf(stderr, "%.0f ", (double)(st[4 * r + 3] - st[4 * r + 1]) * 0.01);
+        fprintf(stderr, "\n");
+        for (int r = 0; r < h.p.nrep; r += h.p.nrep / 64) // shader clock seen by the same wavefronts, MHz
+            fprintf(stderr, "%.0f ", (double)(st[4 * r + 2] - st[4 * r]) / (double)(st[4 * r + 3] - st[4 * r + 1]) * 100.0);
+        fprintf(stderr, "\n");
+    }
     return SMCX_OK;
 }
 

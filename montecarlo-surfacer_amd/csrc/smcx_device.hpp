@@ -75,6 +75,7 @@ struct DevCtx {
     const double *wtab;           // [M2 + 1][4] wall table of sweep_kernel_ma: site x, y, W[2m], W[2m+1]; plane last
     double *Rs;                   // [nrep][4096][3] sweep_kernel_mb: positions in cell (z-sorted) order, or null
     unsigned short *loc;          // [nrep][N] sweep_kernel_mb: cell of each particle, or null
+    unsigned *prio;               // [16384] sweep_kernel_mb/mc: progress of the wavefronts of each SIMD (issue priorities)
 #ifdef SMCX_CHECK
     unsigned long long *dbg;      // [4] diagnostic build only (see SweepArgs)
 #endif

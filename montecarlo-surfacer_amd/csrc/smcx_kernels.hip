@@ -42,6 +42,7 @@ rng_prepass_kernel(DevCtx c, int nsweeps, double A)
     int left = uniform((int)c.rng[rep * 32 + 31]);
 
     for (int s = 0; s < nsweeps; s++) {
+#ifndef SMCX_PREPASS_NOGEN
         if (wave == 0) {
             const uint32_t carry = __shfl(hist, 31 - left + lane, 64);
             if (lane < left) raw[lane] = carry >> 1;
@@ -53,6 +54,7 @@ rng_prepass_kernel(DevCtx c, int nsweeps, double A)
             }
             left = have - D;
         }
+#endif
         __syncthreads();
         double *displ = c.displ + ((size_t)rep * c.chunk + s) * 3 * N;
         double *uni = c.uni + ((size_t)rep * c.chunk + s) * N;
@@ -60,8 +62,12 @@ rng_prepass_kernel(DevCtx c, int nsweeps, double A)
         for (int p = tid; p < (3 * N) / 2; p += 256) {
             const double x1 = (double)raw[2 * p] * (1.0 / 2147483648.0);
             const double x2 = (double)raw[2 * p + 1] * (1.0 / 2147483648.0);
+#ifdef SMCX_PREPASS_NOBM
+            displ[2 * p] = sigma * x1; displ[2 * p + 1] = sigma * x2;
+#else
             displ[2 * p] = sigma * sqrt(-2.0 * log(1.0 - x1)) * cos(2.0 * M_PI * x2);
             displ[2 * p + 1] = sigma * sqrt(-2.0 * log(1.0 - x2)) * sin(2.0 * M_PI * x1);
+#endif
         }
         // acceptance uniforms u = rand()/RAND_MAX (SMC.c:335), stored as log(u): the test
         // u < exp(-x/T) of SMC.c:329-335 is evaluated as log(u) < -x/T, which keeps the

@@ -28,7 +28,7 @@ struct MaArgs {
     const unsigned short *loc;                                // 0xc0  mb: cell of each particle [nrep][N]
     int sw0, pad0;                                            // 0xc8  mb: first sweep of this launch within the chunk
     unsigned long long *dbg;                                  // 0xd0  diagnostic build: the screen's counters
-    unsigned long long pad1;
+    unsigned *prio;                                           // 0xd8  mb/mc: progress table of the SIMDs' wavefronts [16384]
 };
 static_assert(sizeof(MaArgs) == 0xe0, "offsets are hard-wired in gen_sweep_ma.py");
 
@@ -348,7 +348,7 @@ hipError_t launch_sweeps_ma(const SweepArgs &s, const DevCtx &c, int S, const do
     a.zsafe = zsafe; a.halfLz = c.halfLz; a.Lz = c.Lz; a.invLz = c.invLz;
     a.N = s.N; a.chunk = s.chunk; a.nsweeps = nsweeps; a.negC = negC;
     a.M2 = (c.flags & 0x1u) ? c.M2 : -1;
-    a.RZ = 0; a.Rs = nullptr; a.loc = nullptr; a.sw0 = 0; a.pad0 = 0; a.dbg = nullptr; a.pad1 = 0;
+    a.RZ = 0; a.Rs = nullptr; a.loc = nullptr; a.sw0 = 0; a.pad0 = 0; a.dbg = nullptr; a.prio = c.prio;
 #ifdef SMCX_CHECK
     a.dbg = s.dbg;
 #endif
