@@ -190,6 +190,11 @@ int smcx_last_kernel_ms(smcx_handle *h, double *ms, int *launches);
 /* the shader clock the LAST sweep kernel launch ran at, measured in the kernel (s_memtime over
  * s_memrealtime, median over the replicas' wavefronts), and a wavefront's lifetime in shader cycles */
 int smcx_last_clock(smcx_handle *h, double *ghz, double *wave_cycles);
+/* diagnostics: lifetimes of the wavefronts of the LAST sweep kernel launch in microseconds (100 MHz counter read
+ * by every wavefront at its first and last instruction): out4 = min, median, max over the replicas, and the span
+ * from the first start to the last end.  With four wavefronts per SIMD the kernel lasts as long as its slowest
+ * wavefront; sweep_kernel_mb64 / mc* steer their issue priorities so that all finish together. */
+int smcx_debug_wave_spread(smcx_handle *h, double *out4);
 /* device time of the whole last smcx_run (RNG pre-pass and bookkeeping kernels included) */
 int smcx_last_run_ms(smcx_handle *h, double *ms);
 /* the launch geometry chosen for this handle */

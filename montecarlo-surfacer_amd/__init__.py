@@ -58,7 +58,7 @@ EXPORTS = [
     "smcx_export_observables_device", "smcx_last_kernel_ms", "smcx_last_run_ms", "smcx_geometry", "smcx_eval_moves",
     "smcx_rng_seed", "smcx_one_particle_moves",
     "smcx_cluster_counts", "smcx_cluster_update", "smcx_cluster_analysis", "smcx_kernel_form", "smcx_screen_bound",
-    "smcx_screen_bound_int", "smcx_screen_bound_byte", "smcx_last_clock",
+    "smcx_screen_bound_int", "smcx_screen_bound_byte", "smcx_last_clock", "smcx_debug_wave_spread",
 ]
 
 
@@ -101,6 +101,7 @@ def _lib():
         L.smcx_last_kernel_ms.argtypes = [vp, _dp, C.POINTER(C.c_int)]
         L.smcx_last_run_ms.argtypes = [vp, _dp]
         L.smcx_last_clock.argtypes = [vp, _dp, _dp]
+        L.smcx_debug_wave_spread.argtypes = [vp, _dp]
         L.smcx_geometry.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.smcx_kernel_form.argtypes = [vp, C.POINTER(C.c_int), C.c_char_p, C.c_int]
         L.smcx_screen_bound.argtypes = [C.POINTER(Params), C.c_int, _dp, _dp, _dp, _dp]
@@ -373,6 +374,12 @@ class Engine:
         g, c = C.c_double(), C.c_double()
         self._chk(_lib().smcx_last_clock(self._h, C.byref(g), C.byref(c)), "smcx_last_clock")
         return g.value, c.value
+
+    def wave_spread(self):
+        """(min, median, max, span) of the wavefront lifetimes of the last sweep launch, microseconds"""
+        out = (C.c_double * 4)()
+        self._chk(_lib().smcx_debug_wave_spread(self._h, out), "smcx_debug_wave_spread")
+        return tuple(out)
 
     def last_kernel_ms(self):
         ms, n = C.c_double(), C.c_int()

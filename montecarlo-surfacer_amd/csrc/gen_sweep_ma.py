@@ -1,33 +1,45 @@
 #!/usr/bin/env python3
-"""gen_sweep_ma.py -- writes smcx_sweep_ma_body.inc: the body of sweep_kernel_ma, the hand-scheduled
-gfx950 form of the screened sweep kernel for ONE wavefront per replica with 64 particles per lane
-(2048 < N <= 4096, the benchmark geometry).  Same algorithm and the same arithmetic per pair as
-sweep_kernel_mi (smcx_sweep_mi.hip: integer screen, fp64 decision and evaluation of every candidate,
-SMC.c:278-351); what changes is that every instruction, register and wait is chosen here instead of
-by hipcc, whose output for that kernel issues ~1600 instructions per move (SGPR spills to VGPR
-lanes, mask bookkeeping, copies around the one-SGPR-per-instruction limit) where ~1100 do the work --
-and on this chip a wavefront's time is its instruction count (four waves per SIMD issue
-one instruction per ~3.7 cycles whatever its kind).
+"""gen_sweep_ma.py OUT.inc [NS [MODE]] -- writes the body of one hand-scheduled gfx950 sweep kernel (one
+`asm volatile` statement of smcx_sweep_ma.hip): ONE wavefront per replica with NS = 64, 32 or 16 particles
+per lane (32 NS < N <= 64 NS).  Same algorithm and the same arithmetic per pair as sweep_kernel_mi
+(smcx_sweep_mi.hip: integer screen, fp64 decision and evaluation of every candidate, SMC.c:278-351); every
+instruction, register and wait is chosen here instead of by hipcc -- on this chip a wavefront's time is its
+instruction count.
 
-A move (iteration i of a run; particle n = first + i sits in register slot 0 of lane tl):
-  B-COPY  probe B = current position of particle n+1: compact copy by v_readlane from its owner lane
-  SCREEN  16 groups of 4 slots x 2 probes, 44 instructions each, z words read two groups ahead
+MODE  kernel                what differs
+ ""   sweep_kernel_ma<NS>   particle l in lane l % 64, slot l / 64 (rotated so that the moving particle is in slot 0);
+                            packed int16 x,y in registers, int16 z in LDS; every slot screened, 5.5 instr per slot+probe
+ zb   sweep_kernel_mb64     cells in z order (zsort_kernel: Rs, loc); a probe screens only the 4-slot groups whose z
+                            range can reach it (computed jump into the unrolled pass); specials on free lanes;
+                            issue priority from the progress of the SIMD's other wavefronts
+ zbc  (diagnostic of zb)    every ranged pass followed by the full pass; counts the bits the ranged one lacks
+ z8   sweep_kernel_mc<NS>   zb with ONE word per cell (int16 z | int8 x | int8 y, units of L/256), screened by
+                            v_sub_u32 + v_dot4_i32_i8 + v_alignbit_b32; no z words in LDS -- the benchmark's kernel
+ z8c  (diagnostic of z8)    the fp64 cutoff test of every cell beside every pass; counts unflagged pairs
+
+A move (iteration i of a run; particle n = first + i; ma: in register slot 0 of lane tl; zb/z8: in cell locA):
+  B-COPY  probe B = current position of particle n+1: compact copy by v_readlane (ma: from its owner lane; zb: from
+          the row registers rxy/rzl, filled with the row cache every 64 moves)
+  SCREEN  ma: 16 groups of 4 slots x 2 probes, 44 instructions each, z words read two groups ahead;
+          zb/z8: the groups in z reach only, 22 / 12 instructions per group and probe
   FIX     unsafe / exclusion bits; the first candidate of either probe picked, its fp64 position asked for
-  PROBE A wall sites + plane (lanes 0..M2; position and coefficients from a 32-byte table row per lane),
-          candidates; ONE fp64 body; reduce4 leaves e, fx, fy, fz in the four 16-lane rows of one register
+  PROBE A wall sites + plane (ma: lanes 0..M2; zb: the first lanes without a candidate; position and coefficients from
+          a 32-byte table row per lane), candidates; ONE fp64 body; reduce4 leaves e, fx, fy, fz in the four 16-lane
+          rows of one register
   MET     Metropolis step in "row layout": row 0 carries the energies, rows 1-3 the x, y, z components, so
           g = Fn - Fm, h = Fn + Fm and dX = Fm A/T + displ are one instruction each and
           arg = sum over rows of  h (dX/2 + A/(4T) g)   [= dX.(Fn+Fm)/2 + deltaW: g.g + 2 g.Fm = g.h]
                 plus 4 (eA - eB) from row 0            [= Un - Um, exactly]
-  PROBE B the same body + the pair with particle n where the move left it (LDS cache p0[tl]) on lane 30;
+  PROBE B the same body + the pair with particle n where the move left it (LDS cache p0[tl]) on the side lane;
           its result vector FmV stays in a register for the next move
   NEXT    proposal of particle n+1 in row layout: q = p0[.] + (FmV A/T + displ) per row, wrap of rows 1-2,
           fixed-point copies by one v_mul / v_rndne / v_cvt for all three coordinates
-Registers: v64..v127 = the 64 packed x,y of this lane; everything else v0..v63; s0..s95 named below;
-the inline-asm operands (lane id, kernarg pointer, block id) live in v0 and s96+.
+Registers: v64..v(63+NS) = the cells of this lane (packed x,y / one word); everything else v0..v63; s0..s95 named
+below; the inline-asm operands (lane id, kernarg pointer, block id) live in v0 and s96+.
 Hazards are padded by the rules hipcc applies on gfx950 (read off its output): 2 wait states between a
 VALU write of an SGPR/VCC and a VALU read of it, 1 before v_readlane / v_readfirstlane of a fresh VGPR,
-2 before DPP or v_permlane*_swap of a fresh VGPR, 1 after v_rcp_f64, 3 after v_dot2 (met by the interleave).
+2 before DPP or v_permlane*_swap of a fresh VGPR, 1 after v_rcp_f64, 3 after v_dot2 / v_dot4 (met by the interleave).
+Generator switches for experiments: SMCX_GEN_PRIO_MODE=static (priority = wave slot), SMCX_GEN_PRIO_SHIFT.
 """
 import os
 import re

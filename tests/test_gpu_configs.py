@@ -324,6 +324,20 @@ def test_byte_screen_kernel_misses_no_pair_inside_the_cutoff(tmp_path, N, lat, n
     assert d["cand"] < 3 * d["inside"] + 40 * moves
 
 
+def test_wavefronts_of_a_launch_finish_together(S):
+    """bench workload, sweep_kernel_mc64: 4096 wavefronts start together, four per SIMD.  Without the priority
+    table the arbiter serves the oldest wavefront of a SIMD first and the lifetimes of one launch
+    span 7.3 .. 13.2 ms (the launch lasts as long as the slowest).  With it: within 8 % of the median."""
+    p = S.default_params(4096, 4096)
+    with S.Engine(p) as eng:
+        assert eng.kernel_form[1] == "smcx::sweep_kernel_mc64"
+        eng.upload(S.fcc_init(8, 16), S.W_REFERENCE)
+        eng.run(0, 2, 10)
+        lo, med, hi, span = eng.wave_spread()
+    print("wavefront lifetimes of the last launch: %.0f .. %.0f us (median %.0f), launch span %.0f" % (lo, hi, med, span))
+    assert hi - lo < 0.08 * med and span < 1.05 * med
+
+
 # ------------------------------------------------------------------ statistics beyond the chaos horizon
 @pytest.mark.parametrize("N,lat", [(256, (4, 4)), (1024, (8, 4))])
 def test_ensemble_statistics_beyond_chaos_horizon(S, O, N, lat):

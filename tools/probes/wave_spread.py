@@ -10,10 +10,7 @@ eng = S.Engine(p); print(eng.kernel_form, flush=True)
 eng.upload(S.fcc_init(8, 16), S.W_REFERENCE)
 for k in range(3):
     eng.run(0, 4, 10)
-    out = (C.c_double * 4)()
-    f = S._lib().smcx_debug_wave_spread
-    f.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
-    assert f(eng._h, out) == 0
+    out = eng.wave_spread()
     ms, n = eng.last_kernel_ms()
     print("wave lifetime us: min %.0f median %.0f max %.0f ; first start to last end %.0f ; HIP events %.0f per launch" %
           (out[0], out[1], out[2], out[3], ms * 1e3 / n), flush=True)
