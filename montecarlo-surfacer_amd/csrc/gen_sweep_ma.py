@@ -1143,6 +1143,24 @@ def wall_dz(tag, pz_is_sgpr, pz):
         src = vp('wdz')
     else:
         src = pz
+    if ZB:
+        E(f"""
+        v_add_f64 {vp('T')}, {src}, {sp('halfLz')}
+        v_cmp_ge_f64 vcc, |{src}|, {sp('halfLz')}
+        v_mul_f64 {vp('S6')}, {vp('T')}, {sp('invLz')}
+        v_rndne_f64 {vp('S6')}, {vp('S6')}
+        v_fma_f64 {vp('wdz')}, -{vp('S6')}, {sp('Lz')}, {vp('T')}
+        s_cbranch_vccz L_wdz_{tag}
+        // at or beyond a wall: +1e-4 below the lower one, -1e-4 above the upper one (T = pz + Lz/2 <= 0: the lower)
+        v_cmp_ge_f64 {stp(0)}, 0, {vp('T')}
+        v_mov_b32 {v('wdz')}, 0xeb1c432d
+        v_mov_b32 {v('T')}, 0xbf1a36e2
+        v_mov_b32 {v('T',1)}, 0x3f1a36e2
+        s_nop 0
+        v_cndmask_b32 {v('wdz',1)}, {v('T')}, {v('T',1)}, {stp(0)}
+        L_wdz_{tag}:
+        """)
+        return
     E(f"""
     v_add_f64 {vp('T')}, {src}, {sp('halfLz')}
     v_cmp_le_f64 {stp(0)}, {src}, -{sp('halfLz')}
@@ -1320,7 +1338,7 @@ def assign_specials(tag, w0, w1, X, C, wl, pl, with_side, have):
     need = st(6) if with_side else st(3)
     E(f"""
     v_cmp_ne_u64 {have}, 0, v[{w0}:{w1}]
-    s_add_u32 {st(3)}, {s('M2')}, 1
+    {f"s_mov_b32 {st(3)}, {s('az16')}" if False else f"s_add_u32 {st(3)}, {s('M2')}, 1"}
     s_not_b64 {stp(0)}, {have}
     s_bcnt1_i32_b64 {st(2)}, {stp(0)}
     {f"s_add_u32 {st(6)}, {st(3)}, {s('hasA')}" if with_side else ""}
@@ -1542,7 +1560,7 @@ L_nofb:
 E(f"s_cmp_eq_u32 {s('hasA')}, 0")
 E("s_cbranch_scc1 L_noA")
 QP = [sp('Q', 0), sp('Q', 1), sp('Q', 2)]
-probe("A", QP, True, (s('Q', 4), s('Q', 5)), V['wa0'], V['wa1'], XA_, CA_, sp('haveA'), False, "s_nop 0")
+probe("A", QP, True, (s('Q', 4), s('Q', 5)), V['wa0'], V['wa1'], XA_, CA_, sp('haveA'), False, "" if ZB else "s_nop 0")
 FnV = vp('M', 0)          # v[36:37]: the body's M registers are free now
 reduce4(FnV)
 E(f"""
@@ -1558,26 +1576,49 @@ v_mul_f64 {vp('D',2)}, {vp('D',2)}, {vp('D',1)}
 {"" if ZB else f"s_mov_b64 exec, {stp(0)}"}
 v_mul_f64 {vp('D',2)}, {vp('D',0)}, 4.0
 s_mov_b64 exec, -1
-// sum over the four rows: lanes ^32, then rows ^1
-v_mov_b32 {v('T')}, {v('D',4)}
-v_mov_b32 {v('T',1)}, {v('D',5)}
-s_nop 1
-v_permlane32_swap_b32 {v('D',4)}, {v('T')}
-v_permlane32_swap_b32 {v('D',5)}, {v('T',1)}
-s_nop 0
-v_add_f64 {vp('D',2)}, {vp('D',2)}, {vp('T')}
-s_nop 0
-v_mov_b32 {v('T')}, {v('D',4)}
-v_mov_b32 {v('T',1)}, {v('D',5)}
-s_nop 1
-v_permlane16_swap_b32 {v('D',4)}, {v('T')}
-v_permlane16_swap_b32 {v('D',5)}, {v('T',1)}
-s_nop 0
-v_add_f64 {vp('D',2)}, {vp('D',2)}, {vp('T')}
-v_mul_f64 {vp('D',2)}, {vp('D',2)}, -{sp('invT')}
-v_cmp_lt_f64 vcc, {sp('lu')}, {vp('D',2)}
-{"s_cbranch_vccz L_reject" if ZB else "s_cmp_lg_u64 vcc, 0"}
-{"" if ZB else "s_cbranch_scc0 L_reject"}
+""")
+if ZB:
+    # sum over the four rows into row 3 with the row broadcasts of DPP (the rows are uniform after reduce4):
+    # rows 1, 3 += lane 15 of rows 0, 2; then rows 2, 3 += lane 31; the decision is row 3's
+    E(f"""
+    v_mov_b32 {v('T')}, 0
+    v_mov_b32 {v('T',1)}, 0
+    v_mov_b32_dpp {v('T')}, {v('D',4)} row_bcast:15 row_mask:0xa bank_mask:0xf
+    v_mov_b32_dpp {v('T',1)}, {v('D',5)} row_bcast:15 row_mask:0xa bank_mask:0xf
+    v_add_f64 {vp('D',2)}, {vp('D',2)}, {vp('T')}
+    s_nop 1
+    v_mov_b32_dpp {v('T')}, {v('D',4)} row_bcast:31 row_mask:0xc bank_mask:0xf
+    v_mov_b32_dpp {v('T',1)}, {v('D',5)} row_bcast:31 row_mask:0xc bank_mask:0xf
+    v_add_f64 {vp('D',2)}, {vp('D',2)}, {vp('T')}
+    v_mul_f64 {vp('D',2)}, {vp('D',2)}, -{sp('invT')}
+    v_cmp_lt_f64 vcc, {sp('lu')}, {vp('D',2)}
+    s_bitcmp1_b32 vcc_hi, 31
+    s_cbranch_scc0 L_reject
+    """)
+else:
+    E(f"""
+    // sum over the four rows: lanes ^32, then rows ^1
+    v_mov_b32 {v('T')}, {v('D',4)}
+    v_mov_b32 {v('T',1)}, {v('D',5)}
+    s_nop 1
+    v_permlane32_swap_b32 {v('D',4)}, {v('T')}
+    v_permlane32_swap_b32 {v('D',5)}, {v('T',1)}
+    s_nop 0
+    v_add_f64 {vp('D',2)}, {vp('D',2)}, {vp('T')}
+    s_nop 0
+    v_mov_b32 {v('T')}, {v('D',4)}
+    v_mov_b32 {v('T',1)}, {v('D',5)}
+    s_nop 1
+    v_permlane16_swap_b32 {v('D',4)}, {v('T')}
+    v_permlane16_swap_b32 {v('D',5)}, {v('T',1)}
+    s_nop 0
+    v_add_f64 {vp('D',2)}, {vp('D',2)}, {vp('T')}
+    v_mul_f64 {vp('D',2)}, {vp('D',2)}, -{sp('invT')}
+    v_cmp_lt_f64 vcc, {sp('lu')}, {vp('D',2)}
+    s_cmp_lg_u64 vcc, 0
+    s_cbranch_scc0 L_reject
+    """)
+E(f"""
 // accepted: E += Un - Um = 4 (eA - eB) (row 0 of g), particle n takes the proposal
 v_readlane_b32 {st(0)}, {v('D',0)}, 0
 v_readlane_b32 {st(1)}, {v('D',1)}, 0
