@@ -1364,12 +1364,13 @@ def assign_specials(tag, w0, w1, X, C, wl, pl, with_side, have):
     v_lshl_add_u64 v[46:47], v[{w0}:{w1}], 0, -1
     v_or_b32 v45, 32, v45
     v_min_u32 v44, v44, v45
-    v_and_b32 v{w0}, v{w0}, v46
-    v_and_b32 v{w1}, v{w1}, v47
     v_lshl_or_b32 v44, v44, 6, {LANE}
     v_mul_u32_u24 v45, 24, v44
     v_lshlrev_b32 v49, 5, v48
+    // only the lanes that evaluate their candidate now take it out of w (the fixed-lane fallback keeps some waiting)
     s_mov_b64 exec, {have}
+    v_and_b32 v{w0}, v{w0}, v46
+    v_and_b32 v{w1}, v{w1}, v47
     global_load_dwordx4 v[{X}:{X+3}], v45, {SRC}
     global_load_dwordx2 v[{X+4}:{X+5}], v45, {SRC} offset:16
     s_mov_b64 exec, -1

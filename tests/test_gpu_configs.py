@@ -306,14 +306,16 @@ def test_ranged_screen_sets_every_bit_of_the_full_screen(tmp_path, N, lat, nrep,
     assert d["cand"] > moves and d["acc"] > 0
 
 
-@pytest.mark.parametrize("N,lat,nrep,nsw,gl", [(4096, (8, 16), 64, 4, 2), (4000, (10, 10), 32, 3, 1), (2100, (5, 21), 32, 3, 3)])
+@pytest.mark.parametrize("N,lat,nrep,nsw,gl", [(4096, (8, 16), 64, 4, 2), (4000, (10, 10), 32, 3, 1), (2100, (5, 21), 32, 3, 3),
+                                                (4096, (16, 4), 16, 2, 1)])
 def test_byte_screen_kernel_misses_no_pair_inside_the_cutoff(tmp_path, N, lat, nrep, nsw, gl):
     """sweep_kernel_mc64 (the benchmark's kernel): one word per cell screened by v_dot4_i32_i8, only the groups in
     z reach.  Its diagnostic build (SMCX_CHECK_MB=2) runs, beside EVERY pass, the fp64 cutoff test with the
     minimum image of SMC.c:567-578 on EVERY cell from the fp64 positions in memory and counts the pairs inside
     the cutoff whose bit the pass did not set (the moving particle and the probe's own particle excepted, as
     in the reference's loop): must be zero; the counts of true pairs and of candidate bits show the check is not
-    vacuous and how tight the screen is (the byte units flag about 1.5x the cutoff sphere)."""
+    vacuous and how tight the screen is (the byte units flag about 1.5x the cutoff sphere).  Last case: the dense
+    film fcc(16,4), ~60 pairs inside the cutoff per probe."""
     d = _run_check_worker(tmp_path, "2", N, lat, nrep, nsw, gl)
     moves = nrep * nsw * N
     print("N=%d: %d moves, %d pairs inside the cutoff, %d candidate bits (%.2fx), %d missed" %

@@ -594,6 +594,50 @@ def test_screened_kernel_matches_fp64_kernel(S, O, N, lat, L, slots, waves, nsw,
     assert np.array_equal(za, zb)
 
 
+@pytest.mark.parametrize("case", ["dense_film", "ragged_no_walls", "thin_film_all_groups"])
+def test_byte_screen_kernel_corner_cases_against_fp64_kernel(S, O, case):
+    """sweep_kernel_mc64 (z-ordered cells, one word per cell) against the all-fp64 kernels where its rare paths run:
+    a dense film (fcc(16,4) in L = 33: ~60 candidates per probe, so fewer lanes without a candidate than wall sites
+    -> the fixed-lane fallback for the specials, several evaluation rounds, every group in z reach); no walls with a
+    ragged N (empty cells at the end of the z order) and part of the film moved far up (two separated slabs: most
+    groups out of reach of every probe; z beyond the int16 of the cells cannot be uploaded in a box this kernel
+    serves: |z| <= 4 Lz < 32766 L/256); a film thinner than the
+    cutoff (fcc(24,1) in L = 48, the widest box whose L/256 resolves the cutoff in 16 units: all 9 groups in reach of
+    every probe, both flag words used)."""
+    rs = np.random.RandomState(7)
+    flags = S.FLAGS_REFERENCE | S.FLAG_SERIES
+    N, L, nsw = 4096, 33.0, 2
+    if case == "dense_film":
+        R0 = O.fcc(16, 4, L=L).reshape(-1, 3).copy()
+    elif case == "ragged_no_walls":
+        N = 4000
+        R0 = O.fcc(8, 16, L=L).reshape(-1, 3)[:N].copy()
+        flags = S.FLAG_E0_RESTART | S.FLAG_SERIES
+    else:
+        N, L = 2304, 48.0
+        R0 = O.fcc(24, 1, L=L).reshape(-1, 3).copy()
+    R0 += 0.05 * rs.standard_normal(R0.shape)
+    R0[:, 0] -= L * np.rint(R0[:, 0] / L); R0[:, 1] -= L * np.rint(R0[:, 1] / L)
+    if case == "ragged_no_walls":
+        R0[R0[:, 2] > 6.0, 2] += 700.0
+        assert (R0[:, 2] > 690).sum() > 100 and (np.abs(R0[:, 2]) < 100).sum() > 100
+    out = []
+    for kernel, (slots, waves) in ((1, (0, 0)), (2, (64, 1))):
+        p = S.default_params(N, 3, L=L, tune_slots=slots, tune_waves=waves, tune_kernel=kernel, flags=flags)
+        with S.Engine(p) as eng:
+            if kernel == 2:
+                assert eng.kernel_form[1] == "smcx::sweep_kernel_mc64", eng.kernel_form
+            eng.upload(R0.ravel(), O.W_FIXTURE)
+            eng.run(1, nsw, 1)
+            E, jj = eng.series(nsw)
+            out.append((eng.positions().copy(), E.copy(), jj.copy(), eng.observables()["zhist"].copy()))
+    (Ra, Ea, ja, za), (Rb, Eb, jb, zb) = out
+    assert np.array_equal(ja, jb) and ja.sum() > 0
+    assert np.all(np.abs(Ea - Eb) <= 1e-9 * (1.0 + np.abs(Ea))), np.abs(Ea - Eb).max()
+    assert np.abs(Ra - Rb).max() < 1e-8
+    assert np.array_equal(za, zb)
+
+
 def film_state(O, Na, Nz, L, jitter, seed):
     """a dense fcc film (nearest neighbours inside LCA_cutoff) with thermal jitter"""
     rs = np.random.RandomState(seed)
