@@ -638,6 +638,35 @@ def test_byte_screen_kernel_corner_cases_against_fp64_kernel(S, O, case):
     assert np.array_equal(za, zb)
 
 
+@pytest.mark.parametrize("M,N,lat,slots", [(1, 4096, (8, 16), 64), (2, 4096, (8, 16), 64), (5, 4096, (8, 16), 64),
+                                          (2, 1024, (8, 4), 16), (5, 2048, (8, 8), 32)])
+def test_wall_grids_other_than_3x3_against_oracle(S, O, M, N, lat, slots):
+    """the hand-scheduled kernels give the M^2 wall sites and the plane to the first lanes without a candidate
+    (their rank = row of the wall table): M = 1, 2, 5 (2, 5 and 26 special lanes) against the oracle, with the film
+    pushed against the lower wall so that the sites act on it (SMC.c:729-813)."""
+    rs = np.random.RandomState(M)
+    R0 = O.fcc(*lat).reshape(-1, 3).copy()
+    R0[:, 2] += -118.5 - R0[:, 2].min()
+    W = np.empty(2 * M * M)
+    W[0::2] = rs.uniform(800.0, 1050.0, M * M); W[1::2] = rs.uniform(50.0, 62.0, M * M)
+    nsw, nrep = 2, 2
+    p = S.default_params(N, nrep, M=M, flags=S.FLAGS_REFERENCE | S.FLAG_SERIES, tune_slots=slots, tune_waves=1)
+    with S.Engine(p) as eng:
+        assert eng.kernel_form[1] == "smcx::sweep_kernel_mc%d" % slots, eng.kernel_form
+        eng.upload(R0.ravel(), W)
+        eng.run(0, nsw, 1)
+        Es, jj = eng.series(nsw)
+        Rg = eng.positions()
+    s = sys_of(O, p)
+    for r in range(nrep):
+        ref = O.chain(s, 12345 + r, R0.ravel(), W, T, A, 0, nsw, 1)
+        assert np.array_equal(jj[r], ref["jj"]) and ref["jj"].sum() > 0
+        assert np.all(rel(Es[r], ref["E"], scale=1.0) < 1e-9), (Es[r], ref["E"])
+        assert np.abs(Rg[r] - ref["R"]).max() < 1e-8
+    # the walls matter in this state: without them the first sweep's energy differs
+    assert abs(ref["E"][0]) > 0
+
+
 def film_state(O, Na, Nz, L, jitter, seed):
     """a dense fcc film (nearest neighbours inside LCA_cutoff) with thermal jitter"""
     rs = np.random.RandomState(seed)
