@@ -667,6 +667,35 @@ def test_wall_grids_other_than_3x3_against_oracle(S, O, M, N, lat, slots):
     assert abs(ref["E"][0]) > 0
 
 
+def test_int16_z_ordered_kernel_unsafe_particles_against_fp64_kernel(S, O):
+    """a box whose L/256 does not resolve the cutoff (L = 60) runs sweep_kernel_mb64 (int16 x,y in registers, int16 z
+    in LDS, cells in z order).  No walls and the upper part of the film moved beyond the int16 z range (zsafe = 479):
+    those particles are always candidates, a proposal there flags all real cells of a ragged N, and the groups'
+    z ranges hold clamped values -- against the all-fp64 kernels."""
+    rs = np.random.RandomState(11)
+    N, L, nsw = 4000, 60.0, 2
+    R0 = O.fcc(10, 10, L=L).reshape(-1, 3)[:N].copy()
+    R0 += 0.05 * rs.standard_normal(R0.shape)
+    R0[:, 0] -= L * np.rint(R0[:, 0] / L); R0[:, 1] -= L * np.rint(R0[:, 1] / L)
+    R0[R0[:, 2] > 6.0, 2] += 600.0
+    assert (R0[:, 2] > 480).sum() > 100 and (np.abs(R0[:, 2]) < 100).sum() > 100
+    out = []
+    for kernel, (slots, waves) in ((1, (0, 0)), (2, (64, 1))):
+        p = S.default_params(N, 3, L=L, tune_slots=slots, tune_waves=waves, tune_kernel=kernel,
+                             flags=S.FLAG_E0_RESTART | S.FLAG_SERIES)
+        with S.Engine(p) as eng:
+            if kernel == 2:
+                assert eng.kernel_form[1] == "smcx::sweep_kernel_mb64", eng.kernel_form
+            eng.upload(R0.ravel(), O.W_FIXTURE)
+            eng.run(1, nsw, 1)
+            E, jj = eng.series(nsw)
+            out.append((eng.positions().copy(), E.copy(), jj.copy()))
+    (Ra, Ea, ja), (Rb, Eb, jb) = out
+    assert np.array_equal(ja, jb) and ja.sum() > 0
+    assert np.all(np.abs(Ea - Eb) <= 1e-9 * (1.0 + np.abs(Ea))), np.abs(Ea - Eb).max()
+    assert np.abs(Ra - Rb).max() < 1e-8
+
+
 def film_state(O, Na, Nz, L, jitter, seed):
     """a dense fcc film (nearest neighbours inside LCA_cutoff) with thermal jitter"""
     rs = np.random.RandomState(seed)
