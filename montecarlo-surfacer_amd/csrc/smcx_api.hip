@@ -92,6 +92,24 @@ static void seed_state(uint32_t seed, uint32_t out[32])
 
 extern "C" void smcx_rng_seed(uint32_t *rng, uint32_t seed) { seed_state(seed, rng); }
 
+// the rand() state (31 words, oldest first) advanced by Q blocks of 31 outputs, as a matrix over Z/2^32 stored by
+// columns: out[k * 31 + j] = coefficient of old word k in new word j.  One block: new[j] = old[j] + (j < 3 ?
+// old[j + 28] : new[j - 3])  (r[i] = r[i-31] + r[i-3]); rng_prepass_kernel's waves start a multiple of Q apart.
+static void rng_jump_matrix(int Q, std::vector<uint32_t> &out)
+{
+    out.assign(31 * 31, 0u);
+    for (int k = 0; k < 31; k++) {
+        uint32_t v[31] = {0};
+        v[k] = 1u;
+        for (int b = 0; b < Q; b++) {
+            uint32_t n[31];
+            for (int j = 0; j < 31; j++) n[j] = v[j] + (j < 3 ? v[j + 28] : n[j - 3]);
+            std::memcpy(v, n, sizeof(v));
+        }
+        for (int j = 0; j < 31; j++) out[k * 31 + j] = v[j];
+    }
+}
+
 extern "C" void smcx_default_params(smcx_params *p, int32_t N, int32_t nrep)
 {
     std::memset(p, 0, sizeof(*p));
@@ -237,7 +255,7 @@ extern "C" int smcx_destroy(smcx_handle *hh)
     Handle &h = hh->h;
     hipSetDevice(h.p.device);
     DevCtx &c = h.c;
-    hipFree(c.R); hipFree((void *)c.W); hipFree(c.rng); hipFree(c.raw); hipFree(c.displ);
+    hipFree(c.R); hipFree((void *)c.W); hipFree(c.rng); hipFree(c.raw); hipFree((void *)c.rngJump); hipFree(c.displ);
     hipFree(c.uni); hipFree(c.offs); hipFree(c.obs); hipFree(c.zhist); hipFree(c.Eseries);
     hipFree(c.jjseries); hipFree(c.rec); hipFree(h.d_save); hipFree(h.d_tmp);
     hipFree(c.D); hipFree(c.Mu); hipFree(c.Rbin); hipFree(c.Pseries);
@@ -297,6 +315,13 @@ extern "C" int smcx_create(const smcx_params *p, smcx_handle **out)
     CRT(hipMalloc((void **)&c.W, (size_t)(2 * c.M2 + 2) * sizeof(double))); // + a0, b0 of the plane (sweep_kernel_mi)
     CRT(hipMalloc(&c.rng, nrep * 32 * sizeof(uint32_t)));
     CRT(hipMalloc(&c.raw, nrep * (size_t)c.rawStride * sizeof(uint32_t)));
+    {   // quarter of the blocks of 31 rand() outputs a sweep consumes at most (4N + 1 outputs)
+        c.rngQ = (int)(((4L * p->N + 1 + 30) / 31 + 3) / 4);
+        std::vector<uint32_t> J;
+        rng_jump_matrix(c.rngQ, J);
+        CRT(hipMalloc((void **)&c.rngJump, J.size() * sizeof(uint32_t)));
+        CRT(hipMemcpy((void *)c.rngJump, J.data(), J.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    }
     CRT(hipMalloc(&c.displ, nrep * h.chunk * 3 * N * sizeof(double)));
     CRT(hipMalloc(&c.uni, nrep * h.chunk * N * sizeof(double)));
     CRT(hipMalloc(&c.offs, nrep * h.chunk * sizeof(int)));

@@ -64,6 +64,8 @@ struct DevCtx {
     double *Eseries;              // [nrep][series_stride] or null
     int *jjseries;                // [nrep][series_stride] or null
     long rawStride;
+    const uint32_t *rngJump;      // [31][31] column-major: the rand() state advanced by rngQ blocks of 31 outputs, as a
+    int rngQ;                     //          linear map over Z/2^32 (the four waves of the pre-pass start a quarter apart)
     SweepRec *rec;                // [nrep][chunk] per-sweep records of the last sweep launch
     // optional observables (SMCX_FLAG_FULL_HIST / SMCX_FLAG_PRESSURE), null when off
     unsigned long long *D;        // [nrep][Ncx*Ncx*Ncz] cell occupancy   (SMC.c:921)

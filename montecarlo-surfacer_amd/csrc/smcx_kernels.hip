@@ -36,24 +36,45 @@ rng_prepass_kernel(DevCtx c, int nsweeps, double A)
     uint32_t *raw = c.raw + (size_t)rep * c.rawStride;
     const double sigma = sqrt(2.0 * A); // SMC.c:284
 
-    // lane j < 31 of wave 0 holds state word r[i-31+j]; `left` outputs at the top of
-    // the last generated block of 31 have not been consumed yet
-    uint32_t hist = (lane < 31) ? c.rng[rep * 32 + lane] : 0u;
+    // rand() is r[i] = r[i-31] + r[i-3] mod 2^32 (a linear map of the 31-word state), consumed D at a time.  The
+    // four waves generate a quarter of a sweep's blocks of 31 each: wave w starts from the state advanced by
+    // w * rngQ blocks (rngJump applied w times, 31 x 31 multiply-adds each), wave 3 ends with the sweep's final
+    // state and hands it to the others through LDS.
+    // lane j < 31 holds state word r[i-31+j]; `left` outputs at the top of the last generated block of the
+    // previous sweep have not been consumed yet
+    __shared__ uint32_t sh_hist[32];
+    uint32_t hist0 = (lane < 31) ? c.rng[rep * 32 + lane] : 0u;
     int left = uniform((int)c.rng[rep * 32 + 31]);
+    const int Q = c.rngQ;
 
     for (int s = 0; s < nsweeps; s++) {
 #ifndef SMCX_PREPASS_NOGEN
         if (wave == 0) {
-            const uint32_t carry = __shfl(hist, 31 - left + lane, 64);
+            const uint32_t carry = __shfl(hist0, 31 - left + lane, 64);
             if (lane < left) raw[lane] = carry >> 1;
-            int have = left;
-            while (have < D) {
-                hist = rand_block(hist, lane);
-                if (lane < 31) raw[have + lane] = hist >> 1;
-                have += 31;
-            }
-            left = have - D;
         }
+        const int B = (D - left + 30) / 31;             // blocks this sweep
+        const bool par = 3 * Q < B;                      // (a few particles only: wave 0 generates everything)
+        uint32_t hist = hist0;
+        for (int w = 0; par && w < wave; w++) {          // hist <- rngJump . hist
+            uint32_t acc = 0;
+#pragma unroll
+            for (int k = 0; k < 31; k++) {
+                const uint32_t hk = __shfl(hist, k, 64);
+                acc += ((lane < 31) ? c.rngJump[k * 31 + lane] : 0u) * hk;
+            }
+            hist = acc;
+        }
+        const int b0 = par ? wave * Q : (wave == 0 ? 0 : B);
+        const int b1 = par ? (wave == 3 ? B : (wave + 1) * Q) : B;
+        for (int b = b0; b < b1; b++) {
+            hist = rand_block(hist, lane);
+            if (lane < 31) raw[left + 31 * b + lane] = hist >> 1;
+        }
+        if (wave == (par ? 3 : 0) && lane < 31) sh_hist[lane] = hist;
+        left = left + 31 * B - D;
+        __syncthreads();
+        hist0 = (lane < 31) ? sh_hist[lane] : 0u;
 #endif
         __syncthreads();
         double *displ = c.displ + ((size_t)rep * c.chunk + s) * 3 * N;
@@ -83,7 +104,7 @@ rng_prepass_kernel(DevCtx c, int nsweeps, double A)
         __syncthreads();
     }
     if (wave == 0) {
-        if (lane < 31) c.rng[rep * 32 + lane] = hist;
+        if (lane < 31) c.rng[rep * 32 + lane] = hist0;
         if (lane == 31) c.rng[rep * 32 + 31] = (uint32_t)left;
     }
 }
