@@ -212,7 +212,11 @@ static int choose_geometry(const smcx_params *p, int *S, int *WPR)
         s = pow2_at_least((p->N + 63) / 64); w = 1;
         if (s < 16) s = 16;
         while (s > 64) { s /= 2; w *= 2; }
-        while ((long)p->nrep * w < 2048 && s > 16 && w < 8 && geometry_supported(s / 2, w * 2)) { s /= 2; w *= 2; }
+        // one wavefront per replica has hand-scheduled kernels (sweep_kernel_mc*/mb64/ma*) that beat any split over
+        // several wavefronts even with few replicas (N = 2048: 3.1-3.6 ms per sweep against 5.2-9.0 for 16 x 2 at
+        // 128..1024 replicas, tools/probes/geom_rule.py); the split stays for boxes those kernels do not serve
+        const bool one_wave = (w == 1) && mi_supported(s, 1, p->L, p->Lz, p->cutoff * p->cutoff);
+        while (!one_wave && (long)p->nrep * w < 2048 && s > 16 && w < 8 && geometry_supported(s / 2, w * 2)) { s /= 2; w *= 2; }
     } else {
         if (p->N <= 1024) { s = pow2_at_least((p->N + 63) / 64); w = 1; }
         else {
