@@ -1508,8 +1508,10 @@ if ZB:
     excl(v('wb0'), v('wb1'), s('locA'))
     E(f"""
     L_fb1:
-    // probe A's data has had the whole second pass to arrive; B's travels while probe A is evaluated
-    s_waitcnt vmcnt(0)
+    // B's four loads (candidate x2, wall row x2) are asked for without waiting for probe A's: probe A's body waits
+    // with vmcnt(4) -- its own data, issued first, complete first.  (The diagnostic build's all-cells test drains
+    // the counter itself.)
+    {"s_waitcnt vmcnt(0)" if (ZBC or Z8C) else ""}
     """)
 else:
     E(f"""
@@ -1561,7 +1563,8 @@ L_nofb:
 E(f"s_cmp_eq_u32 {s('hasA')}, 0")
 E("s_cbranch_scc1 L_noA")
 QP = [sp('Q', 0), sp('Q', 1), sp('Q', 2)]
-probe("A", QP, True, (s('Q', 4), s('Q', 5)), V['wa0'], V['wa1'], XA_, CA_, sp('haveA'), False, "" if ZB else "s_nop 0")
+probe("A", QP, True, (s('Q', 4), s('Q', 5)), V['wa0'], V['wa1'], XA_, CA_, sp('haveA'), False,
+      ("" if (ZBC or Z8C) else "s_waitcnt vmcnt(4)") if ZB else "s_nop 0")
 FnV = vp('M', 0)          # v[36:37]: the body's M registers are free now
 reduce4(FnV)
 E(f"""
