@@ -169,17 +169,17 @@ __device__ inline unsigned spread8(unsigned v)
     return v;
 }
 
-// bitonic network over CELLS 32-bit keys, 256 threads x CELLS/256 keys: the compare-exchanges whose partner is
-// inside a thread's own 16 (CELLS = 4096) consecutive keys run in registers, the others through LDS
-template <int CELLS, bool ASCENDING_AT>
+// bitonic network over CELLS 32-bit keys, TPB threads x CELLS/TPB keys: the compare-exchanges whose partner is
+// inside a thread's own consecutive keys run in registers, the others through LDS
+template <int CELLS, int TPB, bool ASCENDING_AT>
 __device__ inline void bitonic_lds(unsigned *key, int kmax)
 {
-    constexpr int PT = CELLS / 256; // keys per thread (consecutive)
+    constexpr int PT = CELLS / TPB; // keys per thread (consecutive)
     const int base = threadIdx.x * PT;
     for (int k = 2; k <= kmax; k <<= 1) {
         int j = k >> 1;
         for (; j >= PT; j >>= 1) { // partner in another thread's keys
-            for (int t = threadIdx.x; t < CELLS / 2; t += 256) {
+            for (int t = threadIdx.x; t < CELLS / 2; t += TPB) {
                 const int i = 2 * t - (t & (j - 1));
                 const int q = i + j;
                 const unsigned a = key[i], b = key[q];
@@ -215,15 +215,15 @@ __device__ inline void bitonic_lds(unsigned *key, int kmax)
 
 // first keys: z in units of L/256 (what sweep_kernel_mc64 keeps the groups' z ranges in), biased to unsigned, above
 // the 12-bit particle index; second keys: group, Morton code of (x, y), particle
-template <int CELLS>
-__global__ void __launch_bounds__(256) zsort_kernel(const double *__restrict__ R, double *__restrict__ Rs,
+template <int CELLS, int TPB>
+__global__ void __launch_bounds__(TPB) zsort_kernel(const double *__restrict__ R, double *__restrict__ Rs,
                                                     unsigned short *__restrict__ loc, int N, double toFix)
 {
     static_assert(CELLS <= 4096, "12-bit particle index in the keys");
     __shared__ unsigned key[CELLS];
     const double *Rr = R + (size_t)blockIdx.x * 3 * N;
     const double zFix = toFix * (1.0 / 256.0); // 256 / L
-    for (int n = threadIdx.x; n < CELLS; n += 256) {
+    for (int n = threadIdx.x; n < CELLS; n += TPB) {
         unsigned k = ~0u;
         if (n < N) {
             int zq = (int)rint(Rr[3 * n + 2] * zFix);
@@ -233,9 +233,9 @@ __global__ void __launch_bounds__(256) zsort_kernel(const double *__restrict__ R
         key[n] = k;
     }
     __syncthreads();
-    bitonic_lds<CELLS, false>(key, CELLS);
+    bitonic_lds<CELLS, TPB, false>(key, CELLS);
     const int full = N >> 8; // groups with 256 particles
-    for (int p = threadIdx.x; p < CELLS; p += 256) {
+    for (int p = threadIdx.x; p < CELLS; p += TPB) {
         const unsigned k = key[p];
         if (k == ~0u) continue;
         const unsigned n = k & 0xfffu;
@@ -248,8 +248,8 @@ __global__ void __launch_bounds__(256) zsort_kernel(const double *__restrict__ R
         key[p] = ((unsigned)(p >> 8) << 28) | (sub << 12) | n;
     }
     __syncthreads();
-    bitonic_lds<CELLS, true>(key, 256);
-    for (int p = threadIdx.x; p < CELLS; p += 256) {
+    bitonic_lds<CELLS, TPB, true>(key, 256);
+    for (int p = threadIdx.x; p < CELLS; p += TPB) {
         const unsigned k = key[p];
         const int g = p >> 8, r = p & 255;
         const int c = g < full ? (4 * g + (r >> 6)) * 64 + ((r + 16 * (g & 3)) & 63) : p;
@@ -366,12 +366,15 @@ hipError_t launch_sweeps_ma(const SweepArgs &s, const DevCtx &c, int S, const do
         }
         static const int every = [] { const char *e = getenv("SMCX_RESORT"); int v = e ? atoi(e) : 1; return v > 0 ? v : 1; }();
         for (int sw = 0; sw < nsweeps; sw += every) {
-            if (S == 64)
-                hipLaunchKernelGGL(zsort_kernel<64 * 64>, dim3(c.nrep), dim3(256), 0, st, (const double *)s.R, c.Rs, c.loc, s.N, toFix);
-            else if (S == 32)
-                hipLaunchKernelGGL(zsort_kernel<32 * 64>, dim3(c.nrep), dim3(256), 0, st, (const double *)s.R, c.Rs, c.loc, s.N, toFix);
-            else
-                hipLaunchKernelGGL(zsort_kernel<16 * 64>, dim3(c.nrep), dim3(256), 0, st, (const double *)s.R, c.Rs, c.loc, s.N, toFix);
+            static const int tpb = [] { const char *e = getenv("SMCX_ZSORT_TPB"); return e ? atoi(e) : 512; }(); // 512 threads (8 keys each) measured best of 128..1024 for 4096 cells
+#define SMCX_ZSORT(C, T) hipLaunchKernelGGL((zsort_kernel<C, T>), dim3(c.nrep), dim3(T), 0, st, (const double *)s.R, c.Rs, c.loc, s.N, toFix)
+            if (S == 64 && tpb == 128) SMCX_ZSORT(64 * 64, 128);
+            else if (S == 64 && tpb == 256) SMCX_ZSORT(64 * 64, 256);
+            else if (S == 64 && tpb == 1024) SMCX_ZSORT(64 * 64, 1024);
+            else if (S == 64) SMCX_ZSORT(64 * 64, 512);
+            else if (S == 32) SMCX_ZSORT(32 * 64, 256);
+            else SMCX_ZSORT(16 * 64, 256);
+#undef SMCX_ZSORT
             a.sw0 = sw; a.nsweeps = nsweeps - sw < every ? nsweeps - sw : every;
             hipError_t rc = tm ? tm->mark(st) : hipSuccess;
             if (rc != hipSuccess) return rc;
