@@ -1338,7 +1338,7 @@ def assign_specials(tag, w0, w1, X, C, wl, pl, with_side, have):
     need = st(6) if with_side else st(3)
     E(f"""
     v_cmp_ne_u64 {have}, 0, v[{w0}:{w1}]
-    {f"s_mov_b32 {st(3)}, {s('az16')}" if False else f"s_add_u32 {st(3)}, {s('M2')}, 1"}
+    s_add_u32 {st(3)}, {s('M2')}, 1
     s_not_b64 {stp(0)}, {have}
     s_bcnt1_i32_b64 {st(2)}, {stp(0)}
     {f"s_add_u32 {st(6)}, {st(3)}, {s('hasA')}" if with_side else ""}

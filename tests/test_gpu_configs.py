@@ -209,6 +209,31 @@ def test_hand_scheduled_kernel_matches_compiled_kernel(S, O, tmp_path, N, lat, n
         assert np.abs(out[tag]["R"] - out["mi"]["R"]).max() < 1e-8, tag
 
 
+def test_benchmark_kernel_ensemble_statistics_beyond_chaos_horizon(S, O, tmp_path):
+    """sweep_kernel_mc64 against sweep_kernel_mi (hipcc-compiled, every slot screened) on the benchmark's system, 256
+    replicas x 60 sweeps: the chains separate after ~10 sweeps (chaos), so the realised energies differ; the ensemble
+    means of the final energy and of the accepted moves must agree within 4 standard errors of their difference.
+    A bias from a rare path of the z-ordered kernel (group ranges, lane assignment, issue priorities are all
+    configuration dependent) would accumulate here."""
+    w = tmp_path / "mi_worker.py"
+    w.write_text(_MI_WORKER)
+    out = {}
+    for tag, env in (("mc", {}), ("mi", {"SMCX_MA": "0"})):
+        f = str(tmp_path / (tag + ".npz"))
+        r = subprocess.run([sys.executable, str(w), ROOT, f, "4096", "8", "16", "256", "60", "64"],
+                           env=dict(os.environ, **env), capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        out[tag] = np.load(f)
+    assert str(out["mc"]["name"]) == "smcx::sweep_kernel_mc64" and "sweep_kernel_mi" in str(out["mi"]["name"])
+    for what, a, b in (("final energy", out["mc"]["E"][:, -1], out["mi"]["E"][:, -1]),
+                       ("accepted moves", out["mc"]["jj"].sum(axis=1).astype(float), out["mi"]["jj"].sum(axis=1).astype(float))):
+        se = np.sqrt(a.var(ddof=1) / len(a) + b.var(ddof=1) / len(b))
+        print("%s: %.4f vs %.4f (difference %.2f standard errors)" % (what, a.mean(), b.mean(), (a.mean() - b.mean()) / se))
+        assert abs(a.mean() - b.mean()) < 4 * se, what
+    # and they did separate: identical trajectories would make the comparison vacuous
+    assert (out["mc"]["jj"] != out["mi"]["jj"]).any()
+
+
 def _load_check_build():
     path = os.path.join(ROOT, "montecarlo-surfacer_amd", "libsmcx_check.so")
     if not os.path.exists(path):
