@@ -48,7 +48,7 @@ rng_prepass_kernel(DevCtx c, int nsweeps, double A)
     const int Q = c.rngQ;
 
     for (int s = 0; s < nsweeps; s++) {
-#ifndef SMCX_PREPASS_NOGEN
+#ifndef SMCX_PREPASS_NOGEN // (measurement builds: make VARIANT=nogen EXTRA=-DSMCX_PREPASS_NOGEN, likewise _NOBM)
         if (wave == 0) {
             const uint32_t carry = __shfl(hist0, 31 - left + lane, 64);
             if (lane < left) raw[lane] = carry >> 1;
