@@ -155,7 +155,7 @@ constexpr unsigned mc_lds_bytes() { return 65u * 24u; }
 //  1. the particles of a replica sorted by z (bitonic sort of (float z, particle) keys in LDS): group g holds
 //     ranks 256 g .. 256 g + 255, so its z range is as narrow as the configuration allows;
 //  2. inside every full group, sorted along a Morton curve in (x, y) and dealt to the lanes round-robin, the deal
-//     of group g starting at lane 16 (g mod 4): the candidates of one probe are close in (x, y) and spread over
+//     of group g starting at lane 25 g mod 64: the candidates of one probe are close in (x, y) and spread over
 //     three or four consecutive groups, so they land in different lanes and the kernel needs one evaluation
 //     round per probe instead of one per candidate of the fullest lane.
 // Written as Rs[cell] = position and loc[particle] = cell; a partial last group keeps z order, so the cells beyond N
@@ -215,6 +215,10 @@ __device__ inline void bitonic_lds(unsigned *key, int kmax)
 
 // first keys: z in units of L/256 (what sweep_kernel_mc64 keeps the groups' z ranges in), biased to unsigned, above
 // the 12-bit particle index; second keys: group, Morton code of (x, y), particle
+#ifndef ZSORT_DEAL
+#define ZSORT_DEAL 25 // lane where the deal of group g starts = 25 g mod 64 (64 / golden ratio^2: the starts of any few consecutive
+                      // groups stay far apart); measured 9..39: 25..29 best, 16 (g mod 4) +1.7 %, 13 +2.5 %, 9 +4 %
+#endif
 template <int CELLS, int TPB>
 __global__ void __launch_bounds__(TPB) zsort_kernel(const double *__restrict__ R, double *__restrict__ Rs,
                                                     unsigned short *__restrict__ loc, int N, double toFix)
@@ -252,7 +256,7 @@ __global__ void __launch_bounds__(TPB) zsort_kernel(const double *__restrict__ R
     for (int p = threadIdx.x; p < CELLS; p += TPB) {
         const unsigned k = key[p];
         const int g = p >> 8, r = p & 255;
-        const int c = g < full ? (4 * g + (r >> 6)) * 64 + ((r + 16 * (g & 3)) & 63) : p;
+        const int c = g < full ? (4 * g + (r >> 6)) * 64 + ((r + ZSORT_DEAL * g) & 63) : p;
         double *d = Rs + ((size_t)blockIdx.x * CELLS + c) * 3;
         if (k != ~0u) {
             const unsigned n = k & 0xfffu;
