@@ -209,6 +209,27 @@ def test_hand_scheduled_kernel_matches_compiled_kernel(S, O, tmp_path, N, lat, n
         assert np.abs(out[tag]["R"] - out["mi"]["R"]).max() < 1e-8, tag
 
 
+def test_several_sweeps_per_launch_between_sorts(S, O, tmp_path):
+    """SMCX_RESORT=3: the z sort runs every third sweep and the sweep kernel loops over the sweeps of a launch itself
+    (group ranges widened by three sweeps of moves, energy carried in a register, per-sweep records): same chains
+    as with a sort before every sweep, to rounding (the cells differ, so the sums associate differently)."""
+    w = tmp_path / "mi_worker.py"
+    w.write_text(_MI_WORKER)
+    out = {}
+    for tag, env in (("every", {}), ("third", {"SMCX_RESORT": "3"})):
+        f = str(tmp_path / (tag + ".npz"))
+        r = subprocess.run([sys.executable, str(w), ROOT, f, "4096", "8", "16", "64", "7", "64"],
+                           env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        out[tag] = np.load(f)
+    assert str(out["third"]["name"]) == "smcx::sweep_kernel_mc64"
+    k = 4
+    assert np.array_equal(out["every"]["jj"][:, :k], out["third"]["jj"][:, :k]) and out["every"]["jj"].sum() > 0
+    dE = np.abs(out["every"]["E"][:, :k + 1] - out["third"]["E"][:, :k + 1])
+    assert np.all(dE <= 1e-9 * (1.0 + np.abs(out["every"]["E"][:, :k + 1]))), dE.max()
+    assert np.abs(out["every"]["E"] - out["third"]["E"]).max() < 1e-3
+
+
 def test_benchmark_kernel_ensemble_statistics_beyond_chaos_horizon(S, O, tmp_path):
     """sweep_kernel_mc64 against sweep_kernel_mi (hipcc-compiled, every slot screened) on the benchmark's system, 256
     replicas x 60 sweeps: the chains separate after ~10 sweeps (chaos), so the realised energies differ; the ensemble
