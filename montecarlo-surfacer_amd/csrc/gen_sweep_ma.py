@@ -70,17 +70,25 @@ ZBC = MODE == "zbc"                                       # diagnostic: every pa
 # probe, no z words in LDS).  The byte-wise squares alias |dz| >= 128 units; such cells are far outside the
 # cutoff, cost at most a wasted evaluation, and the group ranges keep them out of the passes anyway.
 # "z8c": its diagnostic build: the fp64 cutoff test of every cell beside every pass, counting unflagged pairs.
-PRIO = True                                               # rotate the wavefronts' issue priority (zb kernels)
+PRIO = MODE != "z8w"                                      # issue priority from the SIMD neighbours' progress (one-wave zb kernels)
 PRIO_MODE = os.environ.get("SMCX_GEN_PRIO_MODE", "rotate")
 PRIO_SHIFT = int(os.environ.get("SMCX_GEN_PRIO_SHIFT", "14"))   # ... every 2^14 ticks of the 100 MHz clock (164 us)
 Z8C = MODE == "z8c"
-Z8 = Z8C or MODE == "z8"
+# "z8w": z8 for FOUR wavefronts per replica (8192 < N <= 16384): wave w owns the cells 4096 w .. 4096 w + 4095 of the
+# z order (its own 16 groups and ranges) and runs the whole move loop itself -- same scalar state, own copy of the row
+# cache -- except that the wall sites, plane and side pair live on wave 0, a cell is written by its owner only, and
+# the two reductions of a move are completed across the waves through LDS (fixed order, so every wave takes the
+# same Metropolis decision); operand %3 = the wave's index
+W4 = MODE == "z8w"
+Z8 = Z8C or W4 or MODE == "z8"
 ZB = ZBC or Z8 or MODE == "zb"
 NG = NS // 4                                              # 4-slot groups
 LDS_P0 = 0 if Z8 else (NS // 2) * 256                     # after the int16 z words
 LDS_GB = LDS_P0                                           # zb: (min, max) z of each group while the copies are built (p0 is filled afterwards)
 LDS_CNT = LDS_P0 + 65 * 24 + 8                            # zbc: per lane (candidates, bits missing from the ranged pass)
-LANE, KARG, REP = "%0", "%1", "%2"
+LDS_WAVE = 2048                                           # z8w: each wave's copy of the row cache (v1 = wave * LDS_WAVE)
+LDS_X = 4 * LDS_WAVE                                      # z8w: exchange area [2 buffers][4 waves][64 lanes] doubles
+LANE, KARG, REP, WAVE = "%0", "%1", "%2", "%3"
 
 V = dict(zaddr=1, uns0=2, uns1=3, wa0=4, wa1=5, wb0=6, wb1=7, axy=8, bxy=9,
          zA=10, zB=12,            # z words of the screen: two pairs
@@ -124,7 +132,15 @@ if ZB:
     S.update(Rs=2, locA=4, locB=5, axys=12, bxys=13, nxy=14, nzl=15, first=65, planeB=48, sideL=64, wallB=86)
 
 
+if W4:
+    # bzz: real cells of this wave ; az16: M2 on wave 0, -1 elsewhere ; azz: hasA on wave 0, 0 elsewhere
+    S.update(Nw=S['bzz'], M2w=S['az16'], hasAw=S['azz'])
+
+
 def s(name, i=0): return "s%d" % (S[name] + i)
+def s_Nw(): return s('Nw') if W4 else s('N')
+def s_M2w(): return s('M2w') if W4 else s('M2')
+def s_hasAw(): return s('hasAw') if W4 else s('hasA')
 def sp(name, i=0): return "s[%d:%d]" % (S[name] + 2 * i, S[name] + 2 * i + 1)
 def st(i): return "s%d" % (S["t"] + i)
 def stp(i): return "s[%d:%d]" % (S["t"] + i, S["t"] + i + 1)
@@ -186,11 +202,27 @@ else:
     s_load_dwordx2 {sp('Rs')}, {KARG}, {K_RS}
     s_load_dword {st(3)}, {KARG}, {K_SW0}
     s_mov_b32 {st(0)}, {NS * 64 * 24}
-    s_mul_hi_u32 {st(1)}, {st(0)}, {REP}
-    s_mul_i32 {st(0)}, {st(0)}, {REP}
+    {f"s_lshl_b32 {st(2)}, {REP}, 2" if W4 else ""}
+    {f"s_add_u32 {st(2)}, {st(2)}, {WAVE}" if W4 else ""}
+    s_mul_hi_u32 {st(1)}, {st(0)}, {st(2) if W4 else REP}
+    s_mul_i32 {st(0)}, {st(0)}, {st(2) if W4 else REP}
     s_waitcnt lgkmcnt(0)
     s_add_u32 {s('Rs')}, {s('Rs')}, {st(0)}
     s_addc_u32 {s('Rs',1)}, {s('Rs',1)}, {st(1)}
+    """)
+    if W4:
+        # Rs points at this wave's 4096 cells; Nw = how many of them hold a particle; walls and side pair: wave 0
+        E(f"""
+        s_lshl_b32 {st(0)}, {WAVE}, 12
+        s_sub_i32 {s('Nw')}, {s('N')}, {st(0)}
+        s_max_i32 {s('Nw')}, {s('Nw')}, 0
+        s_min_i32 {s('Nw')}, {s('Nw')}, {NS * 64}
+        s_cmp_eq_u32 {WAVE}, 0
+        s_cselect_b32 {s('M2w')}, {s('M2')}, -1
+        s_mul_i32 {st(0)}, {WAVE}, {LDS_WAVE}
+        v_mov_b32 v1, {st(0)}
+        """)
+    E(f"""
     s_mov_b32 {s('sw')}, {st(3)}
     s_add_u32 {s('nsw')}, {s('nsw')}, {st(3)}
     // a launch that continues a chunk (sw0 > 0) takes the running energy from the previous sweep's record
@@ -265,7 +297,7 @@ if not ZB:
     s_mov_b32 {s('sideM',1)}, 0
     """)
 E(f"""
-v_lshlrev_b32 {v('zaddr')}, 2, {LANE}
+{"" if W4 else f"v_lshlrev_b32 {v('zaddr')}, 2, {LANE}"}
 v_mov_b32 {v('uns0')}, 0
 v_mov_b32 {v('uns1')}, 0
 s_mov_b32 {s('rot')}, 0
@@ -274,7 +306,7 @@ SRC = sp('Rs') if ZB else sp('Rg')    # what the compact copies are built from /
 if ZB:
     # LDS gb[g] = (max int, min int); lane g will read its group's pair when the copies are built
     E(f"""
-    v_lshlrev_b32 v14, 3, {LANE}
+    {f"v_lshl_add_u32 v14, {LANE}, 3, v1" if W4 else f"v_lshlrev_b32 v14, 3, {LANE}"}
     v_mov_b32 v16, 0x7fffffff
     v_mov_b32 v17, 0x80000000
     ds_write_b64 v14, v[16:17] offset:{LDS_GB}
@@ -287,7 +319,7 @@ if ZB:
 zb_range_update = "" if not ZB else f"""
 s_lshr_b32 {st(6)}, {st(0)}, 2
 s_lshl_b32 {st(6)}, {st(6)}, 3
-v_mov_b32 v26, {st(6)}
+{f"v_add_u32 v26, {st(6)}, v1" if W4 else f"v_mov_b32 v26, {st(6)}"}
 s_mov_b64 exec, vcc
 ds_min_i32 v26, v24 offset:{LDS_GB}
 ds_max_i32 v26, v24 offset:{LDS_GB + 4}
@@ -300,7 +332,7 @@ E(f"""
 s_mov_b32 {st(0)}, 0
 L_init:
 v_lshl_or_b32 v14, {st(0)}, 6, {LANE}
-v_cmp_gt_u32 vcc, {s('N')}, v14
+v_cmp_gt_u32 vcc, {s_Nw()}, v14
 v_mul_u32_u24 v15, 24, v14
 v_mov_b32 v16, 0
 v_mov_b32 v17, 0
@@ -369,7 +401,7 @@ if ZB:
     # lane g < NG: (lowest z - RZ, highest z + RZ) of group g; an empty group and the other lanes: never reached
     E(f"""
     s_load_dword {st(0)}, {KARG}, {K_RZ}
-    v_lshlrev_b32 v14, 3, {LANE}
+    {f"v_lshl_add_u32 v14, {LANE}, 3, v1" if W4 else f"v_lshlrev_b32 v14, 3, {LANE}"}
     ds_read_b64 v[16:17], v14 offset:{LDS_GB}
     s_waitcnt lgkmcnt(0)
     v_subrev_u32 {v('gloR')}, {st(0)}, v16
@@ -420,7 +452,7 @@ def fill_p0(tag):
     v_or_b32 v14, {st(0)}, {LANE}
     v_cmp_gt_u32 vcc, {s('N')}, v14
     v_mul_u32_u24 v15, 24, v14
-    v_mul_u32_u24 v22, 24, {LANE}
+    {f"v_mad_u32_u24 v22, {LANE}, 24, v1" if W4 else f"v_mul_u32_u24 v22, 24, {LANE}"}
     """)
     if ZB:
         E(f"""
@@ -457,7 +489,7 @@ def fill_p0(tag):
     global_load_dwordx4 v[16:19], v15, {sp('Rg')}
     global_load_dwordx2 v[20:21], v15, {sp('Rg')} offset:16
     {f"global_load_ushort v24, v23, {stp(4)}" if ZB else ""}
-    v_mov_b32 v22, {LDS_P0 + 64 * 24}
+    {f"v_add_u32 v22, {LDS_P0 + 64 * 24}, v1" if W4 else f"v_mov_b32 v22, {LDS_P0 + 64 * 24}"}
     s_waitcnt vmcnt(0)
     ds_write_b64 v22, v[16:17]
     ds_write_b64 v22, v[18:19] offset:8
@@ -711,9 +743,10 @@ else:
 E(f"""
 s_mov_b32 {s('i')}, -1
 s_mov_b32 {s('hasA')}, 0
+{f"s_mov_b32 {s('hasAw')}, 0" if W4 else ""}
 s_mov_b32 {s('hasB')}, 1
-s_mov_b32 {s('azz')}, 0
-s_mov_b32 {s('az16')}, 0
+{"" if Z8 else f"s_mov_b32 {s('azz')}, 0"}
+{"" if Z8 else f"s_mov_b32 {s('az16')}, 0"}
 s_mov_b32 {s('ua')}, 0
 {f"s_mov_b32 {s('axys')}, 0" if ZB else f"v_mov_b32 {v('axy')}, 0"}
 v_mov_b32 {v('FmV')}, 0
@@ -1073,10 +1106,20 @@ def z8c_check(tag, P_sgpr, w0, w1, locs, guard):
     """)
 
 
+NEXCL = [0]
+
+
 def excl(w0, w1, loc):
-    """zb: the particle in cell `loc` (s: slot << 6 | lane) is not a candidate"""
+    """zb: the particle in cell `loc` (s: slot << 6 | lane; z8w: wave << 12 | ...) is not a candidate"""
+    NEXCL[0] += 1
+    if W4:   # only the wave that owns the cell holds its bit
+        E(f"""
+        s_lshr_b32 {st(1)}, {loc}, 12
+        s_cmp_lg_u32 {st(1)}, {WAVE}
+        s_cbranch_scc1 L_excl{NEXCL[0]}
+        """)
     E(f"""
-    s_lshr_b32 {st(1)}, {loc}, 6
+    {f"s_bfe_u32 {st(1)}, {loc}, 0x60006" if W4 else f"s_lshr_b32 {st(1)}, {loc}, 6"}
     s_lshl_b64 {stp(2)}, 1, {loc}
     s_lshl_b64 {stp(4)}, 1, {st(1)}
     s_not_b64 {stp(4)}, {stp(4)}
@@ -1085,6 +1128,8 @@ def excl(w0, w1, loc):
     v_and_b32 {w1}, {st(5)}, {w1}
     s_mov_b64 exec, -1
     """)
+    if W4:
+        E(f"L_excl{NEXCL[0]}:")
 
 
 # ---------------------------------------------------------------------------------------------- helpers
@@ -1290,6 +1335,28 @@ def reduce4(dst):
         """)
 
 
+def xchg(dst, buf):
+    """z8w: dst (row layout, this wave's partial sums) <- the sum over the four waves, added in wave order by every
+    wave alike; two buffers alternate (probe A, probe B) so that a fast wave cannot overwrite what a slow one reads"""
+    X = LDS_X + buf * 2048
+    E(f"""
+    s_lshl_b32 {st(0)}, {WAVE}, 9
+    v_lshl_add_u32 v44, {LANE}, 3, {st(0)}
+    v_lshlrev_b32 v45, 3, {LANE}
+    ds_write_b64 v44, {dst} offset:{X}
+    s_waitcnt lgkmcnt(0)
+    s_barrier
+    ds_read_b64 v[46:47], v45 offset:{X}
+    ds_read_b64 v[48:49], v45 offset:{X + 512}
+    ds_read_b64 v[50:51], v45 offset:{X + 1024}
+    ds_read_b64 v[52:53], v45 offset:{X + 1536}
+    s_waitcnt lgkmcnt(0)
+    v_add_f64 {dst}, v[46:47], v[48:49]
+    v_add_f64 {dst}, {dst}, v[50:51]
+    v_add_f64 {dst}, {dst}, v[52:53]
+    """)
+
+
 def probe(tag, P, pz_sgpr, pz, w0, w1, X, C, have, side, wait, wl=None, pl=None):
     """a whole probe: round 0 (specials + the first candidates, already requested into X / `have`), then
     further rounds while any lane still has a candidate.  `wait`: the s_waitcnt that covers round 0's loads"""
@@ -1303,7 +1370,7 @@ def probe(tag, P, pz_sgpr, pz, w0, w1, X, C, have, side, wait, wl=None, pl=None)
     E(f"L_nw_{tag}:")
     E(f"s_or_b64 {stp(6)}, {have}, {wl}")
     if side:
-        E(f"s_cmp_eq_u32 {s('hasA')}, 0")
+        E(f"s_cmp_eq_u32 {s_hasAw()}, 0")
         E(f"s_cbranch_scc1 L_noside_{tag}")
         if ZB:
             E(f"s_lshl_b64 {stp(0)}, 1, {s('sideL')}")
@@ -1338,10 +1405,10 @@ def assign_specials(tag, w0, w1, X, C, wl, pl, with_side, have):
     need = st(6) if with_side else st(3)
     E(f"""
     v_cmp_ne_u64 {have}, 0, v[{w0}:{w1}]
-    s_add_u32 {st(3)}, {s('M2')}, 1
+    s_add_u32 {st(3)}, {s_M2w()}, 1
     s_not_b64 {stp(0)}, {have}
     s_bcnt1_i32_b64 {st(2)}, {stp(0)}
-    {f"s_add_u32 {st(6)}, {st(3)}, {s('hasA')}" if with_side else ""}
+    {f"s_add_u32 {st(6)}, {st(3)}, {s_hasAw()}" if with_side else ""}
     s_cmp_lt_u32 {st(2)}, {need}
     s_cbranch_scc1 L_sps_{tag}
     v_mbcnt_lo_u32_b32 v48, {st(0)}, 0
@@ -1349,7 +1416,7 @@ def assign_specials(tag, w0, w1, X, C, wl, pl, with_side, have):
     v_ffbl_b32 v44, v{w0}
     v_ffbl_b32 v45, v{w1}
     v_cmp_gt_u32 {wl}, {st(3)}, v48
-    v_cmp_eq_u32 {pl}, {s('M2')}, v48
+    v_cmp_eq_u32 {pl}, {s_M2w()}, v48
     """)
     if with_side:
         E(f"""
@@ -1387,8 +1454,8 @@ def assign_specials(tag, w0, w1, X, C, wl, pl, with_side, have):
     s_lshl_b64 {wl}, 1, {st(3)}
     s_sub_u32 s{wlo}, s{wlo}, 1
     s_subb_u32 s{whi}, s{whi}, 0
-    s_lshl_b64 {pl}, 1, {s('M2')}
-    s_cmp_lt_i32 {s('M2')}, 0
+    s_lshl_b64 {pl}, 1, {s_M2w()}
+    s_cmp_lt_i32 {s_M2w()}, 0
     s_cselect_b64 {pl}, 0, {pl}
     s_mov_b64 {stp(4)}, {wl}
     {f"s_mov_b32 {s('sideL')}, 30" if with_side else ""}
@@ -1404,7 +1471,7 @@ def assign_specials(tag, w0, w1, X, C, wl, pl, with_side, have):
 def all_real_cells(w0, w1):
     """zb, unsafe probe: every REAL cell of this lane is a candidate (cell = slot * 64 + lane < N)"""
     E(f"""
-    v_sub_u32 v14, {s('N')}, {LANE}
+    v_sub_u32 v14, {s_Nw()}, {LANE}
     v_add_u32 v14, 63, v14
     v_ashrrev_i32 v14, 6, v14
     v_max_i32 v14, 0, v14
@@ -1549,7 +1616,7 @@ E(f"""
 // probe B's fp64 position from the LDS cache: row = cross ? 64 : tl + 1 (= tl + 1 either way)
 s_add_u32 {st(0)}, {s('tl')}, 1
 s_mul_i32 {st(0)}, {st(0)}, 24
-v_mov_b32 {v('T')}, {st(0)}
+{f"v_add_u32 {v('T')}, {st(0)}, v1" if W4 else f"v_mov_b32 {v('T')}, {st(0)}"}
 ds_read_b64 v[14:15], {v('T')} offset:{LDS_P0}
 ds_read_b64 v[16:17], {v('T')} offset:{LDS_P0 + 8}
 ds_read_b64 v[18:19], {v('T')} offset:{LDS_P0 + 16}
@@ -1567,6 +1634,8 @@ probe("A", QP, True, (s('Q', 4), s('Q', 5)), V['wa0'], V['wa1'], XA_, CA_, sp('h
       ("" if (ZBC or Z8C) else "s_waitcnt vmcnt(4)") if ZB else "s_nop 0")
 FnV = vp('M', 0)          # v[36:37]: the body's M registers are free now
 reduce4(FnV)
+if W4:
+    xchg(FnV, 0)
 E(f"""
 // ---- Metropolis step in row layout (SMC.c:326-335); DdV = displacement of this move per row
 v_add_f64 {vp('D',0)}, {FnV}, -{vp('FmV')}
@@ -1665,7 +1734,8 @@ else:
     # lane tl: the fp64 position to R (particle order), Rs (cell order) and the row cache; then the owner lane of
     # the particle's cell: packed x,y (indexed register write), unsafe bit, int16 z; then lane g: the group's range
     E(f"""
-    s_mul_i32 {st(3)}, {s('locA')}, 24
+    {f"s_and_b32 {st(3)}, {s('locA')}, 4095" if W4 else ""}
+    s_mul_i32 {st(3)}, {st(3) if W4 else s('locA')}, 24
     s_mov_b64 exec, {stp(0)}
     v_mov_b32 v50, {s('Q',0)}
     v_mov_b32 v51, {s('Q',1)}
@@ -1675,15 +1745,23 @@ else:
     v_mov_b32 v55, {s('Q',5)}
     v_mov_b32 {v('T',1)}, {st(2)}
     v_mov_b32 {v('T')}, {st(3)}
-    v_mul_u32_u24 {v('S6')}, 24, {LANE}
+    {f"v_mad_u32_u24 {v('S6')}, {LANE}, 24, v1" if W4 else f"v_mul_u32_u24 {v('S6')}, 24, {LANE}"}
     global_store_dwordx4 {v('T',1)}, v[50:53], {sp('Rg')}
     global_store_dwordx2 {v('T',1)}, v[54:55], {sp('Rg')} offset:16
-    global_store_dwordx4 {v('T')}, v[50:53], {sp('Rs')}
-    global_store_dwordx2 {v('T')}, v[54:55], {sp('Rs')} offset:16
     ds_write_b64 {v('S6')}, v[50:51] offset:{LDS_P0}
     ds_write_b64 {v('S6')}, v[52:53] offset:{LDS_P0 + 8}
     ds_write_b64 {v('S6')}, v[54:55] offset:{LDS_P0 + 16}
-    s_lshr_b32 {st(1)}, {s('locA')}, 6
+    """)
+    if W4:   # the cell, its copy in Rs and its group's range belong to one wave
+        E(f"""
+        s_lshr_b32 {st(1)}, {s('locA')}, 12
+        s_cmp_lg_u32 {st(1)}, {WAVE}
+        s_cbranch_scc1 L_notmine
+        """)
+    E(f"""
+    global_store_dwordx4 {v('T')}, v[50:53], {sp('Rs')}
+    global_store_dwordx2 {v('T')}, v[54:55], {sp('Rs')} offset:16
+    {f"s_bfe_u32 {st(1)}, {s('locA')}, 0x60006" if W4 else f"s_lshr_b32 {st(1)}, {s('locA')}, 6"}
     s_lshl_b64 {stp(2)}, 1, {s('locA')}
     s_lshl_b64 {stp(4)}, 1, {st(1)}
     s_not_b64 {stp(6)}, {stp(4)}
@@ -1721,6 +1799,7 @@ else:
     s_mov_b64 exec, {stp(2)}
     v_min_i32 {v('gloR')}, {st(4)}, {v('gloR')}
     v_max_i32 {v('ghiR')}, {st(5)}, {v('ghiR')}
+    {"L_notmine:" if W4 else ""}
     s_mov_b64 exec, -1
     s_nop 1
     """)
@@ -1744,10 +1823,10 @@ s_add_u32 {st(1)}, {s('i')}, 1
 s_mul_i32 {st(1)}, {st(1)}, 24
 v_add_u32 {v('S6')}, {st(1)}, {v('T')}
 // the side pair's source on lane 30: particle n where the move left it = p0[tl]
-s_cmp_eq_u32 {s('hasA')}, 0
+s_cmp_eq_u32 {s_hasAw()}, 0
 s_cbranch_scc1 L_nosrc
 s_mul_i32 {st(0)}, {s('tl')}, 24
-v_mov_b32 {v('T')}, {st(0)}
+{f"v_add_u32 {v('T')}, {st(0)}, v1" if W4 else f"v_mov_b32 {v('T')}, {st(0)}"}
 {f"s_lshl_b64 {stp(2)}, 1, {s('sideL')}" if ZB else ""}
 s_mov_b64 exec, {stp(2) if ZB else sp('sideM')}
 ds_read_b64 v[{XB_}:{XB_+1}], {v('T')} offset:{LDS_P0}
@@ -1763,6 +1842,8 @@ BP = ["v[14:15]", "v[16:17]", "v[18:19]"]
 probe("B", BP, False, "v[18:19]", V['wb0'], V['wb1'], XB_, CB_, sp('haveB'), True, "s_waitcnt vmcnt(1)",
       sp('wallB') if ZB else None, sp('planeB') if ZB else None)
 reduce4(vp('FmV'))
+if W4:
+    xchg(vp('FmV'), 1)
 E(f"""
 // ---- proposal of particle n+1 in row layout (SMC.c:307-316): q = p + (Fm A/T + displ)
 // rows 1..3 read component row-1 of p0[rowB] and of displ[3 (i+1) ..]; row 0 idles along with component 0
@@ -1772,7 +1853,7 @@ v_max_i32 {v('T')}, 0, {v('T')}
 v_lshlrev_b32 {v('T')}, 3, {v('T')}
 s_add_u32 {st(0)}, {s('tl')}, 1
 s_mul_i32 {st(0)}, {st(0)}, 24
-v_add_u32 {v('T',1)}, {st(0)}, {v('T')}
+{f"v_add3_u32 {v('T',1)}, {st(0)}, {v('T')}, v1" if W4 else f"v_add_u32 {v('T',1)}, {st(0)}, {v('T')}"}
 ds_read_b64 {vp('D',0)}, {v('T',1)} offset:{LDS_P0}
 s_waitcnt vmcnt(0) lgkmcnt(0)
 {'' if Z8 else f"s_mov_b64 {sp('lu')}, {sp('nlu')}"}
@@ -1840,6 +1921,8 @@ if ZB:
 E(f"""
 s_add_u32 {s('i')}, {s('i')}, 1
 s_mov_b32 {s('hasA')}, 1
+{f"s_cmp_eq_u32 {WAVE}, 0" if W4 else ""}
+{f"s_cselect_b32 {s('hasAw')}, 1, 0" if W4 else ""}
 s_add_u32 {st(0)}, {s('i')}, 1
 s_cmp_lt_i32 {st(0)}, {s('len')}
 s_cselect_b32 {s('hasB')}, 1, 0

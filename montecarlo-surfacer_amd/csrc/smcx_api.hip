@@ -215,7 +215,8 @@ static int choose_geometry(const smcx_params *p, int *S, int *WPR)
         // one wavefront per replica has hand-scheduled kernels (sweep_kernel_mc*/mb64/ma*) that beat any split over
         // several wavefronts even with few replicas (N = 2048: 3.1-3.6 ms per sweep against 5.2-9.0 for 16 x 2 at
         // 128..1024 replicas, tools/probes/geom_rule.py); the split stays for boxes those kernels do not serve
-        const bool one_wave = (w == 1) && mi_supported(s, 1, p->L, p->Lz, p->cutoff * p->cutoff);
+        const bool one_wave = ((w == 1) && mi_supported(s, 1, p->L, p->Lz, p->cutoff * p->cutoff)) ||
+                              mcw_supported(s, w, p->N, 0, p->L, p->Lz, p->cutoff * p->cutoff); // (or its 4-wave form)
         while (!one_wave && (long)p->nrep * w < 2048 && s > 16 && w < 8 && geometry_supported(s / 2, w * 2)) { s /= 2; w *= 2; }
     } else {
         if (p->N <= 1024) { s = pow2_at_least((p->N + 63) / 64); w = 1; }
@@ -337,7 +338,7 @@ extern "C" int smcx_create(const smcx_params *p, smcx_handle **out)
     CRT(hipMemset(c.clk, 0, nrep * 4 * sizeof(unsigned long long)));
     if (zordered_supported(h.S, h.WPR, p->N, (p->flags & SMCX_FLAG_WALLS) ? c.M2 : 0, p->L, p->Lz, p->cutoff * p->cutoff)) {
         // cell-ordered copy of the positions and the cell of each particle (sweep_kernel_mb64 / mc*)
-        CRT(hipMalloc(&c.Rs, nrep * (size_t)h.S * 64 * 3 * sizeof(double)));
+        CRT(hipMalloc(&c.Rs, nrep * (size_t)h.S * h.WPR * 64 * 3 * sizeof(double)));
         CRT(hipMalloc(&c.loc, nrep * N * sizeof(unsigned short)));
         CRT(hipMalloc(&c.prio, 16384 * sizeof(unsigned)));
         CRT(hipMemset(c.prio, 0, 16384 * sizeof(unsigned)));
@@ -412,6 +413,10 @@ extern "C" int smcx_kernel_form(const smcx_handle *hh, int *form, char *name, in
     const bool mx = sweep_uses_mx(h.S, h.WPR, h.p.tune_kernel);
     if (form) *form = mx ? 2 : 1;
     const bool mi = mx && mi_supported(h.S, h.WPR, h.p.L, h.p.Lz, h.p.cutoff * h.p.cutoff);
+    if (mx && name && len > 0 && h.c.Rs && mcw_supported(h.S, h.WPR, h.p.N, 0, h.p.L, h.p.Lz, h.p.cutoff * h.p.cutoff)) {
+        std::snprintf(name, (size_t)len, "smcx::sweep_kernel_mc64x4");
+        return SMCX_OK;
+    }
     if (name && len > 0)
         std::snprintf(name, (size_t)len, "%s", mi ? mi_kernel_name(h.S, h.p.N, h.p.L, h.p.Lz, h.p.cutoff * h.p.cutoff)
                                                   : mx ? mx_kernel_name(h.S, h.WPR, h.p.Lz) : fp64_kernel_name(h.S, h.WPR));

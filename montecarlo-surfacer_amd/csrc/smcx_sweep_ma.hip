@@ -144,6 +144,21 @@ __global__ void __launch_bounds__(64, 6) sweep_kernel_mc16(MaArgs a)
         :
         : "memory", "vcc", "scc", "m0", SMCX_MA_SGPRS, SMCX_MA_V79);
 }
+// four wavefronts per replica (8192 < N <= 16384; gen_sweep_ma.py ... z8w): wave w owns the cells 4096 w .. of the
+// z order; LDS = four copies of the row cache (2048 B apart) + the exchange area of the reductions (2 x 2048 B)
+__global__ void __launch_bounds__(256, 1) sweep_kernel_mc64x4(MaArgs a)
+{
+    unsigned lane = threadIdx.x & 63;
+    unsigned long long kp = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
+    unsigned rep = blockIdx.x;
+    unsigned wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    asm volatile(
+#include "smcx_sweep_mcw_body64.inc"
+        : "+v"(lane), "+s"(kp), "+s"(rep), "+s"(wv)
+        :
+        : "memory", "vcc", "scc", "m0", SMCX_MA_SGPRS, SMCX_MA_V127);
+}
+constexpr unsigned mcw_lds_bytes() { return 4u * 2048u + 2u * 2048u; }
 #endif
 #ifdef SMCX_CHECK
 constexpr unsigned mc_lds_bytes() { return 65u * 24u + 8u + 512u; }
@@ -223,7 +238,9 @@ template <int CELLS, int TPB>
 __global__ void __launch_bounds__(TPB) zsort_kernel(const double *__restrict__ R, double *__restrict__ Rs,
                                                     unsigned short *__restrict__ loc, int N, double toFix)
 {
-    static_assert(CELLS <= 4096, "12-bit particle index in the keys");
+    // bits of the particle index in the keys; second keys: 32 - NB - (bits of the group) are left for the Morton code
+    constexpr int NB = CELLS <= 4096 ? 12 : 14, GB = CELLS <= 4096 ? 4 : 6, MB = 32 - NB - GB;
+    static_assert(CELLS <= 16384 && MB >= 12, "key layout");
     __shared__ unsigned key[CELLS];
     const double *Rr = R + (size_t)blockIdx.x * 3 * N;
     const double zFix = toFix * (1.0 / 256.0); // 256 / L
@@ -232,7 +249,7 @@ __global__ void __launch_bounds__(TPB) zsort_kernel(const double *__restrict__ R
         if (n < N) {
             int zq = (int)rint(Rr[3 * n + 2] * zFix);
             zq = zq < -32767 ? -32767 : zq > 32767 ? 32767 : zq;
-            k = ((unsigned)(zq + 32768) << 12) | (unsigned)n;
+            k = ((unsigned)(zq + 32768) << NB) | (unsigned)n;
         }
         key[n] = k;
     }
@@ -242,14 +259,14 @@ __global__ void __launch_bounds__(TPB) zsort_kernel(const double *__restrict__ R
     for (int p = threadIdx.x; p < CELLS; p += TPB) {
         const unsigned k = key[p];
         if (k == ~0u) continue;
-        const unsigned n = k & 0xfffu;
-        unsigned sub = (unsigned)(p & 255) << 8; // a partial group keeps z order
+        const unsigned n = k & ((1u << NB) - 1u);
+        unsigned sub = (unsigned)(p & 255) << (MB - 8); // a partial group keeps z order
         if ((p >> 8) < full) {
             const unsigned ix = ((unsigned)(int)rint(Rr[3 * n] * toFix) + 0x8000u) >> 8;     // 8 bits of the wrapped x
             const unsigned iy = ((unsigned)(int)rint(Rr[3 * n + 1] * toFix) + 0x8000u) >> 8;
-            sub = spread8(ix) | (spread8(iy) << 1);
+            sub = (spread8(ix) | (spread8(iy) << 1)) >> (16 - MB);                            // the top MB bits of the code
         }
-        key[p] = ((unsigned)(p >> 8) << 28) | (sub << 12) | n;
+        key[p] = ((unsigned)(p >> 8) << (32 - GB)) | (sub << NB) | n;
     }
     __syncthreads();
     bitonic_lds<CELLS, TPB, true>(key, 256);
@@ -259,7 +276,7 @@ __global__ void __launch_bounds__(TPB) zsort_kernel(const double *__restrict__ R
         const int c = g < full ? (4 * g + (r >> 6)) * 64 + ((r + ZSORT_DEAL * g) & 63) : p;
         double *d = Rs + ((size_t)blockIdx.x * CELLS + c) * 3;
         if (k != ~0u) {
-            const unsigned n = k & 0xfffu;
+            const unsigned n = k & ((1u << NB) - 1u);
             loc[(size_t)blockIdx.x * N + n] = (unsigned short)c;
             d[0] = Rr[3 * n]; d[1] = Rr[3 * n + 1]; d[2] = Rr[3 * n + 2];
         } else {
@@ -305,11 +322,56 @@ bool mc_supported(int S, int WPR, int N, int M2, double L, double Lz, double cut
     return ma_supported(S, WPR, N, M2) && mc_box_supported(L, Lz, cutoff2);
 }
 
+// four wavefronts per replica with 64 cells per lane each: 8192 < N <= 16384 in a box the byte screen serves
+bool mcw_supported(int S, int WPR, int N, int M2, double L, double Lz, double cutoff2)
+{
+#ifdef SMCX_CHECK
+    return false;
+#endif
+    static const char *env = getenv("SMCX_MCW"); // SMCX_MCW=0: sweep_kernel_mx for this geometry
+    if (env && env[0] == '0') return false;
+    return S == 64 && WPR == 4 && N > 8192 && N <= 16384 && M2 + 1 <= 30 && mc_box_supported(L, Lz, cutoff2);
+}
+
 // does this geometry / box run a kernel with z-ordered cells (and need Rs, loc)?
 bool zordered_supported(int S, int WPR, int N, int M2, double L, double Lz, double cutoff2)
 {
-    return mb_supported(S, WPR, N, M2) || mc_supported(S, WPR, N, M2, L, Lz, cutoff2);
+    return mb_supported(S, WPR, N, M2) || mc_supported(S, WPR, N, M2, L, Lz, cutoff2) ||
+           mcw_supported(S, WPR, N, M2, L, Lz, cutoff2);
 }
+
+#ifndef SMCX_CHECK
+// the multi-wave form has its own launcher: no int16-screen numbers are needed (the byte screen's come from mc_bound)
+hipError_t launch_sweeps_mcw(const SweepArgs &s, const DevCtx &c, int nsweeps, double A, hipStream_t st, SweepTimer *tm)
+{
+    MaArgs a;
+    a.R = s.R; a.displ = s.displ; a.uni = s.uni; a.offs = s.offs; a.obs = s.obs; a.rec = s.rec;
+    a.wtab = c.wtab; a.clk = s.clk;
+    a.L = s.L; a.invL = s.invL; a.cutoff2 = s.cutoff2; a.invT = s.invT;
+    a.AoT = A * s.invT; a.Ao4T = A * 0.25 * s.invT;
+    a.halfLz = c.halfLz; a.Lz = c.Lz; a.invLz = c.invLz;
+    a.N = s.N; a.chunk = s.chunk; a.nsweeps = 1;
+    a.M2 = (c.flags & 0x1u) ? c.M2 : -1;
+    mc_bound_values(c.L, c.cutoff2, &a.toFix, &a.zsafe, &a.negC, &a.RZ);
+    a.zFix = a.toFix;
+    a.Rs = c.Rs; a.loc = c.loc; a.pad0 = 0; a.dbg = nullptr; a.prio = c.prio;
+    const double toFix16 = 65536.0 / c.L; // the Morton code of the z sort takes x, y in units of L/65536
+    for (int sw = 0; sw < nsweeps; sw++) {
+        hipLaunchKernelGGL((zsort_kernel<4 * 64 * 64, 1024>), dim3(c.nrep), dim3(1024), 0, st, (const double *)s.R, c.Rs, c.loc,
+                           s.N, toFix16);
+        a.sw0 = sw;
+        hipError_t rc = tm ? tm->mark(st) : hipSuccess;
+        if (rc != hipSuccess) return rc;
+        hipLaunchKernelGGL(sweep_kernel_mc64x4, dim3(c.nrep), dim3(256), mcw_lds_bytes(), st, a);
+        rc = hipGetLastError();
+        if (rc == hipSuccess && tm) rc = tm->mark(st);
+        if (rc != hipSuccess) return rc;
+    }
+    return hipSuccess;
+}
+#else
+hipError_t launch_sweeps_mcw(const SweepArgs &, const DevCtx &, int, double, hipStream_t, SweepTimer *) { return hipErrorInvalidValue; }
+#endif
 
 void mc_bound(double L, double cutoff2, double *toFix, double *zsafe, int *negC, int *RZ);
 

@@ -38,8 +38,9 @@ def oracle_chains(O, s, seeds, R0, eq, nsw, gl, workers=16):
 
 # ------------------------------------------------------------------ BASELINE config 5: N = 16384
 @pytest.mark.parametrize("slots,waves,name", [
-    (64, 4, "smcx::sweep_kernel_mx<64, 4, 2, false>"),   # multi-wavefront tiling: 4 wavefronts x 64 particles per lane
-    (32, 8, "smcx::sweep_kernel_mx<32, 8, 3, false>"),   # what the geometry rule picks at 256 replicas per GPU
+    (64, 4, "smcx::sweep_kernel_mc64x4"),                # 4 wavefronts x 64 cells per lane, z-ordered, byte screen: the
+                                                         # geometry rule's choice at this N
+    (32, 8, "smcx::sweep_kernel_mx<32, 8, 3, false>"),   # the round-1 multi-wavefront tiling, 8 x 32
 ])
 def test_config5_N16384_against_oracle(S, O, slots, waves, name):
     """BASELINE configs[4]: N=16384 + wall, fcc(16,16) (the reference's own dense lattice),
