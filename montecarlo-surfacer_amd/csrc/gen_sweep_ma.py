@@ -80,6 +80,10 @@ Z8C = MODE == "z8c"
 # the two reductions of a move are completed across the waves through LDS (fixed order, so every wave takes the
 # same Metropolis decision); operand %3 = the wave's index
 W4 = MODE == "z8w"
+WPR = (int(sys.argv[4]) if len(sys.argv) > 4 else 256 // NS) if W4 else 1   # wavefronts per replica: 4 (NS = 64) or 8 (NS = 32)
+assert WPR in (1, 4, 8)
+WSH = (NS * 64).bit_length() - 1                          # cell >> WSH = the wave that owns it
+SLOTF = ((NS.bit_length() - 1) << 16) | 6                 # s_bfe field of the slot inside a cell index
 Z8 = Z8C or W4 or MODE == "z8"
 ZB = ZBC or Z8 or MODE == "zb"
 NG = NS // 4                                              # 4-slot groups
@@ -87,7 +91,7 @@ LDS_P0 = 0 if Z8 else (NS // 2) * 256                     # after the int16 z wo
 LDS_GB = LDS_P0                                           # zb: (min, max) z of each group while the copies are built (p0 is filled afterwards)
 LDS_CNT = LDS_P0 + 65 * 24 + 8                            # zbc: per lane (candidates, bits missing from the ranged pass)
 LDS_WAVE = 2048                                           # z8w: each wave's copy of the row cache (v1 = wave * LDS_WAVE)
-LDS_X = 4 * LDS_WAVE                                      # z8w: exchange area [2 buffers][4 waves][64 lanes] doubles
+LDS_X = WPR * LDS_WAVE                                    # z8w: exchange area [2 buffers][WPR waves][64 lanes] doubles
 LANE, KARG, REP, WAVE = "%0", "%1", "%2", "%3"
 
 V = dict(zaddr=1, uns0=2, uns1=3, wa0=4, wa1=5, wb0=6, wb1=7, axy=8, bxy=9,
@@ -202,7 +206,7 @@ else:
     s_load_dwordx2 {sp('Rs')}, {KARG}, {K_RS}
     s_load_dword {st(3)}, {KARG}, {K_SW0}
     s_mov_b32 {st(0)}, {NS * 64 * 24}
-    {f"s_lshl_b32 {st(2)}, {REP}, 2" if W4 else ""}
+    {f"s_mul_i32 {st(2)}, {REP}, {WPR}" if W4 else ""}
     {f"s_add_u32 {st(2)}, {st(2)}, {WAVE}" if W4 else ""}
     s_mul_hi_u32 {st(1)}, {st(0)}, {st(2) if W4 else REP}
     s_mul_i32 {st(0)}, {st(0)}, {st(2) if W4 else REP}
@@ -213,7 +217,7 @@ else:
     if W4:
         # Rs points at this wave's 4096 cells; Nw = how many of them hold a particle; walls and side pair: wave 0
         E(f"""
-        s_lshl_b32 {st(0)}, {WAVE}, 12
+        s_lshl_b32 {st(0)}, {WAVE}, {WSH}
         s_sub_i32 {s('Nw')}, {s('N')}, {st(0)}
         s_max_i32 {s('Nw')}, {s('Nw')}, 0
         s_min_i32 {s('Nw')}, {s('Nw')}, {NS * 64}
@@ -1114,12 +1118,12 @@ def excl(w0, w1, loc):
     NEXCL[0] += 1
     if W4:   # only the wave that owns the cell holds its bit
         E(f"""
-        s_lshr_b32 {st(1)}, {loc}, 12
+        s_lshr_b32 {st(1)}, {loc}, {WSH}
         s_cmp_lg_u32 {st(1)}, {WAVE}
         s_cbranch_scc1 L_excl{NEXCL[0]}
         """)
     E(f"""
-    {f"s_bfe_u32 {st(1)}, {loc}, 0x60006" if W4 else f"s_lshr_b32 {st(1)}, {loc}, 6"}
+    {f"s_bfe_u32 {st(1)}, {loc}, {SLOTF}" if W4 else f"s_lshr_b32 {st(1)}, {loc}, 6"}
     s_lshl_b64 {stp(2)}, 1, {loc}
     s_lshl_b64 {stp(4)}, 1, {st(1)}
     s_not_b64 {stp(4)}, {stp(4)}
@@ -1336,9 +1340,10 @@ def reduce4(dst):
 
 
 def xchg(dst, buf):
-    """z8w: dst (row layout, this wave's partial sums) <- the sum over the four waves, added in wave order by every
-    wave alike; two buffers alternate (probe A, probe B) so that a fast wave cannot overwrite what a slow one reads"""
-    X = LDS_X + buf * 2048
+    """z8w: dst (row layout, this wave's partial sums) <- the sum over the waves of the replica, added in wave order by
+    every wave alike; two buffers alternate (probe A, probe B) so that a fast wave cannot overwrite what a slow one
+    still reads"""
+    X = LDS_X + buf * WPR * 512
     E(f"""
     s_lshl_b32 {st(0)}, {WAVE}, 9
     v_lshl_add_u32 v44, {LANE}, 3, {st(0)}
@@ -1346,15 +1351,18 @@ def xchg(dst, buf):
     ds_write_b64 v44, {dst} offset:{X}
     s_waitcnt lgkmcnt(0)
     s_barrier
-    ds_read_b64 v[46:47], v45 offset:{X}
-    ds_read_b64 v[48:49], v45 offset:{X + 512}
-    ds_read_b64 v[50:51], v45 offset:{X + 1024}
-    ds_read_b64 v[52:53], v45 offset:{X + 1536}
-    s_waitcnt lgkmcnt(0)
-    v_add_f64 {dst}, v[46:47], v[48:49]
-    v_add_f64 {dst}, {dst}, v[50:51]
-    v_add_f64 {dst}, {dst}, v[52:53]
     """)
+    for k in range(0, WPR, 4):           # four partial sums at a time in v46..v53
+        for j in range(4):
+            E(f"ds_read_b64 v[{46 + 2 * j}:{47 + 2 * j}], v45 offset:{X + 512 * (k + j)}")
+        E("s_waitcnt lgkmcnt(0)")
+        if k == 0:
+            E(f"v_add_f64 {dst}, v[46:47], v[48:49]")
+        else:
+            E(f"v_add_f64 {dst}, {dst}, v[46:47]")
+            E(f"v_add_f64 {dst}, {dst}, v[48:49]")
+        E(f"v_add_f64 {dst}, {dst}, v[50:51]")
+        E(f"v_add_f64 {dst}, {dst}, v[52:53]")
 
 
 def probe(tag, P, pz_sgpr, pz, w0, w1, X, C, have, side, wait, wl=None, pl=None):
@@ -1734,7 +1742,7 @@ else:
     # lane tl: the fp64 position to R (particle order), Rs (cell order) and the row cache; then the owner lane of
     # the particle's cell: packed x,y (indexed register write), unsafe bit, int16 z; then lane g: the group's range
     E(f"""
-    {f"s_and_b32 {st(3)}, {s('locA')}, 4095" if W4 else ""}
+    {f"s_and_b32 {st(3)}, {s('locA')}, {NS * 64 - 1}" if W4 else ""}
     s_mul_i32 {st(3)}, {st(3) if W4 else s('locA')}, 24
     s_mov_b64 exec, {stp(0)}
     v_mov_b32 v50, {s('Q',0)}
@@ -1754,14 +1762,14 @@ else:
     """)
     if W4:   # the cell, its copy in Rs and its group's range belong to one wave
         E(f"""
-        s_lshr_b32 {st(1)}, {s('locA')}, 12
+        s_lshr_b32 {st(1)}, {s('locA')}, {WSH}
         s_cmp_lg_u32 {st(1)}, {WAVE}
         s_cbranch_scc1 L_notmine
         """)
     E(f"""
     global_store_dwordx4 {v('T')}, v[50:53], {sp('Rs')}
     global_store_dwordx2 {v('T')}, v[54:55], {sp('Rs')} offset:16
-    {f"s_bfe_u32 {st(1)}, {s('locA')}, 0x60006" if W4 else f"s_lshr_b32 {st(1)}, {s('locA')}, 6"}
+    {f"s_bfe_u32 {st(1)}, {s('locA')}, {SLOTF}" if W4 else f"s_lshr_b32 {st(1)}, {s('locA')}, 6"}
     s_lshl_b64 {stp(2)}, 1, {s('locA')}
     s_lshl_b64 {stp(4)}, 1, {st(1)}
     s_not_b64 {stp(6)}, {stp(4)}

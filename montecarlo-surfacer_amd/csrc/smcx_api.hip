@@ -215,8 +215,11 @@ static int choose_geometry(const smcx_params *p, int *S, int *WPR)
         // one wavefront per replica has hand-scheduled kernels (sweep_kernel_mc*/mb64/ma*) that beat any split over
         // several wavefronts even with few replicas (N = 2048: 3.1-3.6 ms per sweep against 5.2-9.0 for 16 x 2 at
         // 128..1024 replicas, tools/probes/geom_rule.py); the split stays for boxes those kernels do not serve
-        const bool one_wave = ((w == 1) && mi_supported(s, 1, p->L, p->Lz, p->cutoff * p->cutoff)) ||
-                              mcw_supported(s, w, p->N, 0, p->L, p->Lz, p->cutoff * p->cutoff); // (or its 4-wave form)
+        bool one_wave = (w == 1) && mi_supported(s, 1, p->L, p->Lz, p->cutoff * p->cutoff);
+        if (mcw_supported(s, w, p->N, 0, p->L, p->Lz, p->cutoff * p->cutoff)) { // its several-wave forms: 64 x 4, or
+            one_wave = true;                                                     // 32 x 8 while the chip has room
+            if ((long)p->nrep * 8 <= 2048) { s = 32; w = 8; }                    // (44.6 against 47.3 ms per sweep at 256)
+        }
         while (!one_wave && (long)p->nrep * w < 2048 && s > 16 && w < 8 && geometry_supported(s / 2, w * 2)) { s /= 2; w *= 2; }
     } else {
         if (p->N <= 1024) { s = pow2_at_least((p->N + 63) / 64); w = 1; }
@@ -414,7 +417,7 @@ extern "C" int smcx_kernel_form(const smcx_handle *hh, int *form, char *name, in
     if (form) *form = mx ? 2 : 1;
     const bool mi = mx && mi_supported(h.S, h.WPR, h.p.L, h.p.Lz, h.p.cutoff * h.p.cutoff);
     if (mx && name && len > 0 && h.c.Rs && mcw_supported(h.S, h.WPR, h.p.N, 0, h.p.L, h.p.Lz, h.p.cutoff * h.p.cutoff)) {
-        std::snprintf(name, (size_t)len, "smcx::sweep_kernel_mc64x4");
+        std::snprintf(name, (size_t)len, h.WPR == 4 ? "smcx::sweep_kernel_mc64x4" : "smcx::sweep_kernel_mc32x8");
         return SMCX_OK;
     }
     if (name && len > 0)

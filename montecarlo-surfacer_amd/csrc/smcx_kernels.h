@@ -51,7 +51,8 @@ bool mc_supported(int S, int WPR, int N, int M2, double L, double Lz, double cut
 bool mc_box_supported(double L, double Lz, double cutoff2);
 bool zordered_supported(int S, int WPR, int N, int M2, double L, double Lz, double cutoff2);
 bool mcw_supported(int S, int WPR, int N, int M2, double L, double Lz, double cutoff2);
-hipError_t launch_sweeps_mcw(const SweepArgs &s, const DevCtx &c, int nsweeps, double A, hipStream_t st, SweepTimer *tm);
+hipError_t launch_sweeps_mcw(const SweepArgs &s, const DevCtx &c, int WPR, int nsweeps, double A, hipStream_t st,
+                             SweepTimer *tm);
 void mc_bound_values(double L, double cutoff2, double *toFix, double *zsafe, int *negT, int *RZ);
 hipError_t launch_sweeps_ma(const SweepArgs &s, const DevCtx &c, int S, const double *wtab, int nsweeps, double A,
                             double toFix, double zFix, double zsafe, int negC, hipStream_t st, SweepTimer *tm);

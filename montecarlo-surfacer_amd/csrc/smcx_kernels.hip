@@ -830,7 +830,7 @@ hipError_t launch_sweeps(const DevCtx &c, int S, int WPR, int nsweeps, double A,
 #endif
     if (use_mx && mi_supported(S, WPR, c.L, c.Lz, c.cutoff2)) return launch_sweeps_mi(a, c, S, nsweeps, A, st, tm);
     if (use_mx && c.Rs && c.loc && mcw_supported(S, WPR, c.N, (c.flags & 0x1u) ? c.M2 : 0, c.L, c.Lz, c.cutoff2))
-        return launch_sweeps_mcw(a, c, nsweeps, A, st, tm);
+        return launch_sweeps_mcw(a, c, WPR, nsweeps, A, st, tm);
     hipError_t rc = tm ? tm->mark(st) : hipSuccess;
     if (rc != hipSuccess) return rc;
     if (use_mx) {

@@ -158,7 +158,20 @@ __global__ void __launch_bounds__(256, 1) sweep_kernel_mc64x4(MaArgs a)
         :
         : "memory", "vcc", "scc", "m0", SMCX_MA_SGPRS, SMCX_MA_V127);
 }
-constexpr unsigned mcw_lds_bytes() { return 4u * 2048u + 2u * 2048u; }
+// eight wavefronts per replica with 32 cells per lane each (the same generator output with NS = 32)
+__global__ void __launch_bounds__(512, 1) sweep_kernel_mc32x8(MaArgs a)
+{
+    unsigned lane = threadIdx.x & 63;
+    unsigned long long kp = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
+    unsigned rep = blockIdx.x;
+    unsigned wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    asm volatile(
+#include "smcx_sweep_mcw_body32.inc"
+        : "+v"(lane), "+s"(kp), "+s"(rep), "+s"(wv)
+        :
+        : "memory", "vcc", "scc", "m0", SMCX_MA_SGPRS, SMCX_MA_V95);
+}
+constexpr unsigned mcw_lds_bytes(int wpr) { return (unsigned)wpr * 2048u + 2u * (unsigned)wpr * 512u; }
 #endif
 #ifdef SMCX_CHECK
 constexpr unsigned mc_lds_bytes() { return 65u * 24u + 8u + 512u; }
@@ -330,7 +343,8 @@ bool mcw_supported(int S, int WPR, int N, int M2, double L, double Lz, double cu
 #endif
     static const char *env = getenv("SMCX_MCW"); // SMCX_MCW=0: sweep_kernel_mx for this geometry
     if (env && env[0] == '0') return false;
-    return S == 64 && WPR == 4 && N > 8192 && N <= 16384 && M2 + 1 <= 30 && mc_box_supported(L, Lz, cutoff2);
+    return ((S == 64 && WPR == 4) || (S == 32 && WPR == 8)) && N > 8192 && N <= 16384 && M2 + 1 <= 30 &&
+           mc_box_supported(L, Lz, cutoff2);
 }
 
 // does this geometry / box run a kernel with z-ordered cells (and need Rs, loc)?
@@ -342,7 +356,8 @@ bool zordered_supported(int S, int WPR, int N, int M2, double L, double Lz, doub
 
 #ifndef SMCX_CHECK
 // the multi-wave form has its own launcher: no int16-screen numbers are needed (the byte screen's come from mc_bound)
-hipError_t launch_sweeps_mcw(const SweepArgs &s, const DevCtx &c, int nsweeps, double A, hipStream_t st, SweepTimer *tm)
+hipError_t launch_sweeps_mcw(const SweepArgs &s, const DevCtx &c, int WPR, int nsweeps, double A, hipStream_t st,
+                             SweepTimer *tm)
 {
     MaArgs a;
     a.R = s.R; a.displ = s.displ; a.uni = s.uni; a.offs = s.offs; a.obs = s.obs; a.rec = s.rec;
@@ -362,7 +377,10 @@ hipError_t launch_sweeps_mcw(const SweepArgs &s, const DevCtx &c, int nsweeps, d
         a.sw0 = sw;
         hipError_t rc = tm ? tm->mark(st) : hipSuccess;
         if (rc != hipSuccess) return rc;
-        hipLaunchKernelGGL(sweep_kernel_mc64x4, dim3(c.nrep), dim3(256), mcw_lds_bytes(), st, a);
+        if (WPR == 4)
+            hipLaunchKernelGGL(sweep_kernel_mc64x4, dim3(c.nrep), dim3(256), mcw_lds_bytes(4), st, a);
+        else
+            hipLaunchKernelGGL(sweep_kernel_mc32x8, dim3(c.nrep), dim3(512), mcw_lds_bytes(8), st, a);
         rc = hipGetLastError();
         if (rc == hipSuccess && tm) rc = tm->mark(st);
         if (rc != hipSuccess) return rc;
@@ -370,7 +388,7 @@ hipError_t launch_sweeps_mcw(const SweepArgs &s, const DevCtx &c, int nsweeps, d
     return hipSuccess;
 }
 #else
-hipError_t launch_sweeps_mcw(const SweepArgs &, const DevCtx &, int, double, hipStream_t, SweepTimer *) { return hipErrorInvalidValue; }
+hipError_t launch_sweeps_mcw(const SweepArgs &, const DevCtx &, int, int, double, hipStream_t, SweepTimer *) { return hipErrorInvalidValue; }
 #endif
 
 void mc_bound(double L, double cutoff2, double *toFix, double *zsafe, int *negC, int *RZ);

@@ -40,7 +40,8 @@ def oracle_chains(O, s, seeds, R0, eq, nsw, gl, workers=16):
 @pytest.mark.parametrize("slots,waves,name", [
     (64, 4, "smcx::sweep_kernel_mc64x4"),                # 4 wavefronts x 64 cells per lane, z-ordered, byte screen: the
                                                          # geometry rule's choice at this N
-    (32, 8, "smcx::sweep_kernel_mx<32, 8, 3, false>"),   # the round-1 multi-wavefront tiling, 8 x 32
+    (32, 8, "smcx::sweep_kernel_mc32x8"),                # the same with 8 wavefronts x 32 cells (the rule's choice up to
+                                                         # 256 replicas per GPU)
 ])
 def test_config5_N16384_against_oracle(S, O, slots, waves, name):
     """BASELINE configs[4]: N=16384 + wall, fcc(16,16) (the reference's own dense lattice),

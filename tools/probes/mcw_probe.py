@@ -7,9 +7,10 @@ import smcx_loader, oracle_lib as O
 S = smcx_loader.load()
 T = A = 1.1
 nsw = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+slots, waves = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (64, 4)
 N, lat = 16384, (16, 16)
 R0 = O.fcc(*lat)
-p = S.default_params(N, 2, flags=S.FLAGS_REFERENCE | S.FLAG_SERIES, tune_slots=64, tune_waves=4)
+p = S.default_params(N, 2, flags=S.FLAGS_REFERENCE | S.FLAG_SERIES, tune_slots=slots, tune_waves=waves)
 eng = S.Engine(p); print(eng.kernel_form, eng.geometry, flush=True)
 eng.upload(R0, O.W_FIXTURE)
 eng.run(0, nsw, 1)

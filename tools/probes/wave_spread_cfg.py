@@ -7,7 +7,8 @@ import smcx_loader
 S = smcx_loader.load()
 N, nrep, Na, Nz = (int(v) for v in sys.argv[1:5])
 nsw = int(sys.argv[5]) if len(sys.argv) > 5 else 2
-p = S.default_params(N, nrep)
+slots, waves = (int(sys.argv[6]), int(sys.argv[7])) if len(sys.argv) > 7 else (0, 0)
+p = S.default_params(N, nrep, tune_slots=slots, tune_waves=waves)
 eng = S.Engine(p); print(eng.kernel_form, eng.geometry, flush=True)
 eng.upload(S.fcc_init(Na, Nz), S.W_REFERENCE)
 for k in range(2):
