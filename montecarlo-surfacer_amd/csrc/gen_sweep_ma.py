@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""gen_sweep_ma.py OUT.inc [NS [MODE]] -- writes the body of one hand-scheduled gfx950 sweep kernel (one
-`asm volatile` statement of smcx_sweep_ma.hip): ONE wavefront per replica with NS = 64, 32 or 16 particles
-per lane (32 NS < N <= 64 NS).  Same algorithm and the same arithmetic per pair as sweep_kernel_mi
+"""gen_sweep_ma.py OUT.inc [NS [MODE [WPR]]] -- writes the body of one hand-scheduled gfx950 sweep kernel (one
+`asm volatile` statement of smcx_sweep_ma.hip): one wavefront per replica with NS = 64, 32 or 16 particles
+per lane (32 NS < N <= 64 NS), or several (mode z8w).  Same algorithm and the same arithmetic per pair as sweep_kernel_mi
 (smcx_sweep_mi.hip: integer screen, fp64 decision and evaluation of every candidate, SMC.c:278-351); every
 instruction, register and wait is chosen here instead of by hipcc -- on this chip a wavefront's time is its
 instruction count.
@@ -16,6 +16,8 @@ MODE  kernel                what differs
  z8   sweep_kernel_mc<NS>   zb with ONE word per cell (int16 z | int8 x | int8 y, units of L/256), screened by
                             v_sub_u32 + v_dot4_i32_i8 + v_alignbit_b32; no z words in LDS -- the benchmark's kernel
  z8c  (diagnostic of z8)    the fp64 cutoff test of every cell beside every pass; counts unflagged pairs
+ z8w  sweep_kernel_mc64x4   z8 for 4 (NS = 64) or 8 (NS = 32) wavefronts per replica, 8192 < N <= 16384: every wave owns a
+      sweep_kernel_mc32x8   slab of the z order and runs the whole move loop; reductions completed across waves via LDS
 
 A move (iteration i of a run; particle n = first + i; ma: in register slot 0 of lane tl; zb/z8: in cell locA):
   B-COPY  probe B = current position of particle n+1: compact copy by v_readlane (ma: from its owner lane; zb: from
