@@ -69,6 +69,31 @@ def test_config5_N16384_against_oracle(S, O, slots, waves, name):
         assert np.array_equal(ob["zhist"][r], ref["zhist"])
 
 
+@pytest.mark.parametrize("slots,waves", [(64, 4), (32, 8)])
+def test_several_wavefront_kernel_with_many_accepted_moves(S, O, slots, waves):
+    """config 5's lattice is a crystal (66 of 16384 moves accepted per sweep).  The same N in the widest box the byte
+    screen serves (L = 48: fcc(16,16) at spacing 3, a third of the density) accepts thousands of moves per sweep, so
+    the cell writes by the owning wavefront, the widened group ranges and the row caches of all wavefronts are
+    exercised: 2 replicas x 2 sweeps against the oracle."""
+    L = 48.0
+    R0 = O.fcc(16, 16, L=L)
+    nsw, nrep = 2, 2
+    p = S.default_params(16384, nrep, L=L, flags=S.FLAGS_REFERENCE | S.FLAG_SERIES, tune_slots=slots, tune_waves=waves)
+    with S.Engine(p) as eng:
+        assert eng.kernel_form[1] == ("smcx::sweep_kernel_mc64x4" if waves == 4 else "smcx::sweep_kernel_mc32x8")
+        eng.upload(R0, O.W_FIXTURE)
+        eng.run(0, nsw, 1)
+        ob = eng.observables()
+        Es, jj = eng.series(nsw)
+        Rg = eng.positions()
+    refs = oracle_chains(O, sys_of(O, p), [12345 + r for r in range(nrep)], R0, 0, nsw, 1)
+    for r, ref in enumerate(refs):
+        assert np.array_equal(jj[r], ref["jj"]) and ref["jj"].min() > 1000, (jj[r], ref["jj"])
+        assert np.all(rel(Es[r], ref["E"], scale=1.0) < 1e-9), (Es[r], ref["E"])
+        assert np.abs(Rg[r] - ref["R"]).max() < 1e-8
+        assert np.array_equal(ob["zhist"][r], ref["zhist"])
+
+
 def test_config5_N16384_x256_invariants(S, O):
     """config 5 per GPU (2048 replicas / 8 GPUs = 256): the geometry rule's own choice, three sweeps:
     incremental energy = recomputed energy, histograms conserve particles, replica 0 = the oracle's."""
