@@ -72,7 +72,7 @@ ZBC = MODE == "zbc"                                       # diagnostic: every pa
 # probe, no z words in LDS).  The byte-wise squares alias |dz| >= 128 units; such cells are far outside the
 # cutoff, cost at most a wasted evaluation, and the group ranges keep them out of the passes anyway.
 # "z8c": its diagnostic build: the fp64 cutoff test of every cell beside every pass, counting unflagged pairs.
-PRIO = MODE != "z8w"                                      # issue priority from the SIMD neighbours' progress (one-wave zb kernels)
+PRIO = MODE != "z8w"                                      # issue priority from the SIMD neighbours' progress (one-wave kernels)
 PRIO_MODE = os.environ.get("SMCX_GEN_PRIO_MODE", "rotate")
 PRIO_SHIFT = int(os.environ.get("SMCX_GEN_PRIO_SHIFT", "14"))   # ... every 2^14 ticks of the 100 MHz clock (164 us)
 Z8C = MODE == "z8c"
@@ -513,7 +513,7 @@ def fill_p0(tag):
     s_mov_b64 exec, -1
     s_waitcnt lgkmcnt(0)
     """)
-    if ZB and PRIO:
+    if PRIO:
         # The SIMD's arbiter favours the oldest of its four wavefronts: left alone, one replica runs at nearly the
         # lone-wave rate and finishes after 7 ms while the youngest needs 13 and runs the last third of its sweep
         # alone on the SIMD.  So at every row (64 moves) a wavefront publishes its progress in a table row shared

@@ -339,12 +339,12 @@ extern "C" int smcx_create(const smcx_params *p, smcx_handle **out)
     CRT(hipMalloc((void **)&c.wtab, (size_t)(c.M2 + 1) * 4 * sizeof(double)));
     CRT(hipMalloc(&c.clk, nrep * 4 * sizeof(unsigned long long)));
     CRT(hipMemset(c.clk, 0, nrep * 4 * sizeof(unsigned long long)));
+    CRT(hipMalloc(&c.prio, 16384 * sizeof(unsigned))); // progress table of the SIMDs' wavefronts (hand-scheduled kernels)
+    CRT(hipMemset(c.prio, 0, 16384 * sizeof(unsigned)));
     if (zordered_supported(h.S, h.WPR, p->N, (p->flags & SMCX_FLAG_WALLS) ? c.M2 : 0, p->L, p->Lz, p->cutoff * p->cutoff)) {
         // cell-ordered copy of the positions and the cell of each particle (sweep_kernel_mb64 / mc*)
         CRT(hipMalloc(&c.Rs, nrep * (size_t)h.S * h.WPR * 64 * 3 * sizeof(double)));
         CRT(hipMalloc(&c.loc, nrep * N * sizeof(unsigned short)));
-        CRT(hipMalloc(&c.prio, 16384 * sizeof(unsigned)));
-        CRT(hipMemset(c.prio, 0, 16384 * sizeof(unsigned)));
     }
     CRT(hipMalloc(&h.d_save, nrep * sizeof(double)));
     CRT(hipMalloc(&h.d_tmp, nrep * sizeof(double)));
