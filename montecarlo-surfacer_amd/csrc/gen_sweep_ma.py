@@ -518,7 +518,8 @@ def fill_p0(tag):
         # lone-wave rate and finishes after 7 ms while the youngest needs 13 and runs the last third of its sweep
         # alone on the SIMD.  So at every row (64 moves) a wavefront publishes its progress in a table row shared
         # by the wavefronts of its SIMD (index from HW_ID / XCC_ID) and takes as its issue priority the number of
-        # its neighbours that are AHEAD of it.  Only speed depends on this table, never a result.
+        # its neighbours that are AHEAD of it (four levels; two levels -- the two behind get 1 -- measured 2.5 % slower).
+        # Only speed depends on this table, never a result.
         E(f"""
         s_load_dwordx2 {stp(4)}, {KARG}, {K_PRIO}
         s_getreg_b32 {st(0)}, hwreg(HW_REG_HW_ID)
