@@ -248,6 +248,30 @@ def test_thermalisation_and_E0_restart(S, O):
         eng.close()
 
 
+def test_thermalisation_at_the_benchmark_geometry(S, O):
+    """the same through sweep_kernel_mc64 (N=4096): 2 thermalisation sweeps at 2A, then 3 production sweeps with a
+    gather every 2 -- a launch group that ends mid-chunk, the E[0] restart, per-replica positions and explicit seeds"""
+    base = O.fcc(8, 16)
+    R0 = np.stack([base, np.roll(base.reshape(-1, 3), 11, axis=0).ravel()])
+    seeds = np.array([777, 2 ** 31 + 5], dtype=np.uint32)
+    p = S.default_params(4096, 2, flags=S.FLAGS_REFERENCE | S.FLAG_SERIES, tune_slots=64, tune_waves=1)
+    with S.Engine(p) as eng:
+        assert eng.kernel_form[1] == "smcx::sweep_kernel_mc64"
+        eng.upload(R0, O.W_FIXTURE, seeds)
+        eng.run(2, 3, 2)
+        ob = eng.observables()
+        Es, jj = eng.series(3)
+        ta = eng.therm_acceptance()
+    s = sys_of(O, p)
+    for r in range(2):
+        ref = O.chain(s, int(seeds[r]), R0[r], O.W_FIXTURE, T, A, 2, 3, 2, e0_restart=True)
+        assert np.array_equal(jj[r], ref["jj"]) and ref["jj"].sum() > 0
+        assert np.all(rel(Es[r], ref["E"], 1.0) < 1e-9)
+        assert abs(ta[r] - ref["therm_acceptance"]) < 1e-12
+        assert rel(ob["meanE"][r], ref["meanE"]) < 1e-9
+        assert np.array_equal(ob["zhist"][r], ref["zhist"])
+
+
 def test_explicit_seeds_and_per_replica_positions(S, O):
     rs = np.random.RandomState(2)
     base = O.fcc(4, 4)
