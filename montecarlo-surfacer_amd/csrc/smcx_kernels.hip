@@ -574,7 +574,8 @@ __global__ void __launch_bounds__(256) hist_kernel(DevCtx c)
                 if (*rb != cell) { atomicAdd(&c.Mu[(size_t)rep * Nc + cell], 1ull); *rb = cell; }
             }
         } else {
-            atomicAdd(&oob, 1u); // the reference writes out of bounds here
+            atomicAdd(&oob, 1u); // the reference writes D, Mu out of bounds here; its Rbin[n] = v is in bounds
+            if (c.D) c.Rbin[(size_t)rep * c.N + l] = cell;
         }
     }
     __syncthreads();

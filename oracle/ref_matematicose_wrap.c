@@ -7,8 +7,8 @@
  * standard headers that declare them (in the reference they arrive through
  * SMC.h:4-17), so the standard headers are included here first; vecBoxMuller's
  * prototype is the one SMC.h:93 gives it (it makes the C99 `inline` definition
- * an external one).  SMC.c itself cannot be built in this image: SMC.h:18,20
- * need <fftw3.h> and misccose.c, which do not exist here.
+ * an external one).  The hot-path functions of SMC.c are built separately:
+ * ref_smc_prelude.c / ref_smc_wrap.c / build_ref.sh.
  */
 #include <stdbool.h>
 #include <stddef.h>

@@ -389,9 +389,10 @@ void orc_local_density(const orc_sys *s, const double *r, uint64_t *D,
         int j = cell8((r[3 * n + 1] / s->L + .5) * Ncx);
         int k = cell8((r[3 * n + 2] / s->Lz + .5) * Ncz);
         int v = i * Ncx * Ncz + j * Ncz + k;
-        if (v >= Nc) { /* the reference writes out of bounds here */
-            if (oob)
+        if (v >= Nc) { /* the reference writes D[v], Mu[v] out of bounds here: not stored, counted; */
+            if (oob)   /* Rbin[n] = v is in bounds and kept, so the next in-range visit bumps Mu */
                 (*oob)++;
+            Rbin[n] = v;
             continue;
         }
         D[v]++;
@@ -424,11 +425,37 @@ int orc_chain_p(const orc_sys *s, unsigned int seed, double *R, const double *W,
                          jj_out, zhist, D_out, Mu_out, P_gathers, 0, 0.0, NULL, res);
 }
 
+static int chain_impl(const orc_sys *s, unsigned int seed, double *R, const double *W,
+                  double T, double A, int eqsteps, int maxsteps, int gather_lapse,
+                  unsigned int flags, double *E_series, int32_t *jj_out, uint64_t *zhist,
+                  uint64_t *D_out, uint64_t *Mu_out, double *P_gathers, int lca_time,
+                  double lca_cutoff, orc_lca_counts *lca, orc_chain_result *res, int32_t *jt_out);
+
 int orc_chain_lca(const orc_sys *s, unsigned int seed, double *R, const double *W,
                   double T, double A, int eqsteps, int maxsteps, int gather_lapse,
                   unsigned int flags, double *E_series, int32_t *jj_out, uint64_t *zhist,
                   uint64_t *D_out, uint64_t *Mu_out, double *P_gathers, int lca_time,
                   double lca_cutoff, orc_lca_counts *lca, orc_chain_result *res)
+{
+    return chain_impl(s, seed, R, W, T, A, eqsteps, maxsteps, gather_lapse, flags, E_series, jj_out,
+                      zhist, D_out, Mu_out, P_gathers, lca_time, lca_cutoff, lca, res, NULL);
+}
+
+int orc_chain_jt(const orc_sys *s, unsigned int seed, double *R, const double *W,
+                 double T, double A, int eqsteps, int maxsteps, int gather_lapse,
+                 unsigned int flags, double *E_series, int32_t *jj_out, int32_t *jt_out,
+                 uint64_t *zhist, uint64_t *D_out, uint64_t *Mu_out, double *P_gathers,
+                 orc_chain_result *res)
+{
+    return chain_impl(s, seed, R, W, T, A, eqsteps, maxsteps, gather_lapse, flags, E_series, jj_out,
+                      zhist, D_out, Mu_out, P_gathers, 0, 0.0, NULL, res, jt_out);
+}
+
+static int chain_impl(const orc_sys *s, unsigned int seed, double *R, const double *W,
+                  double T, double A, int eqsteps, int maxsteps, int gather_lapse,
+                  unsigned int flags, double *E_series, int32_t *jj_out, uint64_t *zhist,
+                  uint64_t *D_out, uint64_t *Mu_out, double *P_gathers, int lca_time,
+                  double lca_cutoff, orc_lca_counts *lca, orc_chain_result *res, int32_t *jt_out)
 {
     const int N = s->N;
     int32_t *LCA = NULL;
@@ -502,6 +529,7 @@ int orc_chain_lca(const orc_sys *s, unsigned int seed, double *R, const double *
         res->meanE = sum / len;
         double var = sum2 / len - (sum / len) * (sum / len);
         res->dE = sqrt(var);
+        res->cv = var / (T * T); /* SMC.c:250 */
         int64_t acc = 0; /* intmean sums in int (overflow past 2^31), fenced */
         for (int n = 0; n < maxsteps; n++)
             acc += jj[n];
@@ -520,6 +548,8 @@ int orc_chain_lca(const orc_sys *s, unsigned int seed, double *R, const double *
     }
     if (jj_out)
         memcpy(jj_out, jj, (size_t)maxsteps * sizeof(int32_t));
+    if (jt_out)
+        memcpy(jt_out, jt, (size_t)eqsteps * sizeof(int32_t));
     if (zhist) { /* wall-normal profile: sum over i,j of D[i][j][k] (plotting.jl:134-166) */
         memset(zhist, 0, (size_t)s->Ncz * sizeof(uint64_t));
         for (size_t v = 0; v < Nc; v++)

@@ -12,16 +12,15 @@
  * SMC.h:26,29).  Build with -O2 -ffp-contract=off so the arithmetic is the
  * reference's own (no FMA contraction).
  *
- * PARITY PIN STATUS (see oracle/README.md and DESIGN.md):
- *   - the reference's SMC.c / SMC_noMPI_noWall.c are UNBUILDABLE in this image
- *     (they need <fftw3.h> and misccose.c, both absent; stand-ins are not
- *     allowed), and the reference ships no tests, fixtures or golden vectors;
- *   - pinned on: (a) the real glibc srand()/rand() of this image, (b) the real
- *     reference vecBoxMuller/mean/intmean/variance compiled from
- *     /root/reference/matematicose.c into oracle/_ref/, (c) outputs of the
- *     real reference recorded in SURVEY.md (E0 of four lattices, the wall
- *     fixture W, a 20-sweep N=108 chain, acceptance ratios, the noWall
- *     E0/energySingle values).
+ * PARITY PIN STATUS (see oracle/README.md and DESIGN.md section 2): PINNED on the real reference.
+ *   oracle/build_ref.sh compiles the hot-path line ranges of the real SMC.c and
+ *   SMC_noMPI_noWall.c (and the whole matematicose.c) from /root/reference where they lie into
+ *   oracle/_ref/, one library per compile-time N; tests/test_ref_pin.py demands bit-identical
+ *   outputs of every orc_* function on the committed fixtures tests/golden/ref_smc.json
+ *   (generated from those libraries) and live where the libraries are present.  Not pinned on
+ *   reference code: the FFT autocorrelation (fft_acf needs FFTW, absent: numpy restatement in
+ *   tests/oracle_lib.py), and sMC itself (needs FFTW and misccose.c; its loop is replayed around
+ *   the real functions).
  */
 #ifndef SMC_ORACLE_H
 #define SMC_ORACLE_H
@@ -113,6 +112,7 @@ typedef struct orc_chain_result {
     uint64_t accepted;       /* sum of jj */
     uint64_t gathers;        /* number of histogram calls */
     uint64_t oob;            /* histogram cells out of range */
+    double cv;               /* variance(E)/T^2 (SMC.c:250) */
 } orc_chain_result;
 
 #define ORC_FLAG_E0_RESTART 1u /* production energy series restarts from E[0] (SMC.c:194) */
@@ -130,6 +130,14 @@ int orc_chain_p(const orc_sys *s, unsigned int seed, double *R, const double *W,
                 double T, double A, int eqsteps, int maxsteps, int gather_lapse,
                 unsigned int flags, double *E_series, int32_t *jj, uint64_t *zhist,
                 uint64_t *D, uint64_t *Mu, double *P_gathers, orc_chain_result *res);
+
+/* orc_chain_p that also returns the accepted counts of the thermalisation sweeps (jt of
+ * SMC.c:51,117; eqsteps entries, may be NULL) */
+int orc_chain_jt(const orc_sys *s, unsigned int seed, double *R, const double *W,
+                 double T, double A, int eqsteps, int maxsteps, int gather_lapse,
+                 unsigned int flags, double *E_series, int32_t *jj, int32_t *jt,
+                 uint64_t *zhist, uint64_t *D, uint64_t *Mu, double *P_gathers,
+                 orc_chain_result *res);
 
 /* ---- common-neighbour cluster analysis -------------------- */
 /* clusterAnalysis, SMC.c:971-1045: LCA[3*idx+{0,1,2}] = num1,num2,num3 of pair entry idx,

@@ -50,7 +50,7 @@ class OrcChainResult(C.Structure):
     _fields_ = [("E0", C.c_double), ("meanE", C.c_double), ("dE", C.c_double),
                 ("acceptance_ratio", C.c_double), ("therm_acceptance", C.c_double),
                 ("Efinal", C.c_double), ("accepted", C.c_uint64), ("gathers", C.c_uint64),
-                ("oob", C.c_uint64)]
+                ("oob", C.c_uint64), ("cv", C.c_double)]
 
 
 TRACE_DTYPE = np.dtype([("n", "i4"), ("accepted", "i4"), ("Um", "f8"), ("Fm", "f8", 3),
@@ -117,6 +117,11 @@ def lib():
                                                                  C.POINTER(OrcLcaCounts),
                                                                  C.POINTER(OrcChainResult)]
         L.orc_chain_lca.restype = C.c_int
+        L.orc_chain_jt.argtypes = [sp, C.c_uint, _dp, _dp, C.c_double, C.c_double, C.c_int, C.c_int,
+                                   C.c_int, C.c_uint, _dp, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                                   C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
+                                   C.POINTER(C.c_uint64), _dp, C.POINTER(OrcChainResult)]
+        L.orc_chain_jt.restype = C.c_int
         L.orc_cluster_analysis.argtypes = [C.c_int, _dp, C.c_double, C.c_double,
                                            C.POINTER(C.c_int32), C.POINTER(C.c_uint64)]
         L.orc_cluster_analysis.restype = None
@@ -272,6 +277,28 @@ def chain(s, seed, R0, W, T, A, eqsteps, maxsteps, gather_lapse, e0_restart=True
                       overflow=int(lca.overflow))
     out.update(R=R, E=E, jj=jj[:maxsteps], zhist=zh, D=D, Mu=Mu,
                P=None if P is None else P[:maxsteps // gather_lapse])
+    return out
+
+
+def chain_jt(s, seed, R0, W, T, A, eqsteps, maxsteps, gather_lapse):
+    """the chain with everything sMC keeps: E[], jj[], jt[], D, Mu, P per gather, final reductions"""
+    R = np.array(R0, dtype=np.float64, copy=True)
+    E = np.zeros(maxsteps + 1)
+    jj = np.zeros(max(maxsteps, 1), dtype=np.int32)
+    jt = np.zeros(max(eqsteps, 1), dtype=np.int32)
+    zh = np.zeros(s.Ncz, dtype=np.uint64)
+    Nc = s.Ncx * s.Ncx * s.Ncz
+    D = np.zeros(Nc, dtype=np.uint64)
+    Mu = np.zeros(Nc, dtype=np.uint64)
+    P = np.zeros(max(maxsteps // gather_lapse, 1))
+    res = OrcChainResult()
+    rc = lib().orc_chain_jt(C.byref(s), seed, _ptr(R), _ptr(W), T, A, eqsteps, maxsteps, gather_lapse, 1,
+                            _ptr(E), _ptr(jj, C.c_int32), _ptr(jt, C.c_int32), _ptr(zh, C.c_uint64),
+                            _ptr(D, C.c_uint64), _ptr(Mu, C.c_uint64), _ptr(P), C.byref(res))
+    assert rc == 0
+    out = {k: getattr(res, k) for k, _ in OrcChainResult._fields_}
+    out.update(R=R, E=E, jj=jj[:maxsteps], jt=jt[:eqsteps], zhist=zh, D=D, Mu=Mu,
+               P=P[:maxsteps // gather_lapse])
     return out
 
 

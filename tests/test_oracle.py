@@ -1,9 +1,10 @@
 """CPU tests: the oracle against every pin available for this path.
 
-The reference ships no tests or fixtures and its SMC.c
-cannot be built in this image, so the pins are: the real glibc rand(), the real
-reference matematicose.c (golden file generated from oracle/_ref), and outputs
-of the real reference recorded in SURVEY.md (tests/golden/reference_pins.json).
+The reference ships no tests or fixtures.  The pins in this file: the real
+glibc rand(), the real reference matematicose.c (golden file generated from oracle/_ref), and
+outputs of the real reference recorded in SURVEY.md (tests/golden/reference_pins.json).  The
+bit-for-bit pin of every hot-path function on the real SMC.c / SMC_noMPI_noWall.c (compiled where
+they lie into oracle/_ref) is tests/test_ref_pin.py.
 """
 import ctypes as C
 import json

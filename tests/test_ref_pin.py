@@ -1,0 +1,99 @@
+"""CPU tests: the oracle (oracle/smc_oracle.c) against the REAL reference, bit for bit.
+
+oracle/build_ref.sh compiles the hot-path line ranges of /root/reference/SMC.c and
+SMC_noMPI_noWall.c where they lie (one library per compile-time N, nothing copied to disk) into
+oracle/_ref/.  tests/golden/ref_smc.json holds their outputs on tests/ref_cases.GOLDEN_CASES
+(generator: tests/golden/make_ref_golden.py); these tests run the same cases through the oracle
+and demand identical bits: K1-K4 values, K5 totals, pressure, whole chains through
+oneParticleMoves with sMC's loop (energy series, accepted counts of every sweep, final positions,
+full density/mobility histograms, results.E/dE/acceptance_ratio/cv), initializeBox,
+initializeWalls, clusterAnalysis, and the noWall variant's sweep (BASELINE config 1).
+Where oracle/_ref is present (the build container; it also travels to the GPU box as prebuilt
+.so files) a second, larger set is compared live.
+"""
+import json
+import os
+
+import pytest
+
+import ref_cases as RC
+import ref_lib
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = json.load(open(os.path.join(HERE, "golden", "ref_smc.json")))
+
+
+def _ident(i):
+    c = GOLD["cases"][i]["case"]
+    return "%s-N%d-%d" % (c["kind"], c["N"], i)
+
+
+def _tuplify(c):
+    c = dict(c)
+    if "start" in c:
+        c["start"] = tuple(c["start"])
+    return c
+
+
+def test_golden_file_describes_the_cases_of_this_tree():
+    assert [_tuplify(e["case"]) for e in GOLD["cases"]] == [dict(c) for c in RC.GOLDEN_CASES]
+
+
+def _diff(exp, got, path=""):
+    """first differing leaf, for a readable failure"""
+    if isinstance(exp, dict):
+        for k in exp:
+            d = _diff(exp[k], got.get(k), path + "/" + k)
+            if d:
+                return d
+        return None
+    if isinstance(exp, list) and isinstance(got, list) and len(exp) == len(got):
+        for k, (a, b) in enumerate(zip(exp, got)):
+            d = _diff(a, b, "%s[%d]" % (path, k))
+            if d:
+                return d
+        return None
+    return None if exp == got else "%s: reference %r, oracle %r" % (path, exp, got)
+
+
+@pytest.fixture(scope="module")
+def oracle_backend():
+    return RC.OracleBackend()
+
+
+@pytest.mark.parametrize("i", range(len(GOLD["cases"])), ids=_ident)
+def test_oracle_reproduces_the_real_reference_bit_for_bit(oracle_backend, i):
+    entry = GOLD["cases"][i]
+    got = RC.compute(oracle_backend, [_tuplify(entry["case"])])[0]
+    assert _diff(entry["expect"], got) is None
+
+
+_have_ref = all(ref_lib.available(n) for n in (108, 256, 1024, 4096)) and ref_lib.available(256, nw=True)
+
+
+@pytest.mark.skipif(not _have_ref, reason="oracle/_ref not built (no reference tree and no prebuilt libraries)")
+@pytest.mark.parametrize("seed0", [1, 2])
+def test_oracle_against_the_reference_libraries_live(oracle_backend, seed0):
+    cases = RC.live_cases(seed0)
+    ref = RC.compute(RC.RefBackend(), cases)
+    got = RC.compute(oracle_backend, cases)
+    for c, a, b in zip(cases, ref, got):
+        assert _diff(a, b) is None, c
+
+
+@pytest.mark.skipif(not _have_ref, reason="oracle/_ref not built")
+def test_reference_libraries_are_the_reference(oracle_backend):
+    """the libraries report the macros of SMC.h:26-58 and reproduce what SURVEY 8c recorded from the
+    survey-time build of the whole reference: the wall fixture and the 20-sweep N=108 chain"""
+    import numpy as np
+    import oracle_lib as O
+    r = ref_lib.RefSMC(108)
+    assert (r.N, r.M, r.ncx, r.ncz, r.cutoff) == (108, 3, 33, 33, 3.0)
+    assert (r.a0, r.b0) == (O.A0_PLANE, O.B0_PLANE)
+    W = r.initialize_walls()
+    assert np.array_equal(W, O.W_FIXTURE)
+    X = r.initialize_box(33.0, 200.0)
+    E0 = r.energy(X, 33.0) + r.walls_energy(X, W, 33.0, 200.0)
+    assert r.walls_energy(X, W, 33.0, 200.0) == -4.0581627260515186e-14
+    E, jj = r.sweeps(12345, X, W, 33.0, 200.0, 1.1, 1.1, 20, E0)
+    assert E[-1] == -3.8631457699032183 and int(jj.sum()) == 2048
