@@ -57,6 +57,19 @@ extern "C" {
 #define SMCX_FLAG_PRESSURE 0x10u   /* evaluate pressure + wallsPressure at every gather (SMC.c:140) */
 #define SMCX_FLAGS_REFERENCE (SMCX_FLAG_WALLS | SMCX_FLAG_E0_RESTART)
 
+/* smcx_params.tune_kernel: measurement switch, not needed in normal use.  The screened sweep kernels are a ladder,
+ * each rung a faster form of the same algorithm with identical results to rounding; a value >= 3 stops the choice at
+ * that rung (where the geometry and box allow it at all).  SMCX_KERNEL_MA is the last rung whose screen visits EVERY
+ * cell for every probe, as the reference's loops do (SMC.c:563-578): the like-for-like "all pairs" kernel. */
+#define SMCX_KERNEL_AUTO 0
+#define SMCX_KERNEL_FP64 1     /* sweep_kernel / sweep_kernel_lead: positions and tests in fp64 */
+#define SMCX_KERNEL_SCREENED 2
+#define SMCX_KERNEL_MX 3       /* sweep_kernel_mx: int16 x,y + fp32/fp16 z screen, any number of wavefronts */
+#define SMCX_KERNEL_MI 4       /* sweep_kernel_mi: all-integer screen, one wavefront per replica */
+#define SMCX_KERNEL_MA 5       /* sweep_kernel_ma16/32/64: the same, hand-scheduled */
+#define SMCX_KERNEL_MB 6       /* sweep_kernel_mb64: cells in z order, only groups in reach are screened */
+#define SMCX_KERNEL_MC 7       /* sweep_kernel_mc16/32/64, mc64x4, mc32x8: one word per cell (default where built) */
+
 typedef struct smcx_params {
     int32_t N;       /* particles per replica            (SMC.h:29)  even, >= 2 */
     int32_t M;       /* wall sites per side, M*M total   (SMC.h:26)  M*M+1 <= 30 */
@@ -74,7 +87,9 @@ typedef struct smcx_params {
     int32_t tune_slots;     /* 0 = auto; else particles per lane (1,2,4,...,64) */
     int32_t tune_waves;     /* 0 = auto; else wavefronts per replica (1,2,4,8,16) */
     int32_t lca_time;       /* LCA_TIME: cluster analysis every lca_time-th gather (SMC.h:48) */
-    int32_t tune_kernel;    /* 0 = auto; 1 = fp64 sweep kernels; 2 = screened (compact-copy) sweep kernel */
+    int32_t tune_kernel;    /* SMCX_KERNEL_*: 0 = auto; 1 = fp64 sweep kernels; 2 = screened (compact-copy) sweep
+                               kernels, best form; 3..7 = the best screened form not above that rung */
+    int32_t tune_resort;    /* 0/1 = sort the cells by z before every sweep (z-ordered kernels); k = every k sweeps */
     double lca_cutoff;      /* LCA_cutoff (SMC.h:50) */
 } smcx_params;
 

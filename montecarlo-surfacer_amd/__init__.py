@@ -21,6 +21,7 @@ OK, ERR_PARAM, ERR_HIP, ERR_STATE, ERR_NOMEM, ERR_UNSUPPORTED, ERR_NODEVICE = ra
 FLAG_WALLS, FLAG_E0_RESTART, FLAG_SERIES, FLAG_FULL_HIST, FLAG_PRESSURE, FLAG_CLUSTERS = 1, 2, 4, 8, 16, 32
 FLAGS_REFERENCE = FLAG_WALLS | FLAG_E0_RESTART
 OBS_RECORD_DOUBLES = 8
+KERNEL_AUTO, KERNEL_FP64, KERNEL_SCREENED, KERNEL_MX, KERNEL_MI, KERNEL_MA, KERNEL_MB, KERNEL_MC = range(8)
 
 
 class Params(C.Structure):
@@ -31,7 +32,8 @@ class Params(C.Structure):
                 ("Ncx", C.c_int32), ("Ncz", C.c_int32), ("flags", C.c_uint32),
                 ("base_seed", C.c_uint32), ("first_replica", C.c_uint32),
                 ("tune_slots", C.c_int32), ("tune_waves", C.c_int32),
-                ("lca_time", C.c_int32), ("tune_kernel", C.c_int32), ("lca_cutoff", C.c_double)]
+                ("lca_time", C.c_int32), ("tune_kernel", C.c_int32), ("tune_resort", C.c_int32),
+                ("lca_cutoff", C.c_double)]
 
 
 class SmcxError(RuntimeError):

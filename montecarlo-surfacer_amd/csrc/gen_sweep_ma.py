@@ -520,10 +520,15 @@ def fill_p0(tag):
         # by the wavefronts of its SIMD (index from HW_ID / XCC_ID) and takes as its issue priority the number of
         # its neighbours that are AHEAD of it (four levels; two levels -- the two behind get 1 -- measured 2.5 % slower).
         # Only speed depends on this table, never a result.
+        # Row index (16-byte rows, 4096 rows = the 64 KB table of smcx_create): HW_ID[14:8] (CU_ID 4 bits, SH_ID 1, SE_ID 2)
+        # << 4 | HW_ID[5:4] (SIMD_ID) << 2 ... in words: bits 4-10, 2-3, and XCC_ID (3 bits, MI355X has 8 XCDs) in bits
+        # 11-13; the slot inside the row is HW_ID[1:0] (WAVE_ID & 3).  Every field is read with its exact width, so the
+        # store below stays inside the table whatever the registers hold; wavefronts whose WAVE_IDs alias modulo 4 share
+        # a slot and only blunt the heuristic.
         E(f"""
         s_load_dwordx2 {stp(4)}, {KARG}, {K_PRIO}
         s_getreg_b32 {st(0)}, hwreg(HW_REG_HW_ID)
-        s_getreg_b32 {st(1)}, hwreg(HW_REG_XCC_ID, 0, 4)
+        s_getreg_b32 {st(1)}, hwreg(HW_REG_XCC_ID, 0, 3)
         s_bfe_u32 {st(2)}, {st(0)}, 0x70008
         s_lshl_b32 {st(2)}, {st(2)}, 4
         s_bfe_u32 {st(3)}, {st(0)}, 0x20004

@@ -24,6 +24,7 @@ struct Handle {
     smcx_params p;
     DevCtx c;
     int S = 0, WPR = 0;
+    KernelPlan plan;        // the sweep kernel of this handle, fixed at smcx_create (plan_kernel)
     int chunk = 1;          // sweeps of random numbers per pre-pass launch
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -36,7 +37,6 @@ struct Handle {
     double last_sweep_ms = 0.0; // sweep kernels only
     int last_launches = 0;
     SweepTimer timer;            // start/stop events around every launch of the sweep kernel
-    std::vector<int> last_sweeps; // sweeps in each launch of the last run
     int last_gathers = 0;
     // cluster analysis (SMCX_FLAG_CLUSTERS or on demand)
     unsigned *lca_bits = nullptr;          // [lca_batch][lca_words]
@@ -175,7 +175,8 @@ static int validate(const smcx_params *p)
     if (!(p->L > 0) || !(p->Lz > 0) || !(p->T > 0) || !(p->A > 0) || !(p->cutoff > 0))
         return SMCX_ERR_PARAM;
     if (p->Ncx < 1 || p->Ncz < 1 || p->Ncx > 255 || p->Ncz > 255) return SMCX_ERR_PARAM;
-    if (p->tune_kernel < 0 || p->tune_kernel > 2) return SMCX_ERR_PARAM;
+    if (p->tune_kernel < 0 || p->tune_kernel > SMCX_KERNEL_MC) return SMCX_ERR_PARAM;
+    if (p->tune_resort < 0 || p->tune_resort > 1024) return SMCX_ERR_PARAM;
     if (p->flags & SMCX_FLAG_WALLS) {
         if (p->M < 1) return SMCX_ERR_PARAM;
         if (p->M * p->M + 1 > 30) return SMCX_ERR_UNSUPPORTED;
@@ -187,14 +188,64 @@ static int validate(const smcx_params *p)
 
 // particles per lane (S) and wavefronts per replica (WPR): the smallest capacity 64*WPR*S
 // that holds N from a table of the geometries measured fastest on MI355X.
-static int choose_geometry(const smcx_params *p, int *S, int *WPR)
+// The measurement switches of the sweep kernels.  They are smcx_params fields (tune_kernel, tune_resort); the SMCX_*
+// environment variables of rounds 1-2 still exist for tools/ and A/B sessions, but only under
+// SMCX_ALLOW_ENV_TUNING=1: without it a set variable makes smcx_create fail instead of silently changing the kernel
+// a caller gets.
+static const char *const k_tune_env[] = {"SMCX_MX", "SMCX_MI", "SMCX_MA", "SMCX_MB", "SMCX_MC", "SMCX_MCW", "SMCX_MZ",
+                                         "SMCX_RESORT", "SMCX_ZSORT_TPB", "SMCX_LEAD", "SMCX_NO_LEAD"};
+
+static int make_tune(const smcx_params *p, Tune *t)
 {
+    *t = Tune();
+    t->kernel = p->tune_kernel;
+    t->resort = p->tune_resort > 0 ? p->tune_resort : 1;
+    if (const char *e = getenv("SMCX_CHECK_MB")) t->check_mb = atoi(e); // read by the diagnostic build only (ma_cap)
+    const char *allow = getenv("SMCX_ALLOW_ENV_TUNING");
+    if (!(allow && allow[0] == '1')) {
+        for (const char *name : k_tune_env)
+            if (getenv(name)) {
+                g_last_error = std::string("environment variable ") + name +
+                               " is set but SMCX_ALLOW_ENV_TUNING=1 is not: refusing to let a stale measurement "
+                               "switch pick the kernel (use smcx_params.tune_kernel / tune_resort)";
+                return SMCX_ERR_PARAM;
+            }
+        return SMCX_OK;
+    }
+    auto off = [](const char *n) { const char *e = getenv(n); return e && e[0] == '0'; };
+    if (t->kernel == 0) {
+        if (const char *e = getenv("SMCX_MX")) t->kernel = (e[0] == '0') ? 1 : 2;
+    }
+    if (t->kernel == 0 || t->kernel == 2) { // each switch steps one rung down the ladder of plan_kernel
+        int cap = FORM_MC;
+        if (off("SMCX_MC")) cap = FORM_MB;
+        if (off("SMCX_MB")) cap = FORM_MA;
+        if (off("SMCX_MA")) cap = FORM_MI;
+        if (off("SMCX_MI")) cap = FORM_MX;
+        if (cap != FORM_MC) t->kernel = cap;
+    }
+    if (getenv("SMCX_NO_LEAD")) t->lead = 0;
+    if (getenv("SMCX_LEAD")) t->lead = 1;
+    if (const char *e = getenv("SMCX_MZ")) t->mz = (e[0] != '0');
+    if (const char *e = getenv("SMCX_RESORT")) { const int v = atoi(e); if (v > 0) t->resort = v; }
+    if (const char *e = getenv("SMCX_ZSORT_TPB")) { const int v = atoi(e); if (v == 128 || v == 256 || v == 512 || v == 1024) t->zsort_tpb = v; }
+    return SMCX_OK;
+}
+
+static bool plan_for(const smcx_params *p, int s, int w, const Tune &t, KernelPlan *pl)
+{
+    return plan_kernel(p->N, (p->flags & SMCX_FLAG_WALLS) ? p->M * p->M : 0, p->L, p->Lz, p->cutoff * p->cutoff, s, w, t, pl);
+}
+
+static int choose_geometry(const smcx_params *p, const Tune &t, int *S, int *WPR)
+{
+    KernelPlan pl;
     if (p->tune_slots > 0 || p->tune_waves > 0) {
         int s = p->tune_slots > 0 ? p->tune_slots : 16;
         int w = p->tune_waves > 0 ? p->tune_waves : 1;
         if (!geometry_supported(s, w) || (long)s * w * 64 < p->N) return SMCX_ERR_UNSUPPORTED;
         if (p->tune_kernel == 1 && !fp64_supported(s, w)) return SMCX_ERR_UNSUPPORTED;
-        if (p->tune_kernel == 2 && !mx_supported(s, w)) return SMCX_ERR_UNSUPPORTED;
+        if (p->tune_kernel >= 2 && !mx_supported(s, w)) return SMCX_ERR_UNSUPPORTED;
         *S = s; *WPR = w;
         return SMCX_OK;
     }
@@ -208,15 +259,15 @@ static int choose_geometry(const smcx_params *p, int *S, int *WPR)
     auto pow2_at_least = [](long v) { int r = 1; while (r < v) r *= 2; return r; };
     int s, w;
     const bool fp64_only = (p->tune_kernel == 1);
-    if (!fp64_only && (p->N > 512 || p->tune_kernel == 2)) {
+    if (!fp64_only && (p->N > 512 || p->tune_kernel >= 2)) {
         s = pow2_at_least((p->N + 63) / 64); w = 1;
         if (s < 16) s = 16;
         while (s > 64) { s /= 2; w *= 2; }
         // one wavefront per replica has hand-scheduled kernels (sweep_kernel_mc*/mb64/ma*) that beat any split over
         // several wavefronts even with few replicas (N = 2048: 3.1-3.6 ms per sweep against 5.2-9.0 for 16 x 2 at
         // 128..1024 replicas, tools/probes/geom_rule.py); the split stays for boxes those kernels do not serve
-        bool one_wave = (w == 1) && mi_supported(s, 1, p->L, p->Lz, p->cutoff * p->cutoff);
-        if (mcw_supported(s, w, p->N, 0, p->L, p->Lz, p->cutoff * p->cutoff)) { // its several-wave forms: 64 x 4, or
+        bool one_wave = (w == 1) && plan_for(p, s, 1, t, &pl) && pl.form >= FORM_MI;
+        if (w > 1 && plan_for(p, s, w, t, &pl) && pl.form == FORM_MC) {          // its several-wave forms: 64 x 4, or
             one_wave = true;                                                     // 32 x 8 while the chip has room
             if ((long)p->nrep * 8 <= 2048) { s = 32; w = 8; }                    // (44.6 against 47.3 ms per sweep at 256)
         }
@@ -285,6 +336,9 @@ extern "C" int smcx_create(const smcx_params *p, smcx_handle **out)
     *out = nullptr;
     int rc = validate(p);
     if (rc != SMCX_OK) return rc;
+    Tune tune; // (before the device is looked for: a stale measurement switch is refused on any machine)
+    rc = make_tune(p, &tune);
+    if (rc != SMCX_OK) return rc;
     int ndev = 0;
     rc = smcx_device_count(&ndev);
     if (rc != SMCX_OK) return rc;
@@ -295,7 +349,8 @@ extern "C" int smcx_create(const smcx_params *p, smcx_handle **out)
     Handle &h = hh->h;
     h.p = *p;
     std::memset(&h.c, 0, sizeof(h.c));
-    rc = choose_geometry(p, &h.S, &h.WPR);
+    rc = choose_geometry(p, tune, &h.S, &h.WPR);
+    if (rc == SMCX_OK && !plan_for(p, h.S, h.WPR, tune, &h.plan)) rc = SMCX_ERR_UNSUPPORTED;
     if (rc != SMCX_OK) { delete hh; return rc; }
 
     // sweeps of random numbers kept on the device at once: bounded by ~6 GB
@@ -339,9 +394,11 @@ extern "C" int smcx_create(const smcx_params *p, smcx_handle **out)
     CRT(hipMalloc((void **)&c.wtab, (size_t)(c.M2 + 1) * 4 * sizeof(double)));
     CRT(hipMalloc(&c.clk, nrep * 4 * sizeof(unsigned long long)));
     CRT(hipMemset(c.clk, 0, nrep * 4 * sizeof(unsigned long long)));
-    CRT(hipMalloc(&c.prio, 16384 * sizeof(unsigned))); // progress table of the SIMDs' wavefronts (hand-scheduled kernels)
+    // progress table of the SIMDs' wavefronts (hand-scheduled kernels): 8 XCDs x 128 (SE, SH, CU) x 4 SIMDs rows of
+    // 4 words; the kernels build the index from exact-width register fields (gen_sweep_ma.py, PRIO)
+    CRT(hipMalloc(&c.prio, 16384 * sizeof(unsigned)));
     CRT(hipMemset(c.prio, 0, 16384 * sizeof(unsigned)));
-    if (zordered_supported(h.S, h.WPR, p->N, (p->flags & SMCX_FLAG_WALLS) ? c.M2 : 0, p->L, p->Lz, p->cutoff * p->cutoff)) {
+    if (h.plan.zordered()) {
         // cell-ordered copy of the positions and the cell of each particle (sweep_kernel_mb64 / mc*)
         CRT(hipMalloc(&c.Rs, nrep * (size_t)h.S * h.WPR * 64 * 3 * sizeof(double)));
         CRT(hipMalloc(&c.loc, nrep * N * sizeof(unsigned short)));
@@ -413,16 +470,8 @@ extern "C" int smcx_kernel_form(const smcx_handle *hh, int *form, char *name, in
 {
     if (!hh) return SMCX_ERR_PARAM;
     const Handle &h = hh->h;
-    const bool mx = sweep_uses_mx(h.S, h.WPR, h.p.tune_kernel);
-    if (form) *form = mx ? 2 : 1;
-    const bool mi = mx && mi_supported(h.S, h.WPR, h.p.L, h.p.Lz, h.p.cutoff * h.p.cutoff);
-    if (mx && name && len > 0 && h.c.Rs && mcw_supported(h.S, h.WPR, h.p.N, 0, h.p.L, h.p.Lz, h.p.cutoff * h.p.cutoff)) {
-        std::snprintf(name, (size_t)len, h.WPR == 4 ? "smcx::sweep_kernel_mc64x4" : "smcx::sweep_kernel_mc32x8");
-        return SMCX_OK;
-    }
-    if (name && len > 0)
-        std::snprintf(name, (size_t)len, "%s", mi ? mi_kernel_name(h.S, h.p.N, h.p.L, h.p.Lz, h.p.cutoff * h.p.cutoff)
-                                                  : mx ? mx_kernel_name(h.S, h.WPR, h.p.Lz) : fp64_kernel_name(h.S, h.WPR));
+    if (form) *form = h.plan.form == FORM_FP64 ? 1 : 2;
+    if (name && len > 0) std::snprintf(name, (size_t)len, "%s", h.plan.name);
     return SMCX_OK;
 }
 
@@ -575,10 +624,9 @@ static int run_phase(Handle &h, int steps, double A, int production, int gather_
             if (next - done < k) k = next - done;
         }
         HIPCHK(&h, launch_rng_prepass(h.c, k, A, h.stream));
-        HIPCHK(&h, launch_sweeps(h.c, h.S, h.WPR, k, A, h.p.tune_kernel, h.stream, &h.timer));
+        HIPCHK(&h, launch_sweeps(h.c, h.plan, k, A, h.stream, &h.timer));
         HIPCHK(&h, launch_finalize(h.c, k, production, done, (production && first) ? 1 : 0, h.stream));
         h.last_launches++;
-        h.last_sweeps.push_back(k);
         first = false;
         done += k;
     }
@@ -595,8 +643,7 @@ extern "C" int smcx_run(smcx_handle *hh, int eqsteps, int maxsteps, int gather_l
     int rc = ensure_series(h, maxsteps);
     if (rc != SMCX_OK) return rc;
     h.last_launches = 0;
-    h.timer.n = 0;
-    h.last_sweeps.clear();
+    h.timer.reset();
     h.last_gathers = 0;
     if (h.c.D) { // D, Mu and Rbin start from zero in every sMC call (SMC.c:52-55)
         const size_t Nc = (size_t)h.p.Ncx * h.p.Ncx * h.p.Ncz;
@@ -636,12 +683,8 @@ extern "C" int smcx_run(smcx_handle *hh, int eqsteps, int maxsteps, int gather_l
     float ms = 0.f;
     HIPCHK(&h, hipEventElapsedTime(&ms, h.ev0, h.ev1));
     h.last_ms = ms;
-    h.last_sweep_ms = 0.0;
-    for (int i = 0; i + 1 < h.timer.n; i += 2) {
-        float t = 0.f;
-        HIPCHK(&h, hipEventElapsedTime(&t, h.timer.evs[i], h.timer.evs[i + 1]));
-        h.last_sweep_ms += t;
-    }
+    HIPCHK(&h, h.timer.finish());
+    h.last_sweep_ms = h.timer.sum_ms;
     h.last_maxsteps = maxsteps;
     h.last_eqsteps = eqsteps;
     return SMCX_OK;
@@ -651,7 +694,7 @@ extern "C" int smcx_last_kernel_ms(smcx_handle *hh, double *ms, int *launches)
 {
     if (!hh) return SMCX_ERR_PARAM;
     if (ms) *ms = hh->h.last_sweep_ms;
-    if (launches) *launches = hh->h.timer.n / 2; // launches of the sweep kernel (sweep_kernel_mb64: one per sweep)
+    if (launches) *launches = hh->h.timer.launches(); // launches of the sweep kernel (sweep_kernel_mb64: one per sweep)
     return SMCX_OK;
 }
 
@@ -699,9 +742,10 @@ extern "C" int smcx_debug_wave_spread(smcx_handle *hh, double *out4)
     if (getenv("SMCX_SPREAD_DUMP")) { // lifetime percentiles, and the lifetimes in replica order (which replicas are slow?)
         for (int q : {1, 5, 10, 25, 50, 75, 90, 95, 99}) fprintf(stderr, "p%d %.0f  ", q, d[d.size() * q / 100]);
         fprintf(stderr, "\n");
-        for (int r = 0; r < h.p.nrep; r += h.p.nrep / 64) fprintf(stderr, "%.0f ", (double)(st[4 * r + 3] - st[4 * r + 1]) * 0.01);
+        const int step = std::max(1, h.p.nrep / 64);
+        for (int r = 0; r < h.p.nrep; r += step) fprintf(stderr, "%.0f ", (double)(st[4 * r + 3] - st[4 * r + 1]) * 0.01);
         fprintf(stderr, "\n");
-        for (int r = 0; r < h.p.nrep; r += h.p.nrep / 64) // shader clock seen by the same wavefronts, MHz
+        for (int r = 0; r < h.p.nrep; r += step) // shader clock seen by the same wavefronts, MHz
             fprintf(stderr, "%.0f ", (double)(st[4 * r + 2] - st[4 * r]) / (double)(st[4 * r + 3] - st[4 * r + 1]) * 100.0);
         fprintf(stderr, "\n");
     }

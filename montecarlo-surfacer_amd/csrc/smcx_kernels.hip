@@ -770,18 +770,9 @@ static sweep_fn lookup(int S, int WPR, bool lead = true)
     return nullptr;
 }
 
-// leader/follower form where it measured faster (profiles/r01_leader_follower.log): many
-// waves with few slots each; SMCX_NO_LEAD / SMCX_LEAD force one form for A/B measurements
-static bool use_lead(int S, int WPR)
-{
-    static const bool no_lead = getenv("SMCX_NO_LEAD") != nullptr, force_lead = getenv("SMCX_LEAD") != nullptr;
-    return WPR > 1 && (force_lead || (!no_lead && S <= 16 && WPR >= 4));
-}
-
 // the launched instantiation as rocprofv3 prints it
-const char *fp64_kernel_name(int S, int WPR)
+const char *fp64_kernel_name(int S, int WPR, bool lead)
 {
-    const bool lead = use_lead(S, WPR);
 #define SMCX_CASE1(s, m, gg) if (S == s && WPR == 1) return "smcx::sweep_kernel<" #s ", 1, " #m ", " #gg ">";
 #define SMCX_CASE(s, w, m, gg) if (S == s && WPR == w) return lead ? "smcx::sweep_kernel_lead<" #s ", " #w ", " #m ", " #gg ">" \
                                                                   : "smcx::sweep_kernel<" #s ", " #w ", " #m ", " #gg ">";
@@ -801,25 +792,54 @@ hipError_t launch_rng_prepass(const DevCtx &c, int nsweeps, double A, hipStream_
     return hipGetLastError();
 }
 
-// which form runs: the screened kernel where it exists unless fp64 is asked for (SMCX_MX=0/1
-// overrides "auto" for A/B measurements)
-bool sweep_uses_mx(int S, int WPR, int kernel)
+// The one place that decides which sweep kernel serves a handle (see KernelPlan, smcx_kernels.h).
+//  * fp64 kernels when asked for (tune.kernel == 1) or when no screened kernel is built for (S, WPR); with several
+//    wavefronts their leader/follower form where it measured faster (profiles/r01_leader_follower.log: S <= 16, >= 4 waves);
+//  * else the ladder mx -> mi -> ma -> mb -> mc, each step needing the one below: one wavefront per replica and a z
+//    unit that covers the box (mi), 32 S < N <= 64 S with the standard unit (ma), 64 cells per lane (mb), a box the byte
+//    screen resolves (mc); several wavefronts per replica go from mx straight to the several-wave mc forms.
+bool plan_kernel(int N, int M2, double L, double Lz, double cutoff2, int S, int WPR, const Tune &t, KernelPlan *out)
 {
-    static const char *env = getenv("SMCX_MX");
-    if (kernel == 0 && env) kernel = (env[0] == '0') ? 1 : 2;
-    const bool have64 = lookup(S, WPR) != nullptr;
-    if (kernel == 1 && have64) return false;
-    if (kernel == 2 || !have64) return mx_supported(S, WPR);
-    return mx_supported(S, WPR); // auto
+    KernelPlan p;
+    p.S = S; p.WPR = WPR; p.tune = t;
+    const bool have64 = lookup(S, WPR) != nullptr, havemx = mx_supported(S, WPR);
+    if (!have64 && !havemx) return false;
+    if ((t.kernel == 1 && have64) || !havemx) {
+        p.form = FORM_FP64;
+        p.lead = WPR > 1 && (t.lead == 1 || (t.lead < 0 && S <= 16 && WPR >= 4));
+        p.name = fp64_kernel_name(S, WPR, p.lead);
+        *out = p;
+        return true;
+    }
+    int cap = t.kernel >= FORM_MX ? t.kernel : FORM_MC;
+    if (cap > FORM_MC) cap = FORM_MC;
+    p.form = FORM_MX;
+    if (WPR == 1 && cap >= FORM_MI) {
+        const int zs = mi_built(S, L, Lz, cutoff2);
+        if (zs) { p.form = FORM_MI; p.zs = zs; }
+    }
+    if (p.form == FORM_MI && p.zs == 4 && ma_built(S, N, M2)) {
+        const int top = cap < ma_cap(t, S) ? cap : ma_cap(t, S);
+        if (top >= FORM_MA) p.form = FORM_MA;
+        if (top >= FORM_MB && S == 64) p.form = FORM_MB;
+        if (top >= FORM_MC && mc_box_supported(L, Lz, cutoff2)) p.form = FORM_MC;
+    }
+    if (p.form == FORM_MX && WPR > 1 && cap >= FORM_MC && mcw_built(S, WPR, N, M2, L, Lz, cutoff2)) p.form = FORM_MC;
+    if (p.form == FORM_MX) {
+        p.mz = mx_lds_z(S, WPR, Lz, t.mz);
+        p.name = mx_kernel_name(S, WPR, p.mz);
+    } else if (p.form == FORM_MI) {
+        p.name = mi_kernel_name(S, p.zs);
+    } else {
+        p.name = ma_kernel_name(p.form, S, WPR);
+    }
+    *out = p;
+    return true;
 }
 
-hipError_t launch_sweeps(const DevCtx &c, int S, int WPR, int nsweeps, double A, int kernel, hipStream_t st,
-                         SweepTimer *tm)
+hipError_t launch_sweeps(const DevCtx &c, const KernelPlan &pl, int nsweeps, double A, hipStream_t st, SweepTimer *tm)
 {
-    const bool lead = use_lead(S, WPR);
-    sweep_fn f = lookup(S, WPR, lead);
-    const bool use_mx = sweep_uses_mx(S, WPR, kernel);
-    if (!f && !use_mx) return hipErrorInvalidValue;
+    const int S = pl.S, WPR = pl.WPR;
     SweepArgs a;
     a.N = c.N; a.chunk = c.chunk;
     a.L = c.L; a.invL = c.invL; a.cutoff2 = c.cutoff2; a.invT = c.invT;
@@ -829,14 +849,18 @@ hipError_t launch_sweeps(const DevCtx &c, int S, int WPR, int nsweeps, double A,
 #ifdef SMCX_CHECK
     a.dbg = c.dbg;
 #endif
-    if (use_mx && mi_supported(S, WPR, c.L, c.Lz, c.cutoff2)) return launch_sweeps_mi(a, c, S, nsweeps, A, st, tm);
-    if (use_mx && c.Rs && c.loc && mcw_supported(S, WPR, c.N, (c.flags & 0x1u) ? c.M2 : 0, c.L, c.Lz, c.cutoff2))
+    if (pl.form >= FORM_MI && WPR == 1) return launch_sweeps_mi(a, c, pl, nsweeps, A, st, tm);
+    if (pl.form == FORM_MC) {
+        if (!c.Rs || !c.loc) return hipErrorInvalidValue;
         return launch_sweeps_mcw(a, c, WPR, nsweeps, A, st, tm);
+    }
     hipError_t rc = tm ? tm->mark(st) : hipSuccess;
     if (rc != hipSuccess) return rc;
-    if (use_mx) {
-        rc = launch_sweeps_mx(a, c, S, WPR, nsweeps, A, st);
+    if (pl.form == FORM_MX) {
+        rc = launch_sweeps_mx(a, c, pl, nsweeps, A, st);
     } else {
+        sweep_fn f = lookup(S, WPR, pl.lead);
+        if (!f) return hipErrorInvalidValue;
         hipLaunchKernelGGL(f, dim3(c.nrep), dim3(64 * WPR), 0, st, a, c, nsweeps, A);
         rc = hipGetLastError();
     }

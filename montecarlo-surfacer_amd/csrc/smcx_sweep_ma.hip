@@ -298,60 +298,39 @@ __global__ void __launch_bounds__(TPB) zsort_kernel(const double *__restrict__ R
     }
 }
 
-bool ma_supported(int S, int WPR, int N, int M2)
+// hand-scheduled kernels are generated for 16, 32 and 64 cells per lane, one wavefront per replica
+bool ma_built(int S, int N, int M2)
 {
     if (S != 16 && S != 32 && S != 64) return false;
+    return N > 32 * S && N <= 64 * S && M2 + 1 <= 30;
+}
+
+// highest form the build offers for S.  The product build: all of them (mb needs 64 cells per lane, plan_kernel).
+// The diagnostic build (-DSMCX_CHECK) counts the screen's misses in sweep_kernel_mi (same screen, hipcc-scheduled)
+// unless check_mb asks for sweep_kernel_mb64 (1: ranged passes checked against full ones) or sweep_kernel_mc64
+// (2: the fp64 test of every cell beside every pass), which exist for 64 cells per lane only.
+int ma_cap(const Tune &t, int S)
+{
 #ifdef SMCX_CHECK
-    // the diagnostic build counts the screen's misses in sweep_kernel_mi (same screen, hipcc-scheduled); with
-    // SMCX_CHECK_MB=1 it runs sweep_kernel_mb64 instead, whose ranged passes are checked against full ones
-    static const char *chk = getenv("SMCX_CHECK_MB"); // 1: sweep_kernel_mb64, 2: sweep_kernel_mc64 (fp64 test of every cell)
-    if (!(chk && (chk[0] == '1' || chk[0] == '2') && S == 64)) return false;
+    if (S != 64) return FORM_MI;
+    return t.check_mb == 2 ? FORM_MC : t.check_mb == 1 ? FORM_MB : FORM_MI;
+#else
+    (void)t; (void)S;
+    return FORM_MC;
 #endif
-    static const char *env = getenv("SMCX_MA"); // SMCX_MA=0: sweep_kernel_mi instead, for A/B measurements
-    if (env && env[0] == '0') return false;
-    return WPR == 1 && N > 32 * S && N <= 64 * S && M2 + 1 <= 30;
 }
 
-// the z-binned form serves the 64-particles-per-lane geometry; SMCX_MB=0 keeps sweep_kernel_ma64 (A/B measurements)
-bool mb_supported(int S, int WPR, int N, int M2)
-{
-    static const char *env = getenv("SMCX_MB");
-    if (env && env[0] == '0') return false;
-    return S == 64 && ma_supported(S, WPR, N, M2);
-}
-
-// byte form of the z-binned kernel (one word per cell: z int16, x and y int8, unit L/256): the unit must resolve
-// the cutoff (16 units or more) and the box must fit the int16 z.  SMCX_MC=0 keeps sweep_kernel_mb64.
-bool mc_supported(int S, int WPR, int N, int M2, double L, double Lz, double cutoff2)
+// several wavefronts per replica with the cells in z order: 64 x 4 or 32 x 8, 8192 < N <= 16384, in a box the byte
+// screen serves
+bool mcw_built(int S, int WPR, int N, int M2, double L, double Lz, double cutoff2)
 {
 #ifdef SMCX_CHECK
-    static const char *chk = getenv("SMCX_CHECK_MB");
-    if (!(chk && chk[0] == '2')) return false;
-#endif
-    static const char *env = getenv("SMCX_MC");
-    if (env && env[0] == '0') return false;
-    static const char *envb = getenv("SMCX_MB"); // SMCX_MB=0 switches both z-ordered forms off
-    if (envb && envb[0] == '0') return false;
-    return ma_supported(S, WPR, N, M2) && mc_box_supported(L, Lz, cutoff2);
-}
-
-// four wavefronts per replica with 64 cells per lane each: 8192 < N <= 16384 in a box the byte screen serves
-bool mcw_supported(int S, int WPR, int N, int M2, double L, double Lz, double cutoff2)
-{
-#ifdef SMCX_CHECK
+    (void)S; (void)WPR; (void)N; (void)M2; (void)L; (void)Lz; (void)cutoff2;
     return false;
-#endif
-    static const char *env = getenv("SMCX_MCW"); // SMCX_MCW=0: sweep_kernel_mx for this geometry
-    if (env && env[0] == '0') return false;
+#else
     return ((S == 64 && WPR == 4) || (S == 32 && WPR == 8)) && N > 8192 && N <= 16384 && M2 + 1 <= 30 &&
            mc_box_supported(L, Lz, cutoff2);
-}
-
-// does this geometry / box run a kernel with z-ordered cells (and need Rs, loc)?
-bool zordered_supported(int S, int WPR, int N, int M2, double L, double Lz, double cutoff2)
-{
-    return mb_supported(S, WPR, N, M2) || mc_supported(S, WPR, N, M2, L, Lz, cutoff2) ||
-           mcw_supported(S, WPR, N, M2, L, Lz, cutoff2);
+#endif
 }
 
 #ifndef SMCX_CHECK
@@ -414,16 +393,20 @@ void mc_bound(double L, double cutoff2, double *toFix, double *zsafe, int *negC,
     *RZ = (int)std::floor(q) + 3; // |dz| in units of a pair inside the cutoff, with the two roundings
 }
 
-const char *ma_kernel_name(int S, int N)
+const char *ma_kernel_name(int form, int S, int WPR)
 {
-    if (mb_supported(S, 1, N, 0)) return "smcx::sweep_kernel_mb64"; // (mc: see ma_kernel_name_box)
+    if (form == FORM_MC && WPR == 4) return "smcx::sweep_kernel_mc64x4";
+    if (form == FORM_MC && WPR == 8) return "smcx::sweep_kernel_mc32x8";
+    if (form == FORM_MC) return S == 64 ? "smcx::sweep_kernel_mc64" : S == 32 ? "smcx::sweep_kernel_mc32" : "smcx::sweep_kernel_mc16";
+    if (form == FORM_MB) return "smcx::sweep_kernel_mb64";
     return S == 64 ? "smcx::sweep_kernel_ma64" : S == 32 ? "smcx::sweep_kernel_ma32" : "smcx::sweep_kernel_ma16";
 }
 
 // wtab: [M2 + 1][4] doubles on the device, built by the caller (smcx_api.hip)
-hipError_t launch_sweeps_ma(const SweepArgs &s, const DevCtx &c, int S, const double *wtab, int nsweeps, double A,
-                            double toFix, double zFix, double zsafe, int negC, hipStream_t st, SweepTimer *tm)
+hipError_t launch_sweeps_ma(const SweepArgs &s, const DevCtx &c, const KernelPlan &pl, const double *wtab, int nsweeps,
+                            double A, double toFix, double zFix, double zsafe, int negC, hipStream_t st, SweepTimer *tm)
 {
+    const int S = pl.S;
     MaArgs a;
     a.R = s.R; a.displ = s.displ; a.uni = s.uni; a.offs = s.offs; a.obs = s.obs; a.rec = s.rec;
     a.wtab = wtab; a.clk = s.clk;
@@ -436,21 +419,22 @@ hipError_t launch_sweeps_ma(const SweepArgs &s, const DevCtx &c, int S, const do
 #ifdef SMCX_CHECK
     a.dbg = s.dbg;
 #endif
-    if (zordered_supported(S, 1, s.N, a.M2, c.L, c.Lz, c.cutoff2) && c.Rs && c.loc) {
+    if (pl.zordered()) {
+        if (!c.Rs || !c.loc) return hipErrorInvalidValue;
         // a slot is flagged only if dz^2 < ceil(C / 4^ZS) (dz in z units, C = -negC): the screen's reach in z
         const long T = ((long)(-negC) + 255) >> 8;
         a.RZ = (int)std::floor(std::sqrt((double)T)) + 1;
         a.Rs = c.Rs; a.loc = c.loc;
-        // the cells are re-sorted by z every `every` sweeps (SMCX_RESORT, default 1): the groups' z ranges only
-        // widen inside a launch
-        const bool mc = mc_supported(S, 1, s.N, a.M2, c.L, c.Lz, c.cutoff2);
+        // the cells are re-sorted by z every `every` sweeps (smcx_params.tune_resort, default 1): the groups' z ranges
+        // only widen inside a launch
+        const bool mc = pl.form == FORM_MC;
         if (mc) {
             mc_bound(c.L, c.cutoff2, &a.toFix, &a.zsafe, &a.negC, &a.RZ);
             a.zFix = a.toFix;
         }
-        static const int every = [] { const char *e = getenv("SMCX_RESORT"); int v = e ? atoi(e) : 1; return v > 0 ? v : 1; }();
+        const int every = pl.tune.resort > 0 ? pl.tune.resort : 1;
         for (int sw = 0; sw < nsweeps; sw += every) {
-            static const int tpb = [] { const char *e = getenv("SMCX_ZSORT_TPB"); return e ? atoi(e) : 512; }(); // 512 threads (8 keys each) measured best of 128..1024 for 4096 cells
+            const int tpb = pl.tune.zsort_tpb; // 512 threads (8 keys each) measured best of 128..1024 for 4096 cells
 #define SMCX_ZSORT(C, T) hipLaunchKernelGGL((zsort_kernel<C, T>), dim3(c.nrep), dim3(T), 0, st, (const double *)s.R, c.Rs, c.loc, s.N, toFix)
             if (S == 64 && tpb == 128) SMCX_ZSORT(64 * 64, 128);
             else if (S == 64 && tpb == 256) SMCX_ZSORT(64 * 64, 256);

@@ -594,23 +594,16 @@ static bool mi_bound(double L, double Lz, double cutoff2, int ZS, MiArgs *out)
     return true;
 }
 
-bool mi_supported(int S, int WPR, double L, double Lz, double cutoff2)
+int mi_built(int S, double L, double Lz, double cutoff2)
 {
-    static const char *env = getenv("SMCX_MI"); // SMCX_MI=0: the older sweep_kernel_mx, for A/B measurements
-    if (env && env[0] == '0') return false;
-    if (WPR != 1) return false;
     const int zs = mi_zshift(L, Lz);
     MiArgs m;
-    return zs != 0 && lookup_mi(S, zs) != nullptr && mi_bound(L, Lz, cutoff2, zs, &m);
+    return (zs != 0 && lookup_mi(S, zs) != nullptr && mi_bound(L, Lz, cutoff2, zs, &m)) ? zs : 0;
 }
 
 // the launched instantiation as rocprofv3 prints it
-const char *mi_kernel_name(int S, int N, double L, double Lz, double cutoff2)
+const char *mi_kernel_name(int S, int zs)
 {
-    const int zs = mi_zshift(L, Lz);
-    if (zs == 4 && mc_supported(S, 1, N, 0, L, Lz, cutoff2))
-        return S == 64 ? "smcx::sweep_kernel_mc64" : S == 32 ? "smcx::sweep_kernel_mc32" : "smcx::sweep_kernel_mc16";
-    if (zs == 4 && ma_supported(S, 1, N, 0)) return ma_kernel_name(S, N);
 #define SMCX_MI(s, z, w) if (S == s && zs == z) return "smcx::sweep_kernel_mi<" #s ", " #z ", " #w ">";
     SMCX_MI_TABLE(SMCX_MI)
 #undef SMCX_MI
@@ -630,16 +623,18 @@ void mi_bound_values(double L, double Lz, double cutoff2, double *thr, double *u
     *thr = -(double)m.negC * u * u; *u2 = u * u; *toFix = m.toFix; *zsafe = m.zsafe; *uz = 1.0 / m.zFix; *negC = m.negC;
 }
 
-hipError_t launch_sweeps_mi(const SweepArgs &a, const DevCtx &c, int S, int nsweeps, double A, hipStream_t st,
-                            SweepTimer *tm)
+hipError_t launch_sweeps_mi(const SweepArgs &a, const DevCtx &c, const KernelPlan &pl, int nsweeps, double A,
+                            hipStream_t st, SweepTimer *tm)
 {
-    const int zs = mi_zshift(c.L, c.Lz);
+    const int S = pl.S, zs = pl.zs;
     sweep_mi_fn f = zs ? lookup_mi(S, zs) : nullptr;
     MiArgs m;
     if (!f || !mi_bound(c.L, c.Lz, c.cutoff2, zs, &m)) return hipErrorInvalidValue;
     // 64 particles per lane with the standard z unit: the hand-scheduled form of this kernel
-    if (zs == 4 && c.wtab && ma_supported(S, 1, c.N, (c.flags & 0x1u) ? c.M2 : 0))
-        return launch_sweeps_ma(a, c, S, c.wtab, nsweeps, A, m.toFix, m.zFix, m.zsafe, m.negC, st, tm);
+    if (pl.form >= FORM_MA) {
+        if (!c.wtab) return hipErrorInvalidValue;
+        return launch_sweeps_ma(a, c, pl, c.wtab, nsweeps, A, m.toFix, m.zFix, m.zsafe, m.negC, st, tm);
+    }
     MiWalls wl;
     wl.on = (c.flags & 0x1u) ? 1 : 0; wl.M = c.M; wl.M2 = c.M2;
     wl.dw = c.L / c.M; wl.Lz = c.Lz; wl.invLz = c.invLz; wl.halfLz = c.halfLz;

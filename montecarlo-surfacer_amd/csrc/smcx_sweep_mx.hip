@@ -547,9 +547,8 @@ static sweep_mx_fn lookup_mz(int S, int WPR)
 bool mx_supported(int S, int WPR) { return lookup_mx(S, WPR) != nullptr; }
 
 // the launched instantiation as rocprofv3 prints it
-const char *mx_kernel_name(int S, int WPR, double Lz)
+const char *mx_kernel_name(int S, int WPR, bool mz)
 {
-    const bool mz = mx_lds_z(S, WPR, Lz);
 #define SMCX_MX(s, w, m) if (!mz && S == s && WPR == w) return "smcx::sweep_kernel_mx<" #s ", " #w ", " #m ", false>";
     SMCX_MX_TABLE(SMCX_MX)
 #undef SMCX_MX
@@ -559,11 +558,10 @@ const char *mx_kernel_name(int S, int WPR, double Lz)
     return "";
 }
 
-bool mx_lds_z(int S, int WPR, double Lz)
+bool mx_lds_z(int S, int WPR, double Lz, int force)
 {
-    static const char *env_mz = getenv("SMCX_MZ");
     bool mz = (S == 64 && WPR == 1 && Lz <= 480.0);
-    if (env_mz) mz = (env_mz[0] != '0');
+    if (force >= 0) mz = (force != 0);
     if (Lz > 32768.0) mz = false; // zsafe (the power of two above Lz/2) must stay a finite fp16
     return mz && lookup_mz(S, WPR) != nullptr;
 }
@@ -602,14 +600,15 @@ void mx_bound_values(double L, double Lz, double cutoff2, bool lds_z, double *th
     *thr = m.thr; *u2 = m.u2; *toFix = m.toFix; *zsafe = m.zsafe;
 }
 
-hipError_t launch_sweeps_mx(const SweepArgs &a, const DevCtx &c, int S, int WPR, int nsweeps, double A,
+hipError_t launch_sweeps_mx(const SweepArgs &a, const DevCtx &c, const KernelPlan &pl, int nsweeps, double A,
                             hipStream_t st)
 {
+    const int S = pl.S, WPR = pl.WPR;
     sweep_mx_fn fm = lookup_mx(S, WPR);
     // z as fp16 in LDS (ZL = true) where it measured faster: one wavefront per replica with 64
     // particles per lane, which then fits four waves per SIMD -- unless the box is so tall that fp16
-    // would widen the screen noticeably.  SMCX_MZ=0/1 forces the choice for A/B measurements.
-    const bool mz = mx_lds_z(S, WPR, c.Lz);
+    // would widen the screen noticeably (decided in plan_kernel; Tune.mz forces the choice for A/B measurements).
+    const bool mz = pl.mz;
     if (mz) fm = lookup_mz(S, WPR);
     if (!fm) return hipErrorInvalidValue;
     const MxArgs m = mx_bound(c.L, c.Lz, c.cutoff2, mz);
