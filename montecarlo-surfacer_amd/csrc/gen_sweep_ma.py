@@ -15,9 +15,11 @@ MODE  kernel                what differs
  zbc  (diagnostic of zb)    every ranged pass followed by the full pass; counts the bits the ranged one lacks
  z8   sweep_kernel_mc<NS>   zb with ONE word per cell (int16 z | int8 x | int8 y, units of L/256), screened by
                             v_sub_u32 + v_dot4_i32_i8 + v_alignbit_b32; no z words in LDS -- the benchmark's kernel
- z8c  (diagnostic of z8)    the fp64 cutoff test of every cell beside every pass; counts unflagged pairs
+ z8c  (diagnostic of z8)    the fp64 cutoff test of every cell beside every pass; counts unflagged pairs, and the
+                            executed work: passes, 4-slot groups screened, candidate bits
  z8w  sweep_kernel_mc64x4   z8 for 4 (NS = 64) or 8 (NS = 32) wavefronts per replica, 8192 < N <= 16384: every wave owns a
       sweep_kernel_mc32x8   slab of the z order and runs the whole move loop; reductions completed across waves via LDS
+ z8wc (diagnostic of z8w)   as z8c, every wave testing its own cells
 
 A move (iteration i of a run; particle n = first + i; ma: in register slot 0 of lane tl; zb/z8: in cell locA):
   B-COPY  probe B = current position of particle n+1: compact copy by v_readlane (ma: from its owner lane; zb: from
@@ -72,16 +74,16 @@ ZBC = MODE == "zbc"                                       # diagnostic: every pa
 # probe, no z words in LDS).  The byte-wise squares alias |dz| >= 128 units; such cells are far outside the
 # cutoff, cost at most a wasted evaluation, and the group ranges keep them out of the passes anyway.
 # "z8c": its diagnostic build: the fp64 cutoff test of every cell beside every pass, counting unflagged pairs.
-PRIO = MODE != "z8w"                                      # issue priority from the SIMD neighbours' progress (one-wave kernels)
+PRIO = MODE not in ("z8w", "z8wc")                        # issue priority from the SIMD neighbours' progress (one-wave kernels)
 PRIO_MODE = os.environ.get("SMCX_GEN_PRIO_MODE", "rotate")
 PRIO_SHIFT = int(os.environ.get("SMCX_GEN_PRIO_SHIFT", "14"))   # ... every 2^14 ticks of the 100 MHz clock (164 us)
-Z8C = MODE == "z8c"
+Z8C = MODE in ("z8c", "z8wc")
 # "z8w": z8 for FOUR wavefronts per replica (8192 < N <= 16384): wave w owns the cells 4096 w .. 4096 w + 4095 of the
 # z order (its own 16 groups and ranges) and runs the whole move loop itself -- same scalar state, own copy of the row
 # cache -- except that the wall sites, plane and side pair live on wave 0, a cell is written by its owner only, and
 # the two reductions of a move are completed across the waves through LDS (fixed order, so every wave takes the
 # same Metropolis decision); operand %3 = the wave's index
-W4 = MODE == "z8w"
+W4 = MODE in ("z8w", "z8wc")
 WPR = (int(sys.argv[4]) if len(sys.argv) > 4 else 256 // NS) if W4 else 1   # wavefronts per replica: 4 (NS = 64) or 8 (NS = 32)
 assert WPR in (1, 4, 8)
 WSH = (NS * 64).bit_length() - 1                          # cell >> WSH = the wave that owns it
@@ -94,6 +96,8 @@ LDS_GB = LDS_P0                                           # zb: (min, max) z of 
 LDS_CNT = LDS_P0 + 65 * 24 + 8                            # zbc: per lane (candidates, bits missing from the ranged pass)
 LDS_WAVE = 2048                                           # z8w: each wave's copy of the row cache (v1 = wave * LDS_WAVE)
 LDS_X = WPR * LDS_WAVE                                    # z8w: exchange area [2 buffers][WPR waves][64 lanes] doubles
+if W4:
+    LDS_CNT = LDS_X + 2 * WPR * 512                       # z8wc: 8 counter words per wave behind the exchange area
 LANE, KARG, REP, WAVE = "%0", "%1", "%2", "%3"
 
 V = dict(zaddr=1, uns0=2, uns1=3, wa0=4, wa1=5, wb0=6, wb1=7, axy=8, bxy=9,
@@ -309,6 +313,18 @@ v_mov_b32 {v('uns1')}, 0
 s_mov_b32 {s('rot')}, 0
 """)
 SRC = sp('Rs') if ZB else sp('Rg')    # what the compact copies are built from / candidates are fetched from
+
+
+def cnt_addr(vreg):
+    """z8c / z8wc: vreg <- LDS address (before the offset LDS_CNT) of this wave's diagnostic counters:
+    +0 pairs inside the cutoff, +4 candidate bits, +8 pairs inside whose bit is missing, +12 groups screened, +16 passes"""
+    if W4:
+        E(f"v_mov_b32 {vreg}, {WAVE}")
+        E(f"v_lshlrev_b32 {vreg}, 5, {vreg}")
+    else:
+        E(f"v_mov_b32 {vreg}, 0")
+
+
 if ZB:
     # LDS gb[g] = (max int, min int); lane g will read its group's pair when the copies are built
     E(f"""
@@ -316,11 +332,21 @@ if ZB:
     v_mov_b32 v16, 0x7fffffff
     v_mov_b32 v17, 0x80000000
     ds_write_b64 v14, v[16:17] offset:{LDS_GB}
-    {f"v_mov_b32 v16, 0" if ZBC or Z8C else ""}
-    {f"v_mov_b32 v17, 0" if ZBC or Z8C else ""}
-    {f"ds_write_b64 v14, v[16:17] offset:{LDS_CNT}" if ZBC or Z8C else ""}
+    {f"v_mov_b32 v16, 0" if ZBC else ""}
+    {f"v_mov_b32 v17, 0" if ZBC else ""}
+    {f"ds_write_b64 v14, v[16:17] offset:{LDS_CNT}" if ZBC else ""}
     s_waitcnt lgkmcnt(0)
     """)
+    if Z8C:   # lanes 0..7 zero this wave's eight counter words
+        cnt_addr("v14")
+        E(f"""
+        v_lshl_add_u32 v14, {LANE}, 2, v14
+        v_mov_b32 v16, 0
+        s_mov_b64 exec, 0xff
+        ds_write_b32 v14, v16 offset:{LDS_CNT}
+        s_mov_b64 exec, -1
+        s_waitcnt lgkmcnt(0)
+        """)
 
 zb_range_update = "" if not ZB else f"""
 s_lshr_b32 {st(6)}, {st(0)}, 2
@@ -842,7 +868,7 @@ else:
   """)
   COLD(f"""
   L_nob0:
-  s_mov_b32 {s('bzz')}, 0
+  {"" if Z8 else f"s_mov_b32 {s('bzz')}, 0"}
   s_mov_b32 {s('ub')}, 0
   s_mov_b32 {s('cross')}, 0
   s_mov_b32 {s('lb')}, 0
@@ -1004,6 +1030,8 @@ def screen_ranged8(tag, pws, w0, w1):
     s_cbranch_scc1 L_sdone_{tag}
     s_ff1_i32_b32 {st(4)}, {st(1)}
     s_flbit_i32_b32 {st(5)}, {st(1)}
+    {f"s_add_u32 {st(1)}, {st(4)}, {st(5)}" if Z8C else ""}
+    {f"s_sub_u32 {st(1)}, 32, {st(1)}" if Z8C else ""}
     s_mul_i32 {st(5)}, {st(5)}, L_sg{NG-2}_{tag}-L_sg{NG-1}_{tag}
     s_add_u32 {st(5)}, {st(5)}, L_sg{NG-1}_{tag}-L_sg{NG-1}_A-{32 - NG}*(L_sg{NG-2}_A-L_sg{NG-1}_A)
     s_add_u32 {st(2)}, {s('nlu')}, {st(5)}
@@ -1017,8 +1045,16 @@ def screen_ranged8(tag, pws, w0, w1):
         if g > 0:
             E(f"s_cmp_eq_u32 {st(4)}, {g}")
             E(f"s_cbranch_scc1 L_sfin_{tag}")
+    E(f"L_sfin_{tag}:")
+    if Z8C:   # executed work: groups of this pass = highest - lowest + 1 = 32 - flbit - ff1 (in st(1) since the jump)
+        cnt_addr("v16")
+        E(f"""
+        v_mov_b32 v14, {st(1)}
+        s_mov_b64 exec, 1
+        ds_add_u32 v16, v14 offset:{LDS_CNT + 12}
+        s_mov_b64 exec, -1
+        """)
     E(f"""
-    L_sfin_{tag}:
     s_lshl_b32 {st(0)}, {st(4)}, 2
     v_lshlrev_b32 {w0}, {st(0)}, {w0}
     """)
@@ -1029,6 +1065,14 @@ def screen_ranged8(tag, pws, w0, w1):
         v_lshlrev_b32 {w1}, {st(1)}, {w1}
         """)
     E(f"L_sdone_{tag}:")
+    if Z8C:   # every pass, also one that found no group in reach
+        cnt_addr("v16")
+        E(f"""
+        v_mov_b32 v14, 1
+        s_mov_b64 exec, 1
+        ds_add_u32 v16, v14 offset:{LDS_CNT + 16}
+        s_mov_b64 exec, -1
+        """)
 
 
 def z8c_check(tag, P_sgpr, w0, w1, locs, guard):
@@ -1048,7 +1092,7 @@ def z8c_check(tag, P_sgpr, w0, w1, locs, guard):
         s_cmp_eq_u32 {s('cross')}, 1
         s_cselect_b32 {st(0)}, 64, {s('lb')}
         s_mul_i32 {st(0)}, {st(0)}, 24
-        v_mov_b32 v36, {st(0)}
+        {f"v_add_u32 v36, {st(0)}, v1" if W4 else f"v_mov_b32 v36, {st(0)}"}
         ds_read_b64 v[20:21], v36 offset:{LDS_P0}
         ds_read_b64 v[22:23], v36 offset:{LDS_P0 + 8}
         ds_read_b64 v[24:25], v36 offset:{LDS_P0 + 16}
@@ -1061,7 +1105,7 @@ def z8c_check(tag, P_sgpr, w0, w1, locs, guard):
     s_mov_b32 {st(7)}, 0
     L_ck_{tag}:
     v_lshl_or_b32 v36, {st(7)}, 6, {LANE}
-    v_cmp_gt_u32 vcc, {s('N')}, v36
+    v_cmp_gt_u32 vcc, {s_Nw()}, v36
     v_mul_u32_u24 v37, 24, v36
     s_mov_b64 {stp(0)}, vcc
     s_mov_b64 exec, vcc
@@ -1085,8 +1129,13 @@ def z8c_check(tag, P_sgpr, w0, w1, locs, guard):
     s_and_b64 {stp(2)}, {stp(2)}, {stp(0)}
     """)
     for loc in locs:      # (register, guard) pairs: the cell is not a neighbour when guard != 0
+        if W4:            # v36 counts this wave's cells: compare with the cell's index inside its owner wave, if that is us
+            E(f"""
+            s_lshl_b32 {st(6)}, {WAVE}, {WSH}
+            s_sub_u32 {st(6)}, {loc[0]}, {st(6)}
+            """)
         E(f"""
-        v_cmp_ne_u32 {stp(4)}, {loc[0]}, v36
+        v_cmp_ne_u32 {stp(4)}, {st(6) if W4 else loc[0]}, v36
         s_cmp_eq_u32 {loc[1]}, 0
         s_cselect_b64 {stp(4)}, -1, {stp(4)}
         s_and_b64 {stp(2)}, {stp(2)}, {stp(4)}
@@ -1107,7 +1156,9 @@ def z8c_check(tag, P_sgpr, w0, w1, locs, guard):
     // lane 0: inside += v47 & 0xffff ; missed += v47 >> 16 ; every lane: candidate bits
     v_and_b32 v44, 0xffff, v47
     v_lshrrev_b32 v45, 16, v47
-    v_mov_b32 v36, 0
+    """)
+    cnt_addr("v36")
+    E(f"""
     ds_add_u32 v36, v46 offset:{LDS_CNT + 4}
     s_mov_b64 exec, 1
     ds_add_u32 v36, v44 offset:{LDS_CNT}
@@ -1983,11 +2034,13 @@ s_cmp_lt_u32 {s('sw')}, {s('nsw')}
 s_cbranch_scc1 L_sweep
 """)
 if Z8C:
+    cnt_addr("v25")
     E(f"""
-    v_mov_b32 v25, 0
     ds_read_b32 v22, v25 offset:{LDS_CNT}
     ds_read_b32 v23, v25 offset:{LDS_CNT + 4}
     ds_read_b32 v24, v25 offset:{LDS_CNT + 8}
+    ds_read_b32 v34, v25 offset:{LDS_CNT + 12}
+    ds_read_b32 v35, v25 offset:{LDS_CNT + 16}
     s_load_dwordx2 {stp(2)}, {KARG}, {K_DBG}
     v_mov_b32 v30, 0
     v_mov_b32 v27, 0
@@ -2001,6 +2054,12 @@ if Z8C:
     v_mov_b32 v32, v24
     v_mov_b32 v33, 0
     global_atomic_add_x2 v30, v[32:33], {stp(2)} offset:16
+    v_mov_b32 v36, v34
+    v_mov_b32 v37, 0
+    global_atomic_add_x2 v30, v[36:37], {stp(2)} offset:24
+    v_mov_b32 v38, v35
+    v_mov_b32 v39, 0
+    global_atomic_add_x2 v30, v[38:39], {stp(2)} offset:32
     s_mov_b64 exec, -1
     s_waitcnt vmcnt(0)
     """)

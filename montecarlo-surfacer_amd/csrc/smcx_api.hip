@@ -412,8 +412,8 @@ extern "C" int smcx_create(const smcx_params *p, smcx_handle **out)
         CRT(hipMalloc(&c.Rbin, nrep * N * sizeof(int)));
     }
 #ifdef SMCX_CHECK
-    CRT(hipMalloc(&c.dbg, 4 * sizeof(unsigned long long)));
-    CRT(hipMemset(c.dbg, 0, 4 * sizeof(unsigned long long)));
+    CRT(hipMalloc(&c.dbg, 8 * sizeof(unsigned long long)));
+    CRT(hipMemset(c.dbg, 0, 8 * sizeof(unsigned long long)));
 #endif
     CRT(hipMemset(c.obs, 0, nrep * sizeof(ObsRec)));
     CRT(hipMemset(c.zhist, 0, nrep * p->Ncz * sizeof(unsigned long long)));
@@ -847,6 +847,16 @@ extern "C" int smcx_debug_check_counts(smcx_handle *hh, uint64_t *out /*[3]*/)
     Handle &h = hh->h;
     HIPCHK(&h, hipSetDevice(h.p.device));
     HIPCHK(&h, hipMemcpy(out, h.c.dbg, 3 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    return SMCX_OK;
+}
+// the same plus the executed work of the z-ordered byte-screen kernels (SMCX_CHECK_MB=2): out[3] = 4-slot groups
+// screened (256 cells per wavefront each), out[4] = screen passes (one per probe and wavefront)
+extern "C" int smcx_debug_work_counts(smcx_handle *hh, uint64_t *out /*[5]*/)
+{
+    if (!hh || !out) return SMCX_ERR_PARAM;
+    Handle &h = hh->h;
+    HIPCHK(&h, hipSetDevice(h.p.device));
+    HIPCHK(&h, hipMemcpy(out, h.c.dbg, 5 * sizeof(uint64_t), hipMemcpyDeviceToHost));
     return SMCX_OK;
 }
 #endif

@@ -824,7 +824,8 @@ bool plan_kernel(int N, int M2, double L, double Lz, double cutoff2, int S, int 
         if (top >= FORM_MB && S == 64) p.form = FORM_MB;
         if (top >= FORM_MC && mc_box_supported(L, Lz, cutoff2)) p.form = FORM_MC;
     }
-    if (p.form == FORM_MX && WPR > 1 && cap >= FORM_MC && mcw_built(S, WPR, N, M2, L, Lz, cutoff2)) p.form = FORM_MC;
+    if (p.form == FORM_MX && WPR > 1 && cap >= FORM_MC && ma_cap(t, S) >= FORM_MC && mcw_built(S, WPR, N, M2, L, Lz, cutoff2))
+        p.form = FORM_MC;
     if (p.form == FORM_MX) {
         p.mz = mx_lds_z(S, WPR, Lz, t.mz);
         p.name = mx_kernel_name(S, WPR, p.mz);

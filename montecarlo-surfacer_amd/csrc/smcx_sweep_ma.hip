@@ -120,7 +120,6 @@ __global__ void __launch_bounds__(64, 4) sweep_kernel_mc64(MaArgs a)
         :
         : "memory", "vcc", "scc", "m0", SMCX_MA_SGPRS, SMCX_MA_V127);
 }
-#ifndef SMCX_CHECK
 // 32 and 16 particles per lane (1024 < N <= 2048, 512 < N <= 1024): 8 and 4 groups
 __global__ void __launch_bounds__(64, 5) sweep_kernel_mc32(MaArgs a)
 {
@@ -128,7 +127,11 @@ __global__ void __launch_bounds__(64, 5) sweep_kernel_mc32(MaArgs a)
     unsigned long long kp = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
     unsigned rep = blockIdx.x;
     asm volatile(
+#ifdef SMCX_CHECK
+#include "smcx_sweep_mcc_body32.inc"
+#else
 #include "smcx_sweep_mc_body32.inc"
+#endif
         : "+v"(lane), "+s"(kp), "+s"(rep)
         :
         : "memory", "vcc", "scc", "m0", SMCX_MA_SGPRS, SMCX_MA_V95);
@@ -139,7 +142,11 @@ __global__ void __launch_bounds__(64, 6) sweep_kernel_mc16(MaArgs a)
     unsigned long long kp = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
     unsigned rep = blockIdx.x;
     asm volatile(
+#ifdef SMCX_CHECK
+#include "smcx_sweep_mcc_body16.inc"
+#else
 #include "smcx_sweep_mc_body16.inc"
+#endif
         : "+v"(lane), "+s"(kp), "+s"(rep)
         :
         : "memory", "vcc", "scc", "m0", SMCX_MA_SGPRS, SMCX_MA_V79);
@@ -153,7 +160,11 @@ __global__ void __launch_bounds__(256, 1) sweep_kernel_mc64x4(MaArgs a)
     unsigned rep = blockIdx.x;
     unsigned wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     asm volatile(
+#ifdef SMCX_CHECK
+#include "smcx_sweep_mcwc_body64.inc" // + the fp64 test of every cell of this wave beside every pass
+#else
 #include "smcx_sweep_mcw_body64.inc"
+#endif
         : "+v"(lane), "+s"(kp), "+s"(rep), "+s"(wv)
         :
         : "memory", "vcc", "scc", "m0", SMCX_MA_SGPRS, SMCX_MA_V127);
@@ -166,11 +177,18 @@ __global__ void __launch_bounds__(512, 1) sweep_kernel_mc32x8(MaArgs a)
     unsigned rep = blockIdx.x;
     unsigned wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     asm volatile(
+#ifdef SMCX_CHECK
+#include "smcx_sweep_mcwc_body32.inc"
+#else
 #include "smcx_sweep_mcw_body32.inc"
+#endif
         : "+v"(lane), "+s"(kp), "+s"(rep), "+s"(wv)
         :
         : "memory", "vcc", "scc", "m0", SMCX_MA_SGPRS, SMCX_MA_V95);
 }
+#ifdef SMCX_CHECK
+constexpr unsigned mcw_lds_bytes(int wpr) { return (unsigned)wpr * 2048u + 2u * (unsigned)wpr * 512u + (unsigned)wpr * 32u; }
+#else
 constexpr unsigned mcw_lds_bytes(int wpr) { return (unsigned)wpr * 2048u + 2u * (unsigned)wpr * 512u; }
 #endif
 #ifdef SMCX_CHECK
@@ -307,13 +325,13 @@ bool ma_built(int S, int N, int M2)
 
 // highest form the build offers for S.  The product build: all of them (mb needs 64 cells per lane, plan_kernel).
 // The diagnostic build (-DSMCX_CHECK) counts the screen's misses in sweep_kernel_mi (same screen, hipcc-scheduled)
-// unless check_mb asks for sweep_kernel_mb64 (1: ranged passes checked against full ones) or sweep_kernel_mc64
-// (2: the fp64 test of every cell beside every pass), which exist for 64 cells per lane only.
+// unless check_mb asks for sweep_kernel_mb64 (1: ranged passes checked against full ones; 64 cells per lane) or the
+// sweep_kernel_mc* kernels (2: the fp64 test of every cell beside every pass, and the executed-work counters).
 int ma_cap(const Tune &t, int S)
 {
 #ifdef SMCX_CHECK
-    if (S != 64) return FORM_MI;
-    return t.check_mb == 2 ? FORM_MC : t.check_mb == 1 ? FORM_MB : FORM_MI;
+    if (t.check_mb == 2) return FORM_MC;
+    return (t.check_mb == 1 && S == 64) ? FORM_MB : FORM_MI;
 #else
     (void)t; (void)S;
     return FORM_MC;
@@ -324,16 +342,10 @@ int ma_cap(const Tune &t, int S)
 // screen serves
 bool mcw_built(int S, int WPR, int N, int M2, double L, double Lz, double cutoff2)
 {
-#ifdef SMCX_CHECK
-    (void)S; (void)WPR; (void)N; (void)M2; (void)L; (void)Lz; (void)cutoff2;
-    return false;
-#else
     return ((S == 64 && WPR == 4) || (S == 32 && WPR == 8)) && N > 8192 && N <= 16384 && M2 + 1 <= 30 &&
            mc_box_supported(L, Lz, cutoff2);
-#endif
 }
 
-#ifndef SMCX_CHECK
 // the multi-wave form has its own launcher: no int16-screen numbers are needed (the byte screen's come from mc_bound)
 hipError_t launch_sweeps_mcw(const SweepArgs &s, const DevCtx &c, int WPR, int nsweeps, double A, hipStream_t st,
                              SweepTimer *tm)
@@ -349,6 +361,9 @@ hipError_t launch_sweeps_mcw(const SweepArgs &s, const DevCtx &c, int WPR, int n
     mc_bound_values(c.L, c.cutoff2, &a.toFix, &a.zsafe, &a.negC, &a.RZ);
     a.zFix = a.toFix;
     a.Rs = c.Rs; a.loc = c.loc; a.pad0 = 0; a.dbg = nullptr; a.prio = c.prio;
+#ifdef SMCX_CHECK
+    a.dbg = s.dbg;
+#endif
     const double toFix16 = 65536.0 / c.L; // the Morton code of the z sort takes x, y in units of L/65536
     for (int sw = 0; sw < nsweeps; sw++) {
         hipLaunchKernelGGL((zsort_kernel<4 * 64 * 64, 1024>), dim3(c.nrep), dim3(1024), 0, st, (const double *)s.R, c.Rs, c.loc,
@@ -366,9 +381,6 @@ hipError_t launch_sweeps_mcw(const SweepArgs &s, const DevCtx &c, int WPR, int n
     }
     return hipSuccess;
 }
-#else
-hipError_t launch_sweeps_mcw(const SweepArgs &, const DevCtx &, int, int, double, hipStream_t, SweepTimer *) { return hipErrorInvalidValue; }
-#endif
 
 void mc_bound(double L, double cutoff2, double *toFix, double *zsafe, int *negC, int *RZ);
 
@@ -448,12 +460,10 @@ hipError_t launch_sweeps_ma(const SweepArgs &s, const DevCtx &c, const KernelPla
             if (rc != hipSuccess) return rc;
             if (mc && S == 64)
                 hipLaunchKernelGGL(sweep_kernel_mc64, dim3(c.nrep), dim3(64), mc_lds_bytes(), st, a);
-#ifndef SMCX_CHECK
             else if (mc && S == 32)
                 hipLaunchKernelGGL(sweep_kernel_mc32, dim3(c.nrep), dim3(64), mc_lds_bytes(), st, a);
             else if (mc)
                 hipLaunchKernelGGL(sweep_kernel_mc16, dim3(c.nrep), dim3(64), mc_lds_bytes(), st, a);
-#endif
             else
                 hipLaunchKernelGGL(sweep_kernel_mb64, dim3(c.nrep), dim3(64), mb_lds_bytes(64), st, a);
             rc = hipGetLastError();

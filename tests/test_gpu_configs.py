@@ -311,25 +311,27 @@ root = sys.argv[1]
 os.environ["SMCX_LIB"] = os.path.join(root, "montecarlo-surfacer_amd", "libsmcx_check.so")
 spec = importlib.util.spec_from_file_location("smcx_chk", os.path.join(root, "montecarlo-surfacer_amd", "__init__.py"))
 K = importlib.util.module_from_spec(spec); spec.loader.exec_module(K)
-N, Na, Nz, nrep, nsw, gl = (int(v) for v in sys.argv[2:8])
-p = K.default_params(N, nrep, tune_slots=64, tune_waves=1)
+N, Na, Nz, nrep, nsw, gl, slots, waves = (int(v) for v in sys.argv[2:10])
+p = K.default_params(N, nrep, tune_slots=slots, tune_waves=waves)
 with K.Engine(p) as eng:
     name = eng.kernel_form[1]
     eng.upload(K.fcc_init(Na, Nz), K.W_REFERENCE)
     eng.run(0, nsw, gl)
-    cnt = (C.c_uint64 * 3)()
-    f = K._lib().smcx_debug_check_counts
+    cnt = (C.c_uint64 * 8)()
+    f = K._lib().smcx_debug_work_counts
     f.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
     assert f(eng._h, cnt) == 0
     acc = int(eng.observables()["accepted"].sum())
-print(json.dumps({"name": name, "inside": int(cnt[0]), "cand": int(cnt[1]), "miss": int(cnt[2]), "acc": acc}))
+print(json.dumps({"name": name, "inside": int(cnt[0]), "cand": int(cnt[1]), "miss": int(cnt[2]), "groups": int(cnt[3]),
+                  "passes": int(cnt[4]), "acc": acc}))
 """
 
 
-def _run_check_worker(tmp_path, mode, N, lat, nrep, nsw, gl):
+def _run_check_worker(tmp_path, mode, N, lat, nrep, nsw, gl, slots=64, waves=1):
     w = tmp_path / "mbc_worker.py"
     w.write_text(_MBC_WORKER)
-    r = subprocess.run([sys.executable, str(w), ROOT, str(N), str(lat[0]), str(lat[1]), str(nrep), str(nsw), str(gl)],
+    r = subprocess.run([sys.executable, str(w), ROOT, str(N), str(lat[0]), str(lat[1]), str(nrep), str(nsw), str(gl),
+                        str(slots), str(waves)],
                        env=dict(os.environ, SMCX_CHECK_MB=mode), capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     return json.loads(r.stdout.strip().splitlines()[-1])
@@ -351,22 +353,33 @@ def test_ranged_screen_sets_every_bit_of_the_full_screen(tmp_path, N, lat, nrep,
     assert d["cand"] > moves and d["acc"] > 0
 
 
-@pytest.mark.parametrize("N,lat,nrep,nsw,gl", [(4096, (8, 16), 64, 4, 2), (4000, (10, 10), 32, 3, 1), (2100, (5, 21), 32, 3, 3),
-                                                (4096, (16, 4), 16, 2, 1)])
-def test_byte_screen_kernel_misses_no_pair_inside_the_cutoff(tmp_path, N, lat, nrep, nsw, gl):
-    """sweep_kernel_mc64 (the benchmark's kernel): one word per cell screened by v_dot4_i32_i8, only the groups in
-    z reach.  Its diagnostic build (SMCX_CHECK_MB=2) runs, beside EVERY pass, the fp64 cutoff test with the
+@pytest.mark.parametrize("N,lat,nrep,nsw,gl,slots,waves,kernel", [
+    (4096, (8, 16), 64, 4, 2, 64, 1, "mc64"), (4000, (10, 10), 32, 3, 1, 64, 1, "mc64"), (2100, (5, 21), 32, 3, 3, 64, 1, "mc64"),
+    (4096, (16, 4), 16, 2, 1, 64, 1, "mc64"),
+    (1024, (8, 4), 64, 4, 2, 16, 1, "mc16"), (1000, (5, 10), 32, 3, 1, 16, 1, "mc16"),          # config 2's kernel
+    (2048, (8, 8), 32, 3, 1, 32, 1, "mc32"),
+    (16384, (16, 16), 4, 2, 1, 64, 4, "mc64x4"), (16384, (16, 16), 4, 2, 1, 32, 8, "mc32x8"),   # config 5's kernels
+    (9000, (15, 10), 4, 2, 2, 64, 4, "mc64x4"), (10000, (10, 25), 4, 2, 1, 32, 8, "mc32x8")])   # ragged, tall
+def test_byte_screen_kernel_misses_no_pair_inside_the_cutoff(tmp_path, N, lat, nrep, nsw, gl, slots, waves, kernel):
+    """sweep_kernel_mc64 (the benchmark's kernel), mc16 / mc32 (N <= 2048) and the several-wavefront forms mc64x4 /
+    mc32x8 (8192 < N <= 16384): one word per cell screened by v_dot4_i32_i8, only the groups in
+    z reach.  The diagnostic build (SMCX_CHECK_MB=2) runs, beside EVERY pass, the fp64 cutoff test with the
     minimum image of SMC.c:567-578 on EVERY cell from the fp64 positions in memory and counts the pairs inside
     the cutoff whose bit the pass did not set (the moving particle and the probe's own particle excepted, as
     in the reference's loop): must be zero; the counts of true pairs and of candidate bits show the check is not
     vacuous and how tight the screen is (the byte units flag about 1.5x the cutoff sphere).  Last case: the dense
     film fcc(16,4), ~60 pairs inside the cutoff per probe."""
-    d = _run_check_worker(tmp_path, "2", N, lat, nrep, nsw, gl)
+    d = _run_check_worker(tmp_path, "2", N, lat, nrep, nsw, gl, slots, waves)
     moves = nrep * nsw * N
-    print("N=%d: %d moves, %d pairs inside the cutoff, %d candidate bits (%.2fx), %d missed" %
-          (N, moves, d["inside"], d["cand"], d["cand"] / max(d["inside"], 1), d["miss"]))
-    assert d["name"] == "smcx::sweep_kernel_mc64"
+    print("N=%d %s: %d moves, %d pairs inside the cutoff, %d candidate bits (%.2fx), %d missed; %.2f groups of %d per pass, "
+          "%.2f passes per move and wavefront" %
+          (N, kernel, moves, d["inside"], d["cand"], d["cand"] / max(d["inside"], 1), d["miss"],
+           d["groups"] / max(d["passes"], 1), slots // 4, d["passes"] / (moves * waves)))
+    assert d["name"] == "smcx::sweep_kernel_" + kernel
     assert d["miss"] == 0
+    # the executed-work counters: two passes per move and wavefront (+ one per run start), at most all groups each
+    assert 2 * moves * waves <= d["passes"] <= 2 * (moves + 4 * nrep * nsw) * waves
+    assert 0 < d["groups"] <= d["passes"] * (slots // 4)
     assert d["inside"] > moves and d["cand"] >= d["inside"] and d["acc"] > 0
     assert d["cand"] < 3 * d["inside"] + 40 * moves
 
