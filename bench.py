@@ -33,38 +33,103 @@ MEASURED_COST = {"b32": 3.0, "f64": 3.43, "trans_f64": 8.0}
 
 
 def issue_roofline(kname, sweep_ms_per_sweep, nrep, N, clock_ghz):
-    """VALU-issue roofline of the sweep kernel: SIMD cycles the executed wave-instructions need at the
+    """VALU-issue roofline of a sweep kernel: SIMD cycles the executed wave-instructions need at the
     guide's issue costs, over the SIMD cycles that passed (1024 SIMDs x in-kernel clock x time).
-    Instruction counts per wave-move by class come from the committed PMC run of this kernel
-    (profiles/kernel_counters.json, tools/profile_valu.sh + tools/pmc_to_json.py)."""
+    Instruction counts per wave-move by class come from the committed PMC run of this kernel on this
+    workload (profiles/kernel_counters.json, tools/profile_valu.sh + tools/pmc_to_json.py); a wave-move is
+    one trial move seen by one wavefront (the several-wavefront kernels run every move on all their waves)."""
     path = os.path.join(ROOT, "profiles", "kernel_counters.json")
     if not os.path.exists(path) or not clock_ghz:
         return None
     kc = json.load(open(path)).get(kname)
     if not kc:
         return None
+    if kc["workload"]["replicas"] != nrep or kc["workload"]["N"] != N:
+        return None                                                  # counters are of another workload
     m = kc["per_wave_move"]
     f64 = m.get("SQ_INSTS_VALU_ADD_F64", 0) + m.get("SQ_INSTS_VALU_MUL_F64", 0) + m.get("SQ_INSTS_VALU_FMA_F64", 0)
     tr = m.get("SQ_INSTS_VALU_TRANS_F64", 0)
     b32 = m["SQ_INSTS_VALU"] - f64 - tr
-    moves_per_s = nrep * N / (sweep_ms_per_sweep * 1e-3)          # wave-moves per second (one wavefront per replica)
-    if kc["workload"]["replicas"] * kc["workload"]["N"] != nrep * N:
-        return None                                                  # counters are of another workload
-    waves_per_replica = kc.get("waves_per_replica", 1)
+    wpr = kc["workload"].get("waves_per_replica", 1)
+    moves_per_s = nrep * N / (sweep_ms_per_sweep * 1e-3)             # trial moves per second, all replicas
+    wave_moves_per_s = moves_per_s * wpr
     need = b32 * GUIDE_COST["b32"] + f64 * GUIDE_COST["f64"] + tr * GUIDE_COST["trans_f64"]
     need_m = b32 * MEASURED_COST["b32"] + f64 * MEASURED_COST["f64"] + tr * MEASURED_COST["trans_f64"]
     peak = N_SIMD * clock_ghz                                        # G SIMD-cycles per second
-    achieved = need * moves_per_s / 1e9
-    return {"bound": "valu_issue", "achieved": achieved, "peak": peak, "unit": "G SIMD-cycles/s of VALU issue",
-            "frac": achieved / peak,
-            "frac_at_measured_costs": need_m * moves_per_s / 1e9 / peak,
-            "clock_ghz": clock_ghz, "clock_source": "s_memtime / s_memrealtime inside the timed sweep launch, median over wavefronts",
-            "valu_wave_instr_per_move": m["SQ_INSTS_VALU"], "of_which_fp64": f64, "fp64_transcendental": tr,
-            "salu_per_move": m.get("SQ_INSTS_SALU"), "lds_per_move": m.get("SQ_INSTS_LDS"),
-            "vmem_rd_per_move": m.get("SQ_INSTS_VMEM_RD"), "guide_issue_cycles_per_move": need,
-            "simd_cycles_per_move": peak * 1e9 / moves_per_s / waves_per_replica,
-            "counters": "profiles/kernel_counters.json (rocprofv3 --pmc, %d-sweep launch)" % kc["workload"]["sweeps_in_launch"],
-            "hbm_bytes_per_sweep_pmc": kc.get("hbm_bytes_per_sweep")}
+    achieved = need * wave_moves_per_s / 1e9
+    out = {"bound": "valu_issue", "achieved": achieved, "peak": peak, "unit": "G SIMD-cycles/s of VALU issue",
+           "frac": achieved / peak,
+           "frac_at_measured_costs": need_m * wave_moves_per_s / 1e9 / peak,
+           "clock_ghz": clock_ghz, "clock_source": "s_memtime / s_memrealtime inside the timed sweep launch, median over wavefronts",
+           "waves_per_replica": wpr,
+           "valu_wave_instr_per_move": m["SQ_INSTS_VALU"], "of_which_fp64": f64, "fp64_transcendental": tr,
+           "salu_per_move": m.get("SQ_INSTS_SALU"), "lds_per_move": m.get("SQ_INSTS_LDS"),
+           "vmem_rd_per_move": m.get("SQ_INSTS_VMEM_RD"), "guide_issue_cycles_per_wave_move": need,
+           "simd_cycles_per_wave_move": peak * 1e9 / wave_moves_per_s,
+           "counters": "profiles/kernel_counters.json (rocprofv3 --pmc, %d-sweep launch)" % kc["workload"]["sweeps_in_launch"]}
+    hb = kc.get("hbm_bytes_per_sweep")
+    if hb:
+        sec = sweep_ms_per_sweep * 1e-3
+        out["hbm"] = {"bytes_per_sweep_fetch_x2": hb["fetch_x2_plus_write"], "bytes_per_sweep_fetch_x1": hb["fetch_x1_plus_write"],
+                      "gbs_fetch_x2": hb["fetch_x2_plus_write"] / sec / 1e9, "gbs_fetch_x1": hb["fetch_x1_plus_write"] / sec / 1e9,
+                      "frac_of_peak_fetch_x2": hb["fetch_x2_plus_write"] / sec / 1e9 / HBM_PEAK_GBS,
+                      "frac_of_peak_fetch_x1": hb["fetch_x1_plus_write"] / sec / 1e9 / HBM_PEAK_GBS,
+                      "compulsory_bytes_per_sweep": nrep * (48.0 * N + 32.0 * N + 8),
+                      "note": "PMC FETCH_SIZE/WRITE_SIZE of the profiled launch over this run's time per sweep; x2 = the guide's "
+                              "gfx950 correction for wide reads, x1 = raw (these are 24-byte gathers: uncalibrated); compulsory = "
+                              "read+write every position once, one sweep of random numbers"}
+    return out
+
+
+_EXEC_WORKER = r"""
+import sys, os, ctypes as C, importlib.util, json
+root = sys.argv[1]
+os.environ["SMCX_LIB"] = os.path.join(root, "montecarlo-surfacer_amd", "libsmcx_check.so")
+spec = importlib.util.spec_from_file_location("smcx_chk", os.path.join(root, "montecarlo-surfacer_amd", "__init__.py"))
+K = importlib.util.module_from_spec(spec); spec.loader.exec_module(K)
+N, Na, Nz, nrep, nsw, slots, waves, dev = (int(v) for v in sys.argv[2:10])
+p = K.default_params(N, nrep, tune_slots=slots, tune_waves=waves, device=dev)
+with K.Engine(p) as eng:
+    name = eng.kernel_form[1]
+    eng.upload(K.fcc_init(Na, Nz), K.W_REFERENCE)
+    eng.run(0, nsw, 10)
+    cnt = (C.c_uint64 * 8)()
+    f = K._lib().smcx_debug_work_counts
+    f.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+    assert f(eng._h, cnt) == 0
+print(json.dumps({"name": name, "inside": int(cnt[0]), "cand": int(cnt[1]), "miss": int(cnt[2]), "groups": int(cnt[3]),
+                  "passes": int(cnt[4])}))
+"""
+
+
+def executed_work(kname, N, lattice, slots, waves, device, nrep=64, sweeps=2):
+    """What the z-ordered kernels EXECUTE per probe, counted by the diagnostic build of the same sources
+    (libsmcx_check.so, SMCX_CHECK_MB=2: counters beside every screen pass, plus the fp64 test of every cell) on a
+    sample of the same start, in a child process after the timed region: 4-slot groups screened per pass, hence
+    cells tested per move, candidate bits per probe, pairs truly inside the cutoff, pairs the screen missed (0)."""
+    import subprocess
+    if not os.path.exists(os.path.join(ROOT, "montecarlo-surfacer_amd", "libsmcx_check.so")):
+        return {"note": "libsmcx_check.so not built"}
+    env = {k: v for k, v in os.environ.items() if not (k.startswith("SMCX_") and k not in ("SMCX_FORCE_DEVICE",))}
+    env["SMCX_CHECK_MB"] = "2"
+    r = subprocess.run([sys.executable, "-c", _EXEC_WORKER, ROOT, str(N), str(lattice[0]), str(lattice[1]), str(nrep),
+                        str(sweeps), str(slots), str(waves), str(device)], env=env, capture_output=True, text=True, timeout=600)
+    if r.returncode != 0:
+        return {"note": "diagnostic run failed: " + r.stderr[-300:]}
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    if d["name"] != kname:
+        return {"note": "diagnostic build ran %s, not %s" % (d["name"], kname)}
+    moves = float(nrep) * sweeps * N
+    groups_total = slots // 4
+    gpp = d["groups"] / max(d["passes"], 1)
+    return {"groups_screened_per_pass": gpp, "groups_per_wavefront": groups_total, "wavefronts_per_replica": waves,
+            "passes_per_move": d["passes"] / moves,
+            "cells_screened_per_move": d["groups"] * 256.0 / moves, "cells_per_move_all_pairs": 2.0 * (N - 1),
+            "fraction_of_all_pairs_screened": d["groups"] * 256.0 / moves / (2.0 * (N - 1)),
+            "candidate_bits_per_probe": d["cand"] / (2.0 * moves), "pairs_inside_cutoff_per_probe": d["inside"] / (2.0 * moves),
+            "pairs_inside_cutoff_missed": d["miss"],
+            "source": "libsmcx_check.so (diagnostic build of the same sources, SMCX_CHECK_MB=2), %d replicas x %d sweeps "
+                      "of the same start, after the timed region" % (nrep, sweeps)}
 
 
 def cpu_baseline(N, Na, Nz, seconds_target=12.0):
@@ -128,24 +193,32 @@ def cpu_baseline(N, Na, Nz, seconds_target=12.0):
                       "oracle/smc_oracle.c built %s, %.1f s wall" % (cores, sweeps, N, Na, Nz, flags, wall)}
 
 
-def side_config(S, label, N, nrep, lattice, sweeps, device):
-    """one of the other BASELINE configurations, run briefly AFTER the timed region (not the headline)"""
-    p = S.default_params(N, nrep, device=device)
+def side_config(S, label, N, nrep, lattice, sweeps, device, kernel=0, executed=True):
+    """one of the other BASELINE configurations (or the headline workload through another kernel), run briefly
+    AFTER the timed region (not the headline)"""
+    p = S.default_params(N, nrep, device=device, tune_kernel=kernel)
     with S.Engine(p) as e:
         e.upload(S.fcc_init(*lattice), S.W_REFERENCE)
         e.run(0, 1, 10)
         e.run(0, sweeps, 10)
-        ms, _ = e.last_kernel_ms()
+        ms, launches = e.last_kernel_ms()
         run_ms = e.last_run_ms()
         try:
             ghz, _ = e.last_clock()
         except Exception:
             ghz = None
         s_, w_, _ = e.geometry
-        pe = nrep * sweeps * 2.0 * N * (N - 1.0)
-        return {"workload": label, "N": N, "replicas": nrep, "sweeps": sweeps, "value": pe / (run_ms * 1e-3),
-                "unit": "pair-evals/s (device time of the whole run)", "ms_per_sweep": ms / sweeps,
-                "kernel": e.kernel_form[1], "geometry": "S=%d x %d wavefront(s)" % (s_, w_), "clock_ghz": ghz}
+        kname = e.kernel_form[1]
+    pe = nrep * sweeps * 2.0 * N * (N - 1.0)
+    out = {"workload": label, "N": N, "replicas": nrep, "sweeps": sweeps, "value": pe / (run_ms * 1e-3),
+           "unit": "reference-equivalent pair-evals/s (device time of the whole run)", "ms_per_sweep": ms / sweeps,
+           "kernel": kname, "geometry": "S=%d x %d wavefront(s)" % (s_, w_), "clock_ghz": ghz}
+    rl = issue_roofline(kname, ms / sweeps, nrep, N, ghz)
+    out["roofline"] = rl if rl else {"bound": "valu_issue", "frac": None, "clock_ghz": ghz,
+                                     "note": "no PMC counters committed for this kernel and workload"}
+    if executed and "kernel_mc" in kname:
+        out["executed"] = executed_work(kname, N, lattice, s_, w_, device, nrep=min(nrep, 64 if N <= 4096 else 8))
+    return out
 
 
 def main():
@@ -245,7 +318,9 @@ def main():
         achieved = algo_bytes_per_launch / launch_s / 1e9
         traffic = None   # HBM bytes per launch from the committed PMC run of this kernel (set below)
         out = {
-            "metric": "pair-evals/s (MC sweeps/s x replicas x 2N(N-1)) at N=%d" % N,
+            "metric": "reference-equivalent pair-evals/s (MC sweeps/s x replicas x 2N(N-1), the pair tests the reference's "
+                      "loops run per sweep, SMC.c:563-578; the z-ordered kernel bounds most of them in bulk: see `executed` "
+                      "and `all_pairs_kernel`) at N=%d" % N,
             "value": value, "unit": "pair-evals/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": dt * 1e3 / a.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
@@ -279,8 +354,8 @@ def main():
             rl = {"bound": "valu_issue", "achieved": None, "peak": N_SIMD * clock_ghz if clock_ghz else None,
                   "unit": "G SIMD-cycles/s of VALU issue", "frac": None, "clock_ghz": clock_ghz,
                   "note": "no PMC instruction counts committed for this kernel and workload (profiles/kernel_counters.json)"}
-        elif rl.get("hbm_bytes_per_sweep_pmc"):
-            base["traffic"] = rl["hbm_bytes_per_sweep_pmc"]["fetch_x2_plus_write"] * (a.steps / max(launches, 1))
+        elif rl.get("hbm"):
+            base["traffic"] = rl["hbm"]["bytes_per_sweep_fetch_x2"] * (a.steps / max(launches, 1))
         rl.update(base)
         out["roofline"] = rl
         out["precision"] = ("every energy, force, acceptance test and position is fp64; the compact integer copies "
@@ -304,13 +379,28 @@ def main():
                                                 "unit": "pair-evals/s (sweep kernels only)"}
             except Exception as e:
                 out["fp64_only_kernels"] = {"value": None, "note": "failed: %r" % (e,)}
+        if world == 1 and not a.no_cpu and "kernel_mc" in kname:
+            # what the timed kernel executed per probe (diagnostic build, sample of the same start)
+            eng.close()
+            out["executed"] = executed_work(kname, N, lattice, S_, W_, local_rank, nrep=64 if N <= 4096 else 8)
         if world == 1 and not a.no_cpu and N == 4096:
-            # the other single-GPU BASELINE configurations, briefly, after the timed region
+            # the like-for-like kernel: the same workload through sweep_kernel_ma64, whose screen visits EVERY cell for
+            # every probe as the reference's loops do (SMC.c:563-578, 597-612)
+            try:
+                eng.close()
+                out["all_pairs_kernel"] = side_config(S, "the timed workload through the last kernel that tests every pair "
+                                                         "(tune_kernel = SMCX_KERNEL_MA)", N, nrep, lattice, 5, local_rank,
+                                                      kernel=S.KERNEL_MA, executed=False)
+            except Exception as e:
+                out["all_pairs_kernel"] = {"value": None, "note": "failed: %r" % (e,)}
+            # the other single-GPU BASELINE configurations and one adverse state, briefly, after the timed region
             out["other_configs"] = []
             for label, n_, r_, lat_, sw_ in (("BASELINE config 2: N=1024 + wall, 1024 replicas, fcc(8,4)", 1024, 1024, (8, 4), 40),
-                                             ("BASELINE config 5 per GPU: N=16384 + wall, 256 of 2048 replicas, fcc(16,16)", 16384, 256, (16, 16), 4)):
+                                             ("BASELINE config 5 per GPU: N=16384 + wall, 256 of 2048 replicas, fcc(16,16)", 16384, 256, (16, 16), 4),
+                                             ("adverse state for the z-ordered screen: N=4096 + wall, 4096 replicas, dense film "
+                                              "fcc(16,4) 8.25 high (most groups in reach of every probe, ~46 pairs inside the "
+                                              "cutoff per probe, acceptance 0.007)", 4096, 4096, (16, 4), 5)):
                 try:
-                    eng.close()
                     out["other_configs"].append(side_config(S, label, n_, r_, lat_, sw_, local_rank))
                 except Exception as e:
                     out["other_configs"].append({"workload": label, "value": None, "note": "failed: %r" % (e,)})

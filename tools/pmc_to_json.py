@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""pmc_to_json.py PROF_DIR OUT_JSON [N nrep sweeps] -- turn the rocprofv3 --pmc csv files of
+"""pmc_to_json.py PROF_DIR OUT_JSON [N nrep sweeps [waves_per_replica]] -- turn the rocprofv3 --pmc csv files of
 tools/profile_valu.sh into per-kernel counters of the LARGEST launch of every sweep kernel (the
 9-sweep launch of the default profile command) and per-wave-move figures.  bench.py reads the JSON
 (profiles/kernel_counters.json) for the instruction mix behind its roofline line."""
@@ -7,6 +7,7 @@ import csv, glob, json, os, sys
 
 d, out = sys.argv[1], sys.argv[2]
 N, nrep, sweeps = (int(v) for v in sys.argv[3:6]) if len(sys.argv) > 5 else (4096, 4096, 9)
+wpr = int(sys.argv[6]) if len(sys.argv) > 6 else 1
 res = {}
 for f in glob.glob(os.path.join(d, "*", "*", "*_counter_collection.csv")):
     best = {}
@@ -27,10 +28,14 @@ for f in glob.glob(os.path.join(d, "*", "*", "*_counter_collection.csv")):
         e["launch_ns"][cnt] = ns
 for name, e in res.items():
     c = e["counters"]
-    if "kernel_mb" in name or "kernel_mc" in name:      # one launch per z sort: SMCX_RESORT sweeps (default 1)
+    if "kernel_mb" in name or "kernel_mc" in name:      # one launch per z sort: tune_resort sweeps (default 1)
         sweeps = int(os.environ.get("SMCX_RESORT", "1"))
-    moves = float(nrep) * sweeps * N
-    e["workload"] = {"N": N, "replicas": nrep, "sweeps_in_launch": sweeps, "wave_moves": moves}
+    moves = float(nrep) * sweeps * N * wpr              # wave-moves: every wavefront of a replica runs every move
+    e["workload"] = {"N": N, "replicas": nrep, "sweeps_in_launch": sweeps, "wave_moves": moves, "waves_per_replica": wpr}
+    if "SQ_ACTIVE_INST_VALU" in c and "SQ_BUSY_CYCLES" in c:
+        # SQ_ACTIVE_INST_VALU: per SIMD, quad-cycles with a VALU instruction in flight; SQ_BUSY_CYCLES: per SE/XCD busy
+        # cycles summed (guide).  Reported against the launch time at the clock bench.py measures, see DESIGN section 6
+        e["active_inst_valu_quadcycles"] = c["SQ_ACTIVE_INST_VALU"]
     e["per_wave_move"] = {k: v / moves for k, v in c.items() if k.startswith("SQ_INSTS")}
     if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
         # gfx950: FETCH_SIZE counts 64 B per 128-B request of wide coalesced reads (guide, section HBM); these

@@ -15,4 +15,5 @@ rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_ANY SQ_WAI
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- python3 "$ROOT/bench.py" $ARGS > "$OUT/pmc_fetch.log" 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- python3 "$ROOT/bench.py" $ARGS > "$OUT/pmc_write.log" 2>&1
 python3 "$ROOT/tools/pmc_summary.py" "$OUT" | grep -v prepass
-python3 "$ROOT/tools/pmc_to_json.py" "$OUT" "$OUT/kernel_counters.json"
+# PMC_N / PMC_NREP / PMC_WPR: the workload of the bench args (default: config 3, one wavefront per replica)
+python3 "$ROOT/tools/pmc_to_json.py" "$OUT" "$OUT/kernel_counters.json" ${PMC_N:-4096} ${PMC_NREP:-4096} 9 ${PMC_WPR:-1}
