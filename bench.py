@@ -32,7 +32,7 @@ GUIDE_COST = {"b32": 2.0, "f64": 4.0, "trans_f64": 16.0}
 MEASURED_COST = {"b32": 3.0, "f64": 3.43, "trans_f64": 8.0}
 
 
-def issue_roofline(kname, sweep_ms_per_sweep, nrep, N, clock_ghz):
+def issue_roofline(kname, sweep_ms_per_sweep, nrep, N, clock_ghz, start=None):
     """VALU-issue roofline of a sweep kernel: SIMD cycles the executed wave-instructions need at the
     guide's issue costs, over the SIMD cycles that passed (1024 SIMDs x in-kernel clock x time).
     Instruction counts per wave-move by class come from the committed PMC run of this kernel on this
@@ -44,8 +44,9 @@ def issue_roofline(kname, sweep_ms_per_sweep, nrep, N, clock_ghz):
     kc = json.load(open(path)).get(kname)
     if not kc:
         return None
-    if kc["workload"]["replicas"] != nrep or kc["workload"]["N"] != N:
-        return None                                                  # counters are of another workload
+    if kc["workload"]["replicas"] != nrep or kc["workload"]["N"] != N or \
+            (start is not None and kc["workload"].get("start") != start):
+        return None                                                  # counters are of another workload / start state
     m = kc["per_wave_move"]
     f64 = m.get("SQ_INSTS_VALU_ADD_F64", 0) + m.get("SQ_INSTS_VALU_MUL_F64", 0) + m.get("SQ_INSTS_VALU_FMA_F64", 0)
     tr = m.get("SQ_INSTS_VALU_TRANS_F64", 0)
@@ -213,7 +214,7 @@ def side_config(S, label, N, nrep, lattice, sweeps, device, kernel=0, executed=T
     out = {"workload": label, "N": N, "replicas": nrep, "sweeps": sweeps, "value": pe / (run_ms * 1e-3),
            "unit": "reference-equivalent pair-evals/s (device time of the whole run)", "ms_per_sweep": ms / sweeps,
            "kernel": kname, "geometry": "S=%d x %d wavefront(s)" % (s_, w_), "clock_ghz": ghz}
-    rl = issue_roofline(kname, ms / sweeps, nrep, N, ghz)
+    rl = issue_roofline(kname, ms / sweeps, nrep, N, ghz, start="fcc(%d,%d)" % tuple(lattice))
     out["roofline"] = rl if rl else {"bound": "valu_issue", "frac": None, "clock_ghz": ghz,
                                      "note": "no PMC counters committed for this kernel and workload"}
     if executed and "kernel_mc" in kname:
@@ -344,7 +345,7 @@ def main():
             "observables": {"mean_acceptance": summ["mean_acceptance"], "mean_energy": summ["mean_of_meanE"],
                             "replicas_gathered": int(len(obs["accepted"]))},
         }
-        rl = issue_roofline(kname, sweep_ms / a.steps, nrep, N, clock_ghz)
+        rl = issue_roofline(kname, sweep_ms / a.steps, nrep, N, clock_ghz, start="fcc(%d,%d)" % tuple(lattice))
         base = {"kernel": kname, "launches": launches, "avg_launch_ms": sweep_ms / max(launches, 1),
                 # what `rocprofv3 --stats` averages over: the warm-up launches as well
                 "launches_incl_warmup": launches + warm_launches,

@@ -44,6 +44,7 @@ extern "C" {
 #define SMCX_ERR_NOMEM 4
 #define SMCX_ERR_UNSUPPORTED 5 /* valid request this build cannot serve */
 #define SMCX_ERR_NODEVICE 6    /* no HIP device visible */
+#define SMCX_ERR_RCCL 7        /* the RCCL observable gather across the node's GPUs failed (smcx_host_sMC_multi) */
 
 /* flags */
 #define SMCX_FLAG_WALLS 0x1u      /* K3/K4 wall terms on (SMC.c:300-304); off = particles only */

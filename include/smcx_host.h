@@ -75,6 +75,20 @@ int smcx_host_sMC(const smcx_params *p, const double *W, const double *R0, int m
                   int gather_lapse, int eqsteps, smcx_sim *out);
 void smcx_host_sim_free(smcx_sim *s);
 
+/* The same for the GPUs of one node -- what replaces the reference's one-chain-per-MPI-rank fan-out (SMC.c:40, 43,
+ * 66-95: ranks share R0 and W, differ in their seed and never communicate).  p->nrep replica chains are dealt in
+ * contiguous blocks to `ndev` devices (devices[0..ndev-1], or 0..ndev-1 when NULL), one handle and one host thread per
+ * device; seeds follow the global replica index, so the results do not depend on ndev.  No exchange while sampling;
+ * the final observable gather -- (8 + Ncz) doubles per replica -- is ONE RCCL all-gather over xGMI (ncclCommInitAll,
+ * one communicator rank per device, ncclAllGather inside a group call), also with ndev == 1 (a one-rank
+ * communicator); SMCX_HOST_GATHER=host concatenates through host memory instead.  Final positions travel over PCIe
+ * (smcx_download_positions per device).  Returns an smcx status; SMCX_ERR_RCCL if the collective failed
+ * (smcx_host_multi_error() has the text).  `out` as for smcx_host_sMC, over all replicas in global order;
+ * kernel_ms = the slowest device's. */
+int smcx_host_sMC_multi(const smcx_params *p, int ndev, const int *devices, const double *W, const double *R0,
+                        int maxsteps, int gather_lapse, int eqsteps, smcx_sim *out);
+const char *smcx_host_multi_error(void);
+
 /* The reference's result files for the last smcx_run of `h`, one set per replica with
  * the replica's global index as the `_rank` suffix (SMC.c:66-95 names them per MPI rank):
  *   data_N%d_M%d_r%0.4f_T%0.2f_rank%d.csv    "E, P, jj"  one row per gather   (SMC.c:75-77, 214-215)

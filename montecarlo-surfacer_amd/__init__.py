@@ -17,7 +17,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SMCX_LIB") or os.path.join(_HERE, "libsmcx.so")  # SMCX_LIB: diagnostic builds
 
-OK, ERR_PARAM, ERR_HIP, ERR_STATE, ERR_NOMEM, ERR_UNSUPPORTED, ERR_NODEVICE = range(7)
+OK, ERR_PARAM, ERR_HIP, ERR_STATE, ERR_NOMEM, ERR_UNSUPPORTED, ERR_NODEVICE, ERR_RCCL = range(8)
 FLAG_WALLS, FLAG_E0_RESTART, FLAG_SERIES, FLAG_FULL_HIST, FLAG_PRESSURE, FLAG_CLUSTERS = 1, 2, 4, 8, 16, 32
 FLAGS_REFERENCE = FLAG_WALLS | FLAG_E0_RESTART
 OBS_RECORD_DOUBLES = 8
@@ -62,6 +62,9 @@ EXPORTS = [
     "smcx_cluster_counts", "smcx_cluster_update", "smcx_cluster_analysis", "smcx_kernel_form", "smcx_screen_bound",
     "smcx_screen_bound_int", "smcx_screen_bound_byte", "smcx_last_clock", "smcx_debug_wave_spread",
 ]
+HOST_EXPORTS = ["smcx_host_sMC", "smcx_host_sMC_multi", "smcx_host_multi_error", "smcx_host_sim_free", "smcx_host_fcc_init",
+                "smcx_host_initialize_box", "smcx_host_initialize_walls", "smcx_host_box_for_N", "smcx_host_write_csv",
+                "smcx_host_read_last_state", "smcx_host_srand", "smcx_host_rand", "smcx_host_vec_box_muller"]
 
 
 def _lib():
@@ -428,6 +431,9 @@ def _host():
         H.smcx_host_write_csv.argtypes = [C.c_void_p, C.POINTER(Params), C.c_int, C.c_int, C.c_char_p]
         H.smcx_host_read_last_state.argtypes = [C.c_char_p, C.c_int, _dp]
         H.smcx_host_sMC.argtypes = [C.POINTER(Params), _dp, _dp, C.c_int, C.c_int, C.c_int, C.POINTER(HostSim)]
+        H.smcx_host_sMC_multi.argtypes = [C.POINTER(Params), C.c_int, C.POINTER(C.c_int), _dp, _dp, C.c_int, C.c_int, C.c_int,
+                                          C.POINTER(HostSim)]
+        H.smcx_host_multi_error.restype = C.c_char_p
         H.smcx_host_sim_free.argtypes = [C.POINTER(HostSim)]
         H.smcx_host_sim_free.restype = None
         _HOST = H
@@ -463,15 +469,23 @@ def write_csv(engine, maxsteps, gather_lapse, directory):
         raise SmcxError(rc, "smcx_host_write_csv")
 
 
-def host_sMC(p, W, R0, maxsteps, gather_lapse, eqsteps):
-    """smcx_host_sMC (the C driver mirroring sMC, SMC.c:21-267) -> dict of its results"""
+def host_sMC(p, W, R0, maxsteps, gather_lapse, eqsteps, gpus=0, devices=None):
+    """smcx_host_sMC (the C driver mirroring sMC, SMC.c:21-267) -> dict of its results; gpus > 0:
+    smcx_host_sMC_multi, the replicas dealt over that many devices and the observables gathered by RCCL"""
     sim = HostSim()
     W = np.ascontiguousarray(W, dtype=np.float64)
     R0 = np.ascontiguousarray(R0, dtype=np.float64)
-    rc = _host().smcx_host_sMC(C.byref(p), _p(W, C.c_double), _p(R0, C.c_double), maxsteps, gather_lapse,
-                               eqsteps, C.byref(sim))
-    if rc != OK:
-        raise SmcxError(rc, "smcx_host_sMC")
+    if gpus:
+        dv = None if devices is None else (C.c_int * gpus)(*devices)
+        rc = _host().smcx_host_sMC_multi(C.byref(p), gpus, dv, _p(W, C.c_double), _p(R0, C.c_double), maxsteps,
+                                         gather_lapse, eqsteps, C.byref(sim))
+        if rc != OK:
+            raise SmcxError(rc, "smcx_host_sMC_multi", _host().smcx_host_multi_error().decode())
+    else:
+        rc = _host().smcx_host_sMC(C.byref(p), _p(W, C.c_double), _p(R0, C.c_double), maxsteps, gather_lapse,
+                                   eqsteps, C.byref(sim))
+        if rc != OK:
+            raise SmcxError(rc, "smcx_host_sMC")
     n = sim.nrep
     out = {k: getattr(sim, k) for k in ("E", "dE", "acceptance_ratio", "therm_acceptance", "l1", "lca_analyses",
                                         "P", "dP", "tau", "cv", "kernel_ms", "pair_evals_per_s")}

@@ -143,6 +143,7 @@ extern "C" const char *smcx_strerror(int status)
     case SMCX_ERR_NOMEM: return "out of memory";
     case SMCX_ERR_UNSUPPORTED: return "unsupported configuration";
     case SMCX_ERR_NODEVICE: return "no HIP device";
+    case SMCX_ERR_RCCL: return "RCCL collective failed";
     default: return "unknown status";
     }
 }

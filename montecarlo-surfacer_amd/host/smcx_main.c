@@ -1,20 +1,29 @@
 /*
  * smcx_main.c -- command-line driver in the spirit of the reference's main.c:
- *   smcx_main eqsteps maxsteps numdata T [N [nrep [Na Nz]]]
+ *   smcx_main [--gpus G] eqsteps maxsteps numdata T [N [nrep [Na Nz]]]
  * (main.c:13-19 takes the first four; N is a macro there, SMC.h:29).  Prepares
- * the walls and the lattice (main.c:74-113), runs nrep replica chains on GPU 0
- * and prints the ensemble results (main.c:126-131).
+ * the walls and the lattice (main.c:74-113), runs nrep replica chains on GPU 0 --
+ * or, with --gpus G, dealt over GPUs 0..G-1 with the observables gathered by RCCL
+ * (smcx_host_sMC_multi: the reference's MPI ranks, SMC.c:40, 66-95) -- and prints
+ * the ensemble results (main.c:126-131).
  */
 #include "../../include/smcx_host.h"
 
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 
 int main(int argc, char **argv)
 {
+    int gpus = 0;
+    if (argc > 2 && strcmp(argv[1], "--gpus") == 0) {
+        gpus = (int)strtol(argv[2], NULL, 10);
+        if (gpus < 1) { fprintf(stderr, "--gpus needs a positive count\n"); return 2; }
+        argv += 2; argc -= 2;
+    }
     if (argc < 5) {
-        fprintf(stderr, "usage: %s eqsteps maxsteps numdata T [N [nrep [Na Nz]]]\n", argv[0]);
+        fprintf(stderr, "usage: smcx_main [--gpus G] eqsteps maxsteps numdata T [N [nrep [Na Nz]]]\n");
         return 2;
     }
     const int eqsteps = (int)strtol(argv[1], NULL, 10);
@@ -57,9 +66,12 @@ int main(int argc, char **argv)
            "%d+%d sweeps...\n", nrep, N, p.L, p.L, p.Lz, T, p.A, eqsteps, maxsteps);
 
     smcx_sim sim;
-    int rc = smcx_host_sMC(&p, W, R0, maxsteps, gather_lapse, eqsteps, &sim);
+    int rc = gpus ? smcx_host_sMC_multi(&p, gpus, NULL, W, R0, maxsteps, gather_lapse, eqsteps, &sim)
+                  : smcx_host_sMC(&p, W, R0, maxsteps, gather_lapse, eqsteps, &sim);
+    if (gpus && rc == SMCX_OK) printf("(%d GPU(s), observables gathered by RCCL)\n", gpus);
     if (rc != SMCX_OK) {
-        fprintf(stderr, "smcx_host_sMC: %s (%s)\n", smcx_strerror(rc), smcx_last_error_string(NULL));
+        fprintf(stderr, "%s: %s (%s)\n", gpus ? "smcx_host_sMC_multi" : "smcx_host_sMC", smcx_strerror(rc),
+                gpus && smcx_host_multi_error()[0] ? smcx_host_multi_error() : smcx_last_error_string(NULL));
         free(R0);
         return 1;
     }

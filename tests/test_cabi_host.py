@@ -29,6 +29,24 @@ def test_library_exports_every_declared_symbol(S):
     assert sorted(S.EXPORTS) == names  # the Python binding covers the whole ABI
 
 
+def test_host_library_exports_every_declared_symbol(S):
+    """libsmcx_host.so (plain C above the ABI, incl. the RCCL multi-GPU driver) against include/smcx_host.h"""
+    hdr = open(os.path.join(ROOT, "include", "smcx_host.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    names = sorted(set(re.findall(r"\b(smcx_host_[a-z_0-9A-Z]+)\s*\(", hdr)))
+    assert "smcx_host_sMC_multi" in names and len(names) >= 12
+    lib = C.CDLL(S.HOST_LIB_PATH)
+    for n in names:
+        assert hasattr(lib, n), "libsmcx_host.so does not export %s" % n
+    assert sorted(S.HOST_EXPORTS) == names
+    out = subprocess.run(["ldd", S.HOST_LIB_PATH], capture_output=True, text=True).stdout
+    assert "librccl" in out and "libsmcx.so" in out and "oracle" not in out
+    assert C.CDLL(S.LIB_PATH).smcx_strerror  # (status 7 = the RCCL gather failed)
+    f = C.CDLL(S.LIB_PATH).smcx_strerror
+    f.restype = C.c_char_p
+    assert f(S.ERR_RCCL) == b"RCCL collective failed"
+
+
 def test_no_oracle_in_product():
     """the product never links or imports the oracle"""
     pkg = os.path.join(ROOT, "montecarlo-surfacer_amd")

@@ -506,6 +506,56 @@ def test_host_sMC_driver(S, O):
     assert sim["lca_analyses"] == 2 and rel(sim["l1"], np.mean(l1)) < 1e-12 and abs(sim["l2"].sum() - sim["l1"]) < 1e-9
 
 
+def test_multi_gpu_c_host_gathers_through_rccl(S, O):
+    """smcx_host_sMC_multi (plain C: one handle and one host thread per device, ncclCommInitAll + ncclAllGather of the
+    packed observable records -- the one exchange of the path) on the devices this box has.  Against
+    smcx_host_sMC (host-side reads of one handle), against the oracle, and against the Python gather of dist.py;
+    with two "devices" that are the same GPU (device list [0, 0] is refused by RCCL, so that leg uses the
+    host-concatenation fallback) the shard boundaries and the global seeds are exercised."""
+    L = 8.0
+    R0 = film_state(O, 4, 4, L, 0.05, 5)
+    nrep, maxsteps, gl, eq = 5, 6, 2, 1
+    flags = S.FLAGS_REFERENCE | S.FLAG_SERIES | S.FLAG_PRESSURE | S.FLAG_CLUSTERS
+    p = S.default_params(256, nrep, L=L, flags=flags, lca_time=1)
+    one = S.host_sMC(p, O.W_FIXTURE, R0, maxsteps, gl, eq)
+    multi = S.host_sMC(p, O.W_FIXTURE, R0, maxsteps, gl, eq, gpus=1)            # RCCL path, one-rank communicator
+    for k in ("E", "dE", "acceptance_ratio", "therm_acceptance", "P", "dP", "tau", "cv", "l1"):
+        assert multi[k] == one[k] or rel(multi[k], one[k]) < 1e-14, k
+    for k in ("rep_E", "rep_acceptance", "zprofile", "Rfinal", "l2", "l3"):
+        assert np.array_equal(multi[k], one[k]), k
+    s = sys_of(O, p)
+    for r in (0, nrep - 1):
+        ref = O.chain(s, 12345 + r, R0, O.W_FIXTURE, T, A, eq, maxsteps, gl)
+        assert rel(multi["rep_E"][r], ref["meanE"]) < 1e-9 and rel(multi["rep_acceptance"][r], ref["acceptance_ratio"]) < 1e-12
+    # two shards (3 + 2 replicas) on the same GPU through the host-concatenation fallback: same numbers, global order
+    os.environ["SMCX_HOST_GATHER"] = "host"
+    try:
+        two = S.host_sMC(p, O.W_FIXTURE, R0, maxsteps, gl, eq, gpus=2, devices=[0, 0])
+    finally:
+        del os.environ["SMCX_HOST_GATHER"]
+    for k in ("rep_E", "rep_acceptance", "Rfinal"):
+        assert np.array_equal(two[k], one[k]), k
+    assert rel(two["E"], one["E"]) < 1e-14 and np.allclose(two["zprofile"], one["zprofile"], rtol=1e-14, atol=0)
+    assert rel(two["P"], one["P"]) < 1e-13 and rel(two["l1"], one["l1"]) < 1e-13
+    # bad requests: more devices than the box has, more devices than replicas
+    with pytest.raises(S.SmcxError) as e:
+        S.host_sMC(p, O.W_FIXTURE, R0, maxsteps, gl, eq, gpus=S.device_count() + 1)
+    assert e.value.status == S.ERR_PARAM
+    with pytest.raises(S.SmcxError):
+        S.host_sMC(S.default_params(256, 1, L=L), O.W_FIXTURE, R0, 2, 1, 0, gpus=2, devices=[0, 0])
+
+
+def test_smcx_main_with_gpus_option(S, O):
+    """the C driver program with --gpus 1: the RCCL gather path end to end, same printout as without"""
+    exe = os.path.join(os.path.dirname(S.LIB_PATH), "smcx_main")
+    a = subprocess.run([exe, "1", "4", "2", "1.1", "256", "3", "4", "4"], capture_output=True, text=True, timeout=600)
+    b = subprocess.run([exe, "--gpus", "1", "1", "4", "2", "1.1", "256", "3", "4", "4"], capture_output=True, text=True, timeout=600)
+    assert a.returncode == 0 and b.returncode == 0, (a.stderr[-800:], b.stderr[-800:])
+    pick = lambda t: [ln for ln in t.splitlines() if ln.startswith(("Mean energy", "Mean pressure", "Average acceptance", "z profile"))]
+    assert pick(a.stdout) == pick(b.stdout) and len(pick(a.stdout)) == 4
+    assert "gathered by RCCL" in b.stdout
+
+
 def test_csv_outputs_and_restart(S, O, tmp_path):
     """8f.1: data_/local_/last_state_ files in the reference's formats (SMC.c:75-82, 214-225;
     main.c:162-170), and a restart from last_state (main.c:98-108)"""
