@@ -19,6 +19,7 @@ MODE  kernel                what differs
                             executed work: passes, 4-slot groups screened, candidate bits
  z8w  sweep_kernel_mc64x4   z8 for 4 (NS = 64) or 8 (NS = 32) wavefronts per replica, 8192 < N <= 16384: every wave owns a
       sweep_kernel_mc32x8   slab of the z order and runs the whole move loop; reductions completed across waves via LDS
+      sweep_kernel_mc32x4   (NS = 32 with 4 wavefronts: 4096 < N <= 8192)
  z8wc (diagnostic of z8w)   as z8c, every wave testing its own cells
 
 A move (iteration i of a run; particle n = first + i; ma: in register slot 0 of lane tl; zb/z8: in cell locA):
@@ -85,7 +86,7 @@ Z8C = MODE in ("z8c", "z8wc")
 # same Metropolis decision); operand %3 = the wave's index
 W4 = MODE in ("z8w", "z8wc")
 WPR = (int(sys.argv[4]) if len(sys.argv) > 4 else 256 // NS) if W4 else 1   # wavefronts per replica: 4 (NS = 64) or 8 (NS = 32)
-assert WPR in (1, 4, 8)
+assert WPR in (1, 4, 8)                                   # (NS = 32 with 4: 4096 < N <= 8192)
 WSH = (NS * 64).bit_length() - 1                          # cell >> WSH = the wave that owns it
 SLOTF = ((NS.bit_length() - 1) << 16) | 6                 # s_bfe field of the slot inside a cell index
 Z8 = Z8C or W4 or MODE == "z8"
@@ -2102,6 +2103,6 @@ with open(sys.argv[1] if len(sys.argv) > 1 else "smcx_sweep_ma_body.inc", "w") a
     f.write("// generated by gen_sweep_ma.py -- do not edit\n")
     for ln in out:
         # labels are per variant: the three bodies are assembled into one object
-        ln = re.sub(r"\bL_(\w+)", r"L%d%s_\1" % (NS, MODE), ln)
+        ln = re.sub(r"\bL_(\w+)", r"L%d%s%s_\1" % (NS, MODE, "x%d" % WPR if W4 else ""), ln)
         f.write('"%s\\n\\t"\n' % ln)
 print("%d lines" % len(out), file=sys.stderr)

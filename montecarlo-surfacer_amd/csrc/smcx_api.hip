@@ -268,7 +268,10 @@ static int choose_geometry(const smcx_params *p, const Tune &t, int *S, int *WPR
         // several wavefronts even with few replicas (N = 2048: 3.1-3.6 ms per sweep against 5.2-9.0 for 16 x 2 at
         // 128..1024 replicas, tools/probes/geom_rule.py); the split stays for boxes those kernels do not serve
         bool one_wave = (w == 1) && plan_for(p, s, 1, t, &pl) && pl.form >= FORM_MI;
-        if (w > 1 && plan_for(p, s, w, t, &pl) && pl.form == FORM_MC) {          // its several-wave forms: 64 x 4, or
+        if (w == 2 && s == 64 && plan_for(p, 32, 4, t, &pl) && pl.form == FORM_MC) { // 4096 < N <= 8192: 32 x 4, z-ordered
+            s = 32; w = 4; one_wave = true;
+        }
+        if (w > 1 && s * w == 256 && plan_for(p, s, w, t, &pl) && pl.form == FORM_MC) { // its several-wave forms: 64 x 4, or
             one_wave = true;                                                     // 32 x 8 while the chip has room
             if ((long)p->nrep * 8 <= 2048) { s = 32; w = 8; }                    // (44.6 against 47.3 ms per sweep at 256)
         }

@@ -186,6 +186,23 @@ __global__ void __launch_bounds__(512, 1) sweep_kernel_mc32x8(MaArgs a)
         :
         : "memory", "vcc", "scc", "m0", SMCX_MA_SGPRS, SMCX_MA_V95);
 }
+// four wavefronts per replica with 32 cells per lane each: 4096 < N <= 8192 (NS = 32 with WPR = 4)
+__global__ void __launch_bounds__(256, 1) sweep_kernel_mc32x4(MaArgs a)
+{
+    unsigned lane = threadIdx.x & 63;
+    unsigned long long kp = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
+    unsigned rep = blockIdx.x;
+    unsigned wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    asm volatile(
+#ifdef SMCX_CHECK
+#include "smcx_sweep_mcw4c_body32.inc"
+#else
+#include "smcx_sweep_mcw4_body32.inc"
+#endif
+        : "+v"(lane), "+s"(kp), "+s"(rep), "+s"(wv)
+        :
+        : "memory", "vcc", "scc", "m0", SMCX_MA_SGPRS, SMCX_MA_V95);
+}
 #ifdef SMCX_CHECK
 constexpr unsigned mcw_lds_bytes(int wpr) { return (unsigned)wpr * 2048u + 2u * (unsigned)wpr * 512u + (unsigned)wpr * 32u; }
 #else
@@ -338,12 +355,13 @@ int ma_cap(const Tune &t, int S)
 #endif
 }
 
-// several wavefronts per replica with the cells in z order: 64 x 4 or 32 x 8, 8192 < N <= 16384, in a box the byte
-// screen serves
+// several wavefronts per replica with the cells in z order: 64 x 4 or 32 x 8 for 8192 < N <= 16384, 32 x 4 for
+// 4096 < N <= 8192, in a box the byte screen serves
 bool mcw_built(int S, int WPR, int N, int M2, double L, double Lz, double cutoff2)
 {
-    return ((S == 64 && WPR == 4) || (S == 32 && WPR == 8)) && N > 8192 && N <= 16384 && M2 + 1 <= 30 &&
-           mc_box_supported(L, Lz, cutoff2);
+    const bool big = ((S == 64 && WPR == 4) || (S == 32 && WPR == 8)) && N > 8192 && N <= 16384;
+    const bool mid = S == 32 && WPR == 4 && N > 4096 && N <= 8192;
+    return (big || mid) && M2 + 1 <= 30 && mc_box_supported(L, Lz, cutoff2);
 }
 
 // the multi-wave form has its own launcher: no int16-screen numbers are needed (the byte screen's come from mc_bound)
@@ -365,13 +383,20 @@ hipError_t launch_sweeps_mcw(const SweepArgs &s, const DevCtx &c, int WPR, int n
     a.dbg = s.dbg;
 #endif
     const double toFix16 = 65536.0 / c.L; // the Morton code of the z sort takes x, y in units of L/65536
+    const bool mid = s.N <= 8192; // 32 cells per lane x 4 wavefronts: 8192 cells
     for (int sw = 0; sw < nsweeps; sw++) {
-        hipLaunchKernelGGL((zsort_kernel<4 * 64 * 64, 1024>), dim3(c.nrep), dim3(1024), 0, st, (const double *)s.R, c.Rs, c.loc,
-                           s.N, toFix16);
+        if (mid)
+            hipLaunchKernelGGL((zsort_kernel<2 * 64 * 64, 1024>), dim3(c.nrep), dim3(1024), 0, st, (const double *)s.R, c.Rs, c.loc,
+                               s.N, toFix16);
+        else
+            hipLaunchKernelGGL((zsort_kernel<4 * 64 * 64, 1024>), dim3(c.nrep), dim3(1024), 0, st, (const double *)s.R, c.Rs, c.loc,
+                               s.N, toFix16);
         a.sw0 = sw;
         hipError_t rc = tm ? tm->mark(st) : hipSuccess;
         if (rc != hipSuccess) return rc;
-        if (WPR == 4)
+        if (mid)
+            hipLaunchKernelGGL(sweep_kernel_mc32x4, dim3(c.nrep), dim3(256), mcw_lds_bytes(4), st, a);
+        else if (WPR == 4)
             hipLaunchKernelGGL(sweep_kernel_mc64x4, dim3(c.nrep), dim3(256), mcw_lds_bytes(4), st, a);
         else
             hipLaunchKernelGGL(sweep_kernel_mc32x8, dim3(c.nrep), dim3(512), mcw_lds_bytes(8), st, a);
@@ -407,6 +432,7 @@ void mc_bound(double L, double cutoff2, double *toFix, double *zsafe, int *negC,
 
 const char *ma_kernel_name(int form, int S, int WPR)
 {
+    if (form == FORM_MC && WPR == 4 && S == 32) return "smcx::sweep_kernel_mc32x4";
     if (form == FORM_MC && WPR == 4) return "smcx::sweep_kernel_mc64x4";
     if (form == FORM_MC && WPR == 8) return "smcx::sweep_kernel_mc32x8";
     if (form == FORM_MC) return S == 64 ? "smcx::sweep_kernel_mc64" : S == 32 ? "smcx::sweep_kernel_mc32" : "smcx::sweep_kernel_mc16";

@@ -12,6 +12,9 @@ every such difference is a relative perturbation of ~1e-16 per operation.
    (1e-13 grows to 1e-6 in 30-60 sweeps), so longer chains are
    compared through invariants, not value by value.
 """
+import os
+import subprocess
+
 import numpy as np
 import pytest
 
@@ -514,7 +517,7 @@ def test_multi_gpu_c_host_gathers_through_rccl(S, O):
     host-concatenation fallback) the shard boundaries and the global seeds are exercised."""
     L = 8.0
     R0 = film_state(O, 4, 4, L, 0.05, 5)
-    nrep, maxsteps, gl, eq = 5, 6, 2, 1
+    nrep, maxsteps, gl, eq = 5, 8, 2, 1
     flags = S.FLAGS_REFERENCE | S.FLAG_SERIES | S.FLAG_PRESSURE | S.FLAG_CLUSTERS
     p = S.default_params(256, nrep, L=L, flags=flags, lca_time=1)
     one = S.host_sMC(p, O.W_FIXTURE, R0, maxsteps, gl, eq)
@@ -832,17 +835,20 @@ def test_cluster_analysis_during_run(S, O):
     eng.close()
 
 
-@pytest.mark.parametrize("N", [66, 130, 1000, 2050, 4000])
+@pytest.mark.parametrize("N", [66, 130, 1000, 2050, 4000, 5000, 6144, 8192, 9000])
 def test_ragged_sizes_with_padding(S, O, N):
     """N that does not fill the launch geometry (padding lanes/slots, partial last slot, runs
-    that wrap inside a slot): two free-running sweeps against the oracle"""
+    that wrap inside a slot): two free-running sweeps against the oracle.  4096 < N <= 8192 runs the z-ordered
+    four-wavefront kernel sweep_kernel_mc32x4 (round 3: that range used to fall back to sweep_kernel_mx)."""
     rs = np.random.RandomState(N)
     Na = int(np.ceil((N / 4.0) ** (1 / 3.0))) + 1
     R0 = O.fcc(Na, Na).reshape(-1, 3)
     R0 = R0[rs.permutation(len(R0))[:N]].ravel().copy()
-    nrep = 3
+    nrep = 3 if N <= 4096 else 2
     eng, p = make_engine(S, O, R0, nrep)
     assert eng.geometry[0] * eng.geometry[1] * 64 >= N
+    if 4096 < N <= 8192:
+        assert eng.kernel_form[1] == "smcx::sweep_kernel_mc32x4" and eng.geometry[:2] == (32, 4)
     eng.run(0, 2, 1)
     ob = eng.observables()
     Rg = eng.positions()
