@@ -27,9 +27,13 @@ N_SIMD = 256 * 4          # MI355X_MICROARCH.md: 256 CUs x 4 SIMD-32
 # issue cost of one wave64 VALU instruction on a SIMD-32, MI355X_MICROARCH.md ("v_fma_f32 (wave64) 2 cyc",
 # fp64 at half rate: 4, transcendental 8 -> fp64 transcendental 16)
 GUIDE_COST = {"b32": 2.0, "f64": 4.0, "trans_f64": 16.0}
-# the same from this repo's own measurement at four waves per SIMD (profiles/r02_issue_costs.txt):
-# fast 32-bit forms 1.92, packed / 3-operand integer / converting / SGPR-source forms 3.42, fp64 3.43, v_rcp_f64 8.0
-MEASURED_COST = {"b32": 3.0, "f64": 3.43, "trans_f64": 8.0}
+# the same measured on this chip at four waves per SIMD (profiles/r02_issue_costs.txt): the fast 32-bit forms (VOP1/VOP2
+# add/sub/and/mov/shift with VGPR or inline-constant sources, v_fma_f32) 1.87 cycles, every other 32-bit form (packed,
+# dot, alignbit, 3-operand integer, conversions, compares, DPP, lane reads, any SGPR source) 3.44, fp64 3.43, v_rcp_f64 8.
+# The PMC classes do not separate fast from slow 32-bit forms, so the VALU pipe's busy fraction is bracketed:
+# every 32-bit instruction fast .. every one slow.
+MEASURED_COST_LO = {"b32": 1.87, "f64": 3.43, "trans_f64": 8.0}
+MEASURED_COST_HI = {"b32": 3.44, "f64": 3.43, "trans_f64": 8.0}
 
 
 def issue_roofline(kname, sweep_ms_per_sweep, nrep, N, clock_ghz, start=None):
@@ -55,12 +59,19 @@ def issue_roofline(kname, sweep_ms_per_sweep, nrep, N, clock_ghz, start=None):
     moves_per_s = nrep * N / (sweep_ms_per_sweep * 1e-3)             # trial moves per second, all replicas
     wave_moves_per_s = moves_per_s * wpr
     need = b32 * GUIDE_COST["b32"] + f64 * GUIDE_COST["f64"] + tr * GUIDE_COST["trans_f64"]
-    need_m = b32 * MEASURED_COST["b32"] + f64 * MEASURED_COST["f64"] + tr * MEASURED_COST["trans_f64"]
+    need_lo = b32 * MEASURED_COST_LO["b32"] + f64 * MEASURED_COST_LO["f64"] + tr * MEASURED_COST_LO["trans_f64"]
+    need_hi = b32 * MEASURED_COST_HI["b32"] + f64 * MEASURED_COST_HI["f64"] + tr * MEASURED_COST_HI["trans_f64"]
     peak = N_SIMD * clock_ghz                                        # G SIMD-cycles per second
     achieved = need * wave_moves_per_s / 1e9
     out = {"bound": "valu_issue", "achieved": achieved, "peak": peak, "unit": "G SIMD-cycles/s of VALU issue",
            "frac": achieved / peak,
-           "frac_at_measured_costs": need_m * wave_moves_per_s / 1e9 / peak,
+           "frac_at_measured_costs_range": [need_lo * wave_moves_per_s / 1e9 / peak, need_hi * wave_moves_per_s / 1e9 / peak],
+           # SQ_ACTIVE_INST_VALU is NOT a busy time: it advances by exactly 1 per VALU instruction of any form
+           # (tools/ubench/active_valu.hip), so "ACTIVE_INST_VALU x 4 cycles / kernel time" (0.99 for sweep_kernel_mc64)
+           # restates the instruction count at a nominal 4-cycle cadence; DESIGN section 6
+           "issue_slots_all_kinds_per_simd_cycle": (m["SQ_INSTS_VALU"] + (m.get("SQ_INSTS_SALU") or 0) + (m.get("SQ_INSTS_LDS") or 0)
+                                                    + (m.get("SQ_INSTS_VMEM_RD") or 0) + (m.get("SQ_INSTS_VMEM_WR") or 0)
+                                                    + (m.get("SQ_INSTS_SMEM") or 0)) * wave_moves_per_s / 1e9 / peak,
            "clock_ghz": clock_ghz, "clock_source": "s_memtime / s_memrealtime inside the timed sweep launch, median over wavefronts",
            "waves_per_replica": wpr,
            "valu_wave_instr_per_move": m["SQ_INSTS_VALU"], "of_which_fp64": f64, "fp64_transcendental": tr,

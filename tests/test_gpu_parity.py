@@ -524,8 +524,10 @@ def test_multi_gpu_c_host_gathers_through_rccl(S, O):
     multi = S.host_sMC(p, O.W_FIXTURE, R0, maxsteps, gl, eq, gpus=1)            # RCCL path, one-rank communicator
     for k in ("E", "dE", "acceptance_ratio", "therm_acceptance", "P", "dP", "tau", "cv", "l1"):
         assert multi[k] == one[k] or rel(multi[k], one[k]) < 1e-14, k
-    for k in ("rep_E", "rep_acceptance", "zprofile", "Rfinal", "l2", "l3"):
+    for k in ("rep_E", "rep_acceptance", "zprofile", "Rfinal"):
         assert np.array_equal(multi[k], one[k]), k
+    for k in ("l2", "l3"):
+        assert np.allclose(multi[k], one[k], rtol=1e-13, atol=0), k
     s = sys_of(O, p)
     for r in (0, nrep - 1):
         ref = O.chain(s, 12345 + r, R0, O.W_FIXTURE, T, A, eq, maxsteps, gl)
@@ -551,8 +553,8 @@ def test_multi_gpu_c_host_gathers_through_rccl(S, O):
 def test_smcx_main_with_gpus_option(S, O):
     """the C driver program with --gpus 1: the RCCL gather path end to end, same printout as without"""
     exe = os.path.join(os.path.dirname(S.LIB_PATH), "smcx_main")
-    a = subprocess.run([exe, "1", "4", "2", "1.1", "256", "3", "4", "4"], capture_output=True, text=True, timeout=600)
-    b = subprocess.run([exe, "--gpus", "1", "1", "4", "2", "1.1", "256", "3", "4", "4"], capture_output=True, text=True, timeout=600)
+    a = subprocess.run([exe, "1", "8", "4", "1.1", "256", "3", "4", "4"], capture_output=True, text=True, timeout=600)
+    b = subprocess.run([exe, "--gpus", "1", "1", "8", "4", "1.1", "256", "3", "4", "4"], capture_output=True, text=True, timeout=600)
     assert a.returncode == 0 and b.returncode == 0, (a.stderr[-800:], b.stderr[-800:])
     pick = lambda t: [ln for ln in t.splitlines() if ln.startswith(("Mean energy", "Mean pressure", "Average acceptance", "z profile"))]
     assert pick(a.stdout) == pick(b.stdout) and len(pick(a.stdout)) == 4

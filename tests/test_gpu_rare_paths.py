@@ -1,0 +1,166 @@
+"""The z-ordered kernels where their RARE paths run, against the ORACLE (which tests/test_ref_pin.py pins bit for
+bit on the real SMC.c), not against another kernel: one or two replicas, one or two sweeps each (0.2 s of oracle
+per N = 4096 sweep).  Reference semantics at stake: the acceptance test SMC.c:326-335 and the all-neighbour sums
+SMC.c:557-618 -- a dropped candidate shifts E by >= 4|V(rc)| = 5e-3 and sooner or later flips a decision.
+Required per case: accepted count of every sweep equal, energy series to 1e-9 relative, final positions to 1e-8,
+z histogram equal.
+"""
+import ctypes as C
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+T = A = 1.1
+S_KERNEL = {"ma64": 5, "mb64": 6}   # SMCX_KERNEL_MA, SMCX_KERNEL_MB (include/smcx.h)
+
+
+def _sys(O, p):
+    return O.make_sys(p.N, M=p.M, L=p.L, Lz=p.Lz, cutoff=p.cutoff, a0=p.a0, b0=p.b0, Ncx=p.Ncx, Ncz=p.Ncz)
+
+
+def _wrap(R, L):
+    R[:, 0] -= L * np.rint(R[:, 0] / L)
+    R[:, 1] -= L * np.rint(R[:, 1] / L)
+    return R
+
+
+def _state(O, case):
+    """(R0 [3N], L, Lz, flags, kernel name expected, extra params)"""
+    rs = np.random.RandomState(11)
+    if case == "dense_film":          # fcc(16,4): ~46 pairs inside the cutoff per probe, 12 of 16 groups in reach, fewer
+        L, Lz = 33.0, 240.0           # free lanes than wall sites -> fixed-lane fallback of assign_specials, several rounds
+        R = O.fcc(16, 4, L=L).reshape(-1, 3).copy()
+        R += 0.05 * rs.standard_normal(R.shape)
+        return _wrap(R, L).ravel(), L, Lz, None, "mc64", {}
+    if case == "dense_film_at_wall":  # the same pressed against the lower wall: wall sites act on most probes
+        L, Lz = 33.0, 240.0
+        R = O.fcc(16, 4, L=L).reshape(-1, 3).copy()
+        R += 0.05 * rs.standard_normal(R.shape)
+        R[:, 2] += -118.8 - R[:, 2].min()
+        return _wrap(R, L).ravel(), L, Lz, None, "mc64", {}
+    if case == "thin_film":           # fcc(24,1) in L = 48 (the widest box whose L/256 resolves the cutoff in 16 units):
+        L, Lz = 48.0, 240.0           # thinner than the cutoff: every group in reach of every probe, both flag words
+        R = O.fcc(24, 1, L=L).reshape(-1, 3).copy()
+        R += 0.05 * rs.standard_normal(R.shape)
+        return _wrap(R, L).ravel(), L, Lz, None, "mc64", {}
+    if case == "two_slabs_ragged":    # N = 4000 (empty cells at the end of the z order), no walls, half of the film
+        L, Lz = 33.0, 240.0           # 700 above the rest: most groups out of reach of every probe
+        R = O.fcc(8, 16, L=L).reshape(-1, 3)[:4000].copy()
+        R += 0.05 * rs.standard_normal(R.shape)
+        R[R[:, 2] > 6.0, 2] += 700.0
+        return _wrap(R, L).ravel(), L, Lz, "nowalls", "mc64", {}
+    if case in ("unsafe_z_mb64", "unsafe_z_ma64"):
+        # particles beyond the int16 range of the z words (zsafe = 32767 x 16 L/65536 = 264 at L = 33) are kept exact
+        # through the `unsafe` masks, and a probe out there tests every real cell.  (sweep_kernel_mc* cannot get
+        # there: its zsafe = 32766 L/256 lies beyond the upload bound |z| <= 4 Lz in every box it serves.)
+        L, Lz = 33.0, 240.0
+        R = O.fcc(8, 16, L=L).reshape(-1, 3)[:4000].copy()
+        R += 0.05 * rs.standard_normal(R.shape)
+        R[::131, 2] += 300.0          # 31 particles between 267 and 333
+        R[7::400, 2] = 264.5 + 0.3 * np.arange(len(R[7::400]))          # ten just beyond zsafe, within the cutoff of each other
+        return _wrap(R, L).ravel(), L, Lz, "nowalls", case[-4:], {"tune_kernel": S_KERNEL[case[-4:]]}
+    if case == "resort_3":            # three sweeps per z sort: group ranges widened by two sweeps of accepted moves
+        L, Lz = 33.0, 240.0
+        return O.fcc(8, 16, L=L), L, Lz, None, "mc64", {"tune_resort": 3}
+    if case == "mc16_dense":          # N = 1024 dense film through sweep_kernel_mc16 (config 2's kernel)
+        L, Lz = 33.0, 240.0
+        R = O.fcc(16, 1, L=L).reshape(-1, 3).copy()
+        R[:, 2] = 0.9 * rs.standard_normal(len(R))                      # a rough monolayer: overlaps, rejections
+        R += 0.05 * rs.standard_normal(R.shape)
+        return _wrap(R, L).ravel(), L, Lz, None, "mc16", {}
+    if case == "mc32_two_slabs":      # N = 2000 ragged, two slabs, through sweep_kernel_mc32
+        L, Lz = 33.0, 240.0
+        R = O.fcc(8, 8, L=L).reshape(-1, 3)[:2000].copy()
+        R += 0.05 * rs.standard_normal(R.shape)
+        R[R[:, 2] > 2.0, 2] += 60.0
+        return _wrap(R, L).ravel(), L, Lz, None, "mc32", {}
+    if case == "mc32x4_dense":        # 4096 < N <= 8192: the four-wavefront kernel on a dense film
+        L, Lz = 33.0, 240.0
+        R = O.fcc(16, 6, L=L).reshape(-1, 3).copy()                     # 6144 particles
+        R += 0.05 * rs.standard_normal(R.shape)
+        return _wrap(R, L).ravel(), L, Lz, None, "mc32x4", {}
+    if case == "mc64x4_two_slabs":    # config 5's kernel with two separated slabs and a ragged N
+        L, Lz = 33.0, 240.0
+        R = O.fcc(12, 16, L=L).reshape(-1, 3)[:9000].copy()             # 9216 -> 9000
+        R += 0.05 * rs.standard_normal(R.shape)
+        R[R[:, 2] > 4.0, 2] += 55.0
+        return _wrap(R, L).ravel(), L, Lz, None, "mc64x4", {}
+    raise ValueError(case)
+
+
+CASES = ["dense_film", "dense_film_at_wall", "thin_film", "two_slabs_ragged", "unsafe_z_mb64", "unsafe_z_ma64", "resort_3", "mc16_dense",
+         "mc32_two_slabs", "mc32x4_dense", "mc64x4_two_slabs"]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_rare_path_against_oracle(S, O, case):
+    R0, L, Lz, mode, kernel, extra = _state(O, case)
+    N = R0.size // 3
+    nrep, eq, nsw = 2, 0, (3 if case == "resort_3" else 2 if N <= 2304 else 1)
+    flags = S.FLAG_SERIES | (S.FLAG_E0_RESTART if mode == "nowalls" else S.FLAGS_REFERENCE)
+    geom = {"mc64": (64, 1), "mb64": (64, 1), "ma64": (64, 1), "mc32": (32, 1), "mc16": (16, 1), "mc32x4": (0, 0),
+            "mc64x4": (64, 4)}[kernel]
+    p = S.default_params(N, nrep, L=L, Lz=Lz, flags=flags, tune_slots=geom[0], tune_waves=geom[1], **extra)
+    with S.Engine(p) as eng:
+        assert eng.kernel_form[1] == "smcx::sweep_kernel_" + kernel, eng.kernel_form
+        eng.upload(R0, O.W_FIXTURE)
+        eng.run(eq, nsw, 1)
+        E, jj = eng.series(nsw)
+        ob = eng.observables()
+        Rg = eng.positions()
+    s = _sys(O, p)
+    W = O.W_FIXTURE
+    if mode == "nowalls":      # the oracle has no switch: a wall at infinity strength 0 = sites with zero strengths, plane off
+        s = O.make_sys(N, M=p.M, L=L, Lz=Lz, cutoff=p.cutoff, a0=0.0, b0=0.0, Ncx=p.Ncx, Ncz=p.Ncz)
+        W = np.zeros_like(O.W_FIXTURE)
+    total = 0
+    for r in range(nrep):
+        ref = O.chain(s, 12345 + r, R0, W, T, A, eq, nsw, 1)
+        assert list(jj[r]) == list(ref["jj"]), (case, r, list(jj[r]), list(ref["jj"]))
+        assert np.all(np.abs(E[r] - ref["E"]) <= 1e-9 * (1.0 + np.abs(ref["E"]))), (case, r, np.abs(E[r] - ref["E"]).max())
+        assert np.abs(Rg[r] - ref["R"]).max() < 1e-8, (case, r)
+        assert np.array_equal(ob["zhist"][r], ref["zhist"]), (case, r)
+        total += int(ref["accepted"])
+    assert total > 0 or case in ("dense_film", "dense_film_at_wall", "mc32x4_dense"), case
+
+
+def test_benchmark_kernel_ensemble_statistics_against_the_oracle(S, O):
+    """sweep_kernel_mc64 on the benchmark's system beyond the chaos horizon, with the ORACLE as the second arm:
+    64 replicas x 40 sweeps each (the oracle: one chain per host core, ~35 s on 16 cores).  Chains separate after
+    ~10 sweeps, so realised energies differ; the ensemble means of the final energy, of the accepted moves and the
+    ensemble z profile must agree within 4 standard errors -- a bias from a rare path (group ranges, lane
+    assignment, issue priorities are all configuration dependent) would accumulate here."""
+    N, nrep, nsw = 4096, 64, 40
+    R0 = O.fcc(8, 16)
+    p = S.default_params(N, nrep, flags=S.FLAGS_REFERENCE | S.FLAG_SERIES)
+    with S.Engine(p) as eng:
+        assert eng.kernel_form[1] == "smcx::sweep_kernel_mc64"
+        eng.upload(R0, O.W_FIXTURE)
+        eng.run(0, nsw, 10)
+        E, jj = eng.series(nsw)
+        zg = eng.observables()["zhist"].sum(axis=0).astype(float)
+    s = _sys(O, p)
+
+    def one(r):
+        ref = O.chain(s, 12345 + r, R0, O.W_FIXTURE, T, A, 0, nsw, 10)
+        return ref["E"][-1], float(ref["jj"].sum()), ref["zhist"].astype(float), ref["jj"][:5].copy(), ref["E"][:6].copy()
+    with ThreadPoolExecutor(16) as ex:                      # ctypes releases the GIL
+        refs = list(ex.map(one, range(nrep)))
+    Eo = np.array([r[0] for r in refs]); jo = np.array([r[1] for r in refs])
+    zo = np.sum([r[2] for r in refs], axis=0)
+    # inside the horizon the chains are THE SAME chains (first five sweeps: equal accepted counts, E to 1e-9)
+    for r in range(nrep):
+        assert list(jj[r][:5]) == list(refs[r][3]), r
+        assert np.all(np.abs(E[r][:6] - refs[r][4]) <= 1e-9 * (1.0 + np.abs(refs[r][4]))), r
+    for what, a, b in (("final energy", E[:, -1], Eo), ("accepted moves", jj.sum(axis=1).astype(float), jo)):
+        se = np.sqrt(a.var(ddof=1) / len(a) + b.var(ddof=1) / len(b))
+        print("%s: GPU %.4f vs oracle %.4f (difference %.2f standard errors)" % (what, a.mean(), b.mean(), (a.mean() - b.mean()) / se))
+        assert abs(a.mean() - b.mean()) < 4 * se, what
+    # the wall-normal profile of the ensemble (4 gathers x 64 replicas x 4096 particles): bins within 4 sigma (Poisson)
+    assert zg.sum() == zo.sum()
+    dev = np.abs(zg - zo) / np.sqrt(np.maximum(zg + zo, 1.0))
+    assert dev.max() < 4.5, dev.max()
+    assert (jj.sum(axis=1) != jo).any()                     # and they did separate: the comparison is not vacuous
