@@ -21,7 +21,7 @@ OK, ERR_PARAM, ERR_HIP, ERR_STATE, ERR_NOMEM, ERR_UNSUPPORTED, ERR_NODEVICE, ERR
 FLAG_WALLS, FLAG_E0_RESTART, FLAG_SERIES, FLAG_FULL_HIST, FLAG_PRESSURE, FLAG_CLUSTERS = 1, 2, 4, 8, 16, 32
 FLAGS_REFERENCE = FLAG_WALLS | FLAG_E0_RESTART
 OBS_RECORD_DOUBLES = 8
-KERNEL_AUTO, KERNEL_FP64, KERNEL_SCREENED, KERNEL_MX, KERNEL_MI, KERNEL_MA, KERNEL_MB, KERNEL_MC = range(8)
+KERNEL_AUTO, KERNEL_FP64, KERNEL_SCREENED, KERNEL_MX, KERNEL_MI, KERNEL_MA, KERNEL_MB, KERNEL_MC, KERNEL_MT = range(9)
 
 
 class Params(C.Structure):

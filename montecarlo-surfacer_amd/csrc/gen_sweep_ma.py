@@ -21,6 +21,18 @@ MODE  kernel                what differs
       sweep_kernel_mc32x8   slab of the z order and runs the whole move loop; reductions completed across waves via LDS
       sweep_kernel_mc32x4   (NS = 32 with 4 wavefronts: 4096 < N <= 8192)
  z8wc (diagnostic of z8w)   as z8c, every wave testing its own cells
+ z8t  sweep_kernel_mt16x2   TWO TEAMS of wavefronts per replica (round 3): WPR = 2 K wavefronts, team A = waves 0..K-1, team B
+      sweep_kernel_mt64x8   = waves K..2K-1; BOTH teams hold all cells (wave w owns slab w mod K of the z order).  Team A
+                            screens, fetches and evaluates probe A (the proposal) while team B does the same for probe B (the
+                            next particle) -- without the pair (n, n+1), which team B's slab-0 wave evaluates for BOTH outcomes
+                            on two lanes (old position of n from the row cache, proposal from Q) and keeps out of the reduction.
+                            ONE exchange per move: every wave writes its row-layout partial sums, team B's slab-0 wave the two
+                            side results; s_barrier; every wave sums team A's partials (-> Fn), team B's (-> Fm of the next
+                            particle without the side pair), takes the Metropolis decision, adds the side result that applies
+                            and forms the next proposal.  A move's dependent chain is one probe long instead of two and a
+                            wavefront issues ~40 % fewer instructions: for the latency-bound configurations (N = 1024 x 1024
+                            replicas: one wavefront per SIMD; N = 16384 x 256: eight per replica, 61 % of their cycles waiting)
+ z8tc (diagnostic of z8t)   as z8wc
 
 A move (iteration i of a run; particle n = first + i; ma: in register slot 0 of lane tl; zb/z8: in cell locA):
   B-COPY  probe B = current position of particle n+1: compact copy by v_readlane (ma: from its owner lane; zb: from
@@ -75,18 +87,20 @@ ZBC = MODE == "zbc"                                       # diagnostic: every pa
 # probe, no z words in LDS).  The byte-wise squares alias |dz| >= 128 units; such cells are far outside the
 # cutoff, cost at most a wasted evaluation, and the group ranges keep them out of the passes anyway.
 # "z8c": its diagnostic build: the fp64 cutoff test of every cell beside every pass, counting unflagged pairs.
-PRIO = MODE not in ("z8w", "z8wc")                        # issue priority from the SIMD neighbours' progress (one-wave kernels)
+TT = MODE in ("z8t", "z8tc")                              # two teams of wavefronts per replica (see above)
+PRIO = MODE not in ("z8w", "z8wc", "z8t", "z8tc")         # issue priority from the SIMD neighbours' progress (one-wave kernels)
 PRIO_MODE = os.environ.get("SMCX_GEN_PRIO_MODE", "rotate")
 PRIO_SHIFT = int(os.environ.get("SMCX_GEN_PRIO_SHIFT", "14"))   # ... every 2^14 ticks of the 100 MHz clock (164 us)
-Z8C = MODE in ("z8c", "z8wc")
+Z8C = MODE in ("z8c", "z8wc", "z8tc")
 # "z8w": z8 for FOUR wavefronts per replica (8192 < N <= 16384): wave w owns the cells 4096 w .. 4096 w + 4095 of the
 # z order (its own 16 groups and ranges) and runs the whole move loop itself -- same scalar state, own copy of the row
 # cache -- except that the wall sites, plane and side pair live on wave 0, a cell is written by its owner only, and
 # the two reductions of a move are completed across the waves through LDS (fixed order, so every wave takes the
 # same Metropolis decision); operand %3 = the wave's index
-W4 = MODE in ("z8w", "z8wc")
+W4 = MODE in ("z8w", "z8wc") or TT
 WPR = (int(sys.argv[4]) if len(sys.argv) > 4 else 256 // NS) if W4 else 1   # wavefronts per replica: 4 (NS = 64) or 8 (NS = 32)
-assert WPR in (1, 4, 8)                                   # (NS = 32 with 4: 4096 < N <= 8192)
+assert WPR in (1, 2, 4, 8)                                # (NS = 32 with 4: 4096 < N <= 8192; two teams: 16 x 2, 64 x 8)
+KS = WPR // 2 if TT else WPR                              # slabs of the z order = wavefronts that share out the cells
 WSH = (NS * 64).bit_length() - 1                          # cell >> WSH = the wave that owns it
 SLOTF = ((NS.bit_length() - 1) << 16) | 6                 # s_bfe field of the slot inside a cell index
 Z8 = Z8C or W4 or MODE == "z8"
@@ -97,9 +111,20 @@ LDS_GB = LDS_P0                                           # zb: (min, max) z of 
 LDS_CNT = LDS_P0 + 65 * 24 + 8                            # zbc: per lane (candidates, bits missing from the ranged pass)
 LDS_WAVE = 2048                                           # z8w: each wave's copy of the row cache (v1 = wave * LDS_WAVE)
 LDS_X = WPR * LDS_WAVE                                    # z8w: exchange area [2 buffers][WPR waves][64 lanes] doubles
+LDS_SIDE = LDS_X + 2 * WPR * 512                          # z8t: [2 buffers][old, new][e, fx, fy, fz] of the side pair
 if W4:
-    LDS_CNT = LDS_X + 2 * WPR * 512                       # z8wc: 8 counter words per wave behind the exchange area
+    LDS_CNT = LDS_X + 2 * WPR * 512 + (128 if TT else 0)  # z8wc: 8 counter words per wave behind the exchange area
 LANE, KARG, REP, WAVE = "%0", "%1", "%2", "%3"
+# z8t: the slab of a wave is wave mod K (team B = waves K .. 2K-1), formed in a scratch register where it is needed
+# (the inline-asm statement has no SGPR operand to spare); otherwise slab = wave
+
+
+def slab(tmp):
+    """-> the register that holds this wave's slab index (z8t: computed into `tmp`)"""
+    if not TT:
+        return WAVE
+    E(f"s_and_b32 {tmp}, {WAVE}, {KS - 1}")
+    return tmp
 
 V = dict(zaddr=1, uns0=2, uns1=3, wa0=4, wa1=5, wb0=6, wb1=7, axy=8, bxy=9,
          zA=10, zB=12,            # z words of the screen: two pairs
@@ -146,6 +171,13 @@ if ZB:
 if W4:
     # bzz: real cells of this wave ; az16: M2 on wave 0, -1 elsewhere ; azz: hasA on wave 0, 0 elsewhere
     S.update(Nw=S['bzz'], M2w=S['az16'], hasAw=S['azz'])
+
+
+if TT:
+    # team B's waves never use probe A's masks: haveA's low word holds the lane of the side pair evaluated with the
+    # PROPOSAL (sideL: with n's current position); its high word carries the accept flag from the Metropolis step to
+    # the point where the side result that applies is added (every wave; team A's haveA is dead by then)
+    S.update(sideN=S['haveA'], accf=S['haveA'] + 1)
 
 
 def s(name, i=0): return "s%d" % (S[name] + i)
@@ -213,8 +245,9 @@ else:
     s_load_dwordx2 {sp('Rs')}, {KARG}, {K_RS}
     s_load_dword {st(3)}, {KARG}, {K_SW0}
     s_mov_b32 {st(0)}, {NS * 64 * 24}
-    {f"s_mul_i32 {st(2)}, {REP}, {WPR}" if W4 else ""}
-    {f"s_add_u32 {st(2)}, {st(2)}, {WAVE}" if W4 else ""}
+    {f"s_mul_i32 {st(2)}, {REP}, {KS}" if W4 else ""}
+    {f"s_and_b32 {st(1)}, {WAVE}, {KS - 1}" if TT else ""}
+    {f"s_add_u32 {st(2)}, {st(2)}, {st(1) if TT else WAVE}" if W4 else ""}
     s_mul_hi_u32 {st(1)}, {st(0)}, {st(2) if W4 else REP}
     s_mul_i32 {st(0)}, {st(0)}, {st(2) if W4 else REP}
     s_waitcnt lgkmcnt(0)
@@ -224,11 +257,13 @@ else:
     if W4:
         # Rs points at this wave's 4096 cells; Nw = how many of them hold a particle; walls and side pair: wave 0
         E(f"""
-        s_lshl_b32 {st(0)}, {WAVE}, {WSH}
+        {f"s_and_b32 {st(0)}, {WAVE}, {KS - 1}" if TT else ""}
+        s_lshl_b32 {st(0)}, {st(0) if TT else WAVE}, {WSH}
         s_sub_i32 {s('Nw')}, {s('N')}, {st(0)}
         s_max_i32 {s('Nw')}, {s('Nw')}, 0
         s_min_i32 {s('Nw')}, {s('Nw')}, {NS * 64}
-        s_cmp_eq_u32 {WAVE}, 0
+        {f"s_and_b32 {st(0)}, {WAVE}, {KS - 1}" if TT else ""}
+        s_cmp_eq_u32 {st(0) if TT else WAVE}, 0
         s_cselect_b32 {s('M2w')}, {s('M2')}, -1
         s_mul_i32 {st(0)}, {WAVE}, {LDS_WAVE}
         v_mov_b32 v1, {st(0)}
@@ -1132,7 +1167,8 @@ def z8c_check(tag, P_sgpr, w0, w1, locs, guard):
     for loc in locs:      # (register, guard) pairs: the cell is not a neighbour when guard != 0
         if W4:            # v36 counts this wave's cells: compare with the cell's index inside its owner wave, if that is us
             E(f"""
-            s_lshl_b32 {st(6)}, {WAVE}, {WSH}
+            {f"s_and_b32 {st(6)}, {WAVE}, {KS - 1}" if TT else ""}
+            s_lshl_b32 {st(6)}, {st(6) if TT else WAVE}, {WSH}
             s_sub_u32 {st(6)}, {loc[0]}, {st(6)}
             """)
         E(f"""
@@ -1179,7 +1215,8 @@ def excl(w0, w1, loc):
     if W4:   # only the wave that owns the cell holds its bit
         E(f"""
         s_lshr_b32 {st(1)}, {loc}, {WSH}
-        s_cmp_lg_u32 {st(1)}, {WAVE}
+        {f"s_and_b32 {st(2)}, {WAVE}, {KS - 1}" if TT else ""}
+        s_cmp_lg_u32 {st(1)}, {st(2) if TT else WAVE}
         s_cbranch_scc1 L_excl{NEXCL[0]}
         """)
     E(f"""
@@ -1425,6 +1462,72 @@ def xchg(dst, buf):
         E(f"v_add_f64 {dst}, {dst}, v[52:53]")
 
 
+def side_capture():
+    """z8t, team B's slab-0 wave after probe B's rounds: the accumulators of the two side lanes (each holds that one
+    item) go to the side area of this move's buffer -- [old, new][e, fx, fy, fz] -- and are zeroed, so that the reduction
+    carries probe B WITHOUT the pair (n, n+1); every wave adds the one that applies after the decision"""
+    a = [vp('acc', j) for j in range(4)]
+    E(f"""
+    s_cmp_eq_u32 {s_hasAw()}, 0
+    s_cbranch_scc1 L_nocap
+    s_lshl_b64 {stp(0)}, 1, {s('sideL')}
+    s_lshl_b64 {stp(2)}, 1, {s('sideN')}
+    s_and_b32 {st(4)}, {s('i')}, 1
+    s_lshl_b32 {st(4)}, {st(4)}, 6
+    s_or_b64 exec, {stp(0)}, {stp(2)}
+    v_cmp_eq_u32 vcc, {s('sideN')}, {LANE}
+    v_mov_b32 v44, {st(4)}
+    s_nop 1
+    v_cndmask_b32_e64 v45, 0, 32, vcc
+    v_add_u32 v44, v44, v45
+    ds_write_b64 v44, {a[0]} offset:{LDS_SIDE}
+    ds_write_b64 v44, {a[1]} offset:{LDS_SIDE + 8}
+    ds_write_b64 v44, {a[2]} offset:{LDS_SIDE + 16}
+    ds_write_b64 v44, {a[3]} offset:{LDS_SIDE + 24}
+    v_mov_b64 {a[0]}, 0
+    v_mov_b64 {a[1]}, 0
+    v_mov_b64 {a[2]}, 0
+    v_mov_b64 {a[3]}, 0
+    s_mov_b64 exec, -1
+    L_nocap:
+    """)
+
+
+def xchg2(part, fn, fb):
+    """z8t: the ONE exchange of a move.  `part` (row layout) = this wave's partial sums of ITS team's probe; afterwards
+    fn = sum over team A's waves (probe A), fb = sum over team B's (probe B without the side pair), added in wave order
+    by every wave alike.  Two buffers alternate with the parity of the move counter, so that a wave that is already in
+    the next move cannot overwrite what a slower one still reads (the next barrier stops it before the move after)."""
+    E(f"""
+    s_and_b32 {st(1)}, {s('i')}, 1
+    s_mul_i32 {st(1)}, {st(1)}, {WPR * 512}
+    s_lshl_b32 {st(0)}, {WAVE}, 9
+    s_add_u32 {st(0)}, {st(0)}, {st(1)}
+    v_lshl_add_u32 v44, {LANE}, 3, {st(0)}
+    v_lshl_add_u32 v45, {LANE}, 3, {st(1)}
+    ds_write_b64 v44, {part} offset:{LDS_X}
+    s_waitcnt lgkmcnt(0)
+    s_barrier
+    """)
+    for dst, w0_ in ((fn, 0), (fb, KS)):
+        if KS == 1:
+            E(f"ds_read_b64 {dst}, v45 offset:{LDS_X + 512 * w0_}")
+            continue
+        for k in range(0, KS, 4):
+            n = min(4, KS - k)
+            for j in range(n):
+                E(f"ds_read_b64 v[{46 + 2 * j}:{47 + 2 * j}], v45 offset:{LDS_X + 512 * (w0_ + k + j)}")
+            E("s_waitcnt lgkmcnt(0)")
+            for j in range(n):
+                if k == 0 and j == 0:
+                    continue
+                if k == 0 and j == 1:
+                    E(f"v_add_f64 {dst}, v[46:47], v[48:49]")
+                else:
+                    E(f"v_add_f64 {dst}, {dst}, v[{46 + 2 * j}:{47 + 2 * j}]")
+    E("s_waitcnt lgkmcnt(0)")
+
+
 def probe(tag, P, pz_sgpr, pz, w0, w1, X, C, have, side, wait, wl=None, pl=None):
     """a whole probe: round 0 (specials + the first candidates, already requested into X / `have`), then
     further rounds while any lane still has a candidate.  `wait`: the s_waitcnt that covers round 0's loads"""
@@ -1443,6 +1546,9 @@ def probe(tag, P, pz_sgpr, pz, w0, w1, X, C, have, side, wait, wl=None, pl=None)
         if ZB:
             E(f"s_lshl_b64 {stp(0)}, 1, {s('sideL')}")
             E(f"s_or_b64 {stp(6)}, {stp(6)}, {stp(0)}")
+            if TT:
+                E(f"s_lshl_b64 {stp(0)}, 1, {s('sideN')}")
+                E(f"s_or_b64 {stp(6)}, {stp(6)}, {stp(0)}")
         else:
             E(f"s_or_b64 {stp(6)}, {stp(6)}, {sp('sideM')}")
         E(f"L_noside_{tag}:")
@@ -1477,6 +1583,7 @@ def assign_specials(tag, w0, w1, X, C, wl, pl, with_side, have):
     s_not_b64 {stp(0)}, {have}
     s_bcnt1_i32_b64 {st(2)}, {stp(0)}
     {f"s_add_u32 {st(6)}, {st(3)}, {s_hasAw()}" if with_side else ""}
+    {f"s_add_u32 {st(6)}, {st(6)}, {s_hasAw()}" if with_side and TT else ""}
     s_cmp_lt_u32 {st(2)}, {need}
     s_cbranch_scc1 L_sps_{tag}
     v_mbcnt_lo_u32_b32 v48, {st(0)}, 0
@@ -1492,6 +1599,13 @@ def assign_specials(tag, w0, w1, X, C, wl, pl, with_side, have):
         s_and_b64 {stp(4)}, {stp(4)}, {stp(0)}
         s_ff1_i32_b64 {s('sideL')}, {stp(4)}
         """)
+        if TT:   # the free lane after it: the side pair with the proposal
+            E(f"""
+            s_add_u32 {st(6)}, {st(3)}, 1
+            v_cmp_eq_u32 {stp(4)}, {st(6)}, v48
+            s_and_b64 {stp(4)}, {stp(4)}, {stp(0)}
+            s_ff1_i32_b64 {s('sideN')}, {stp(4)}
+            """)
     E(f"""
     s_and_b64 {wl}, {wl}, {stp(0)}
     s_and_b64 {pl}, {pl}, {stp(0)}
@@ -1527,7 +1641,8 @@ def assign_specials(tag, w0, w1, X, C, wl, pl, with_side, have):
     s_cselect_b64 {pl}, 0, {pl}
     s_mov_b64 {stp(4)}, {wl}
     {f"s_mov_b32 {s('sideL')}, 30" if with_side else ""}
-    {f"s_or_b32 {st(4)}, {st(4)}, 0x40000000" if with_side else ""}
+    {f"s_mov_b32 {s('sideN')}, 31" if with_side and TT else ""}
+    {f"s_or_b32 {st(4)}, {st(4)}, {'0xc0000000' if TT else '0x40000000'}" if with_side else ""}
     s_andn2_b64 {have}, {have}, {stp(4)}
     v_mov_b32 v48, {LANE}
     v_ffbl_b32 v44, v{w0}
@@ -1556,6 +1671,11 @@ def all_real_cells(w0, w1):
 XA_, CA_, XB_, CB_ = 30, 26, 20, 10   # round-0 data: A in the D registers (d = p - X in place), B in v20..25; coefficients
 
 # ---------------------------------------------------------------------------------------------- screen + fetch, probe A first
+if TT:   # team A screens and fetches for probe A only, team B for probe B only
+    E(f"""
+    s_cmp_ge_u32 {WAVE}, {KS}
+    s_cbranch_scc1 L_teamB
+    """)
 if Z8:
     screen_ranged8("A", s('axys'), v('wa0'), v('wa1'))
 elif ZB:
@@ -1599,6 +1719,11 @@ else:
     pick_fetch(V['wa0'], V['wa1'], XA_, sp('wallM'), sp('haveA'))
     wall_fetch(XA_, CA_)
 E("L_nofa:")
+if TT:
+    E(f"""
+    s_branch L_nofb
+    L_teamB:
+    """)
 if Z8:
     screen_ranged8("B", s('bxys'), v('wb0'), v('wb1'))
 elif ZB:
@@ -1695,15 +1820,92 @@ L_nofb:
 """)
 
 # ---------------------------------------------------------------------------------------------- probe A + Metropolis
-E(f"s_cmp_eq_u32 {s('hasA')}, 0")
-E("s_cbranch_scc1 L_noA")
 QP = [sp('Q', 0), sp('Q', 1), sp('Q', 2)]
-probe("A", QP, True, (s('Q', 4), s('Q', 5)), V['wa0'], V['wa1'], XA_, CA_, sp('haveA'), False,
-      ("" if (ZBC or Z8C) else "s_waitcnt vmcnt(4)") if ZB else "s_nop 0")
+BP = ["v[14:15]", "v[16:17]", "v[18:19]"]
 FnV = vp('M', 0)          # v[36:37]: the body's M registers are free now
-reduce4(FnV)
-if W4:
-    xchg(FnV, 0)
+FbV = vp('dr2')           # z8t: v[40:41] = probe B's total without the side pair, from the exchange to the proposal
+DdN = vp('M', 1)          # z8t: v[38:39] = displacement of move i+1 per row, loaded during the exchange
+
+
+def side_sources():
+    """the side pair's sources on the side lanes: particle n = p0[tl] (ma, zb: where the move left it, read after the
+    decision; z8t: its CURRENT position, read before the decision, and the proposal Q on the second lane)"""
+    E(f"""
+    s_cmp_eq_u32 {s_hasAw()}, 0
+    s_cbranch_scc1 L_nosrc
+    s_mul_i32 {st(0)}, {s('tl')}, 24
+    {f"v_add_u32 {v('T')}, {st(0)}, v1" if W4 else f"v_mov_b32 {v('T')}, {st(0)}"}
+    {f"s_lshl_b64 {stp(2)}, 1, {s('sideL')}" if ZB else ""}
+    s_mov_b64 exec, {stp(2) if ZB else sp('sideM')}
+    ds_read_b64 v[{XB_}:{XB_+1}], {v('T')} offset:{LDS_P0}
+    ds_read_b64 v[{XB_+2}:{XB_+3}], {v('T')} offset:{LDS_P0 + 8}
+    ds_read_b64 v[{XB_+4}:{XB_+5}], {v('T')} offset:{LDS_P0 + 16}
+    """)
+    if TT:
+        E(f"s_lshl_b64 exec, 1, {s('sideN')}")
+        for j in range(6):
+            E(f"v_mov_b32 v{XB_ + j}, {s('Q', j)}")
+    E(f"""
+    s_mov_b64 exec, -1
+    L_nosrc:
+    """)
+
+
+if TT:
+    # team A evaluates probe A, team B probe B (with the side pair for both outcomes, kept apart): both leave their
+    # partial sums in FnV's registers; then the one exchange of the move
+    E(f"""
+    v_mov_b32 v{V['M']}, 0
+    v_mov_b32 v{V['M'] + 1}, 0
+    s_cmp_ge_u32 {WAVE}, {KS}
+    s_cbranch_scc1 L_evalB
+    s_cmp_eq_u32 {s('hasA')}, 0
+    s_cbranch_scc1 L_xchg
+    """)
+    probe("A", QP, True, (s('Q', 4), s('Q', 5)), V['wa0'], V['wa1'], XA_, CA_, sp('haveA'), False, "s_waitcnt vmcnt(0)")
+    reduce4(FnV)
+    E(f"""
+    s_branch L_xchg
+    L_evalB:
+    s_cmp_eq_u32 {s('hasB')}, 0
+    s_cbranch_scc1 L_xchg
+    """)
+    side_sources()
+    E("s_waitcnt lgkmcnt(0)")
+    probe("B", BP, False, "v[18:19]", V['wb0'], V['wb1'], XB_, CB_, sp('haveB'), True, "s_waitcnt vmcnt(0)",
+          sp('wallB'), sp('planeB'))
+    side_capture()
+    reduce4(FnV)
+    E(f"""
+    L_xchg:
+    // displacement of move i+1 per row (rows 1..3 -> components 0, 8, 16 of displ[3 (i+1) ..]): asked for now, it
+    // travels during the exchange and the Metropolis step (DdV itself is still this move's)
+    s_cmp_eq_u32 {s('hasB')}, 0
+    s_cbranch_scc1 L_nodd
+    v_lshrrev_b32 {v('T')}, 4, {LANE}
+    v_add_u32 {v('T')}, -1, {v('T')}
+    v_max_i32 {v('T')}, 0, {v('T')}
+    v_lshlrev_b32 {v('T')}, 3, {v('T')}
+    s_add_u32 {st(1)}, {s('i')}, 1
+    s_mul_i32 {st(1)}, {st(1)}, 24
+    v_add_u32 {v('S6')}, {st(1)}, {v('T')}
+    global_load_dwordx2 {DdN}, {v('S6')}, {sp('dK')}
+    L_nodd:
+    """)
+    xchg2(FnV, FnV, FbV)
+    E(f"""
+    s_mov_b32 {s('accf')}, 0
+    s_cmp_eq_u32 {s('hasA')}, 0
+    s_cbranch_scc1 L_noA
+    """)
+else:
+    E(f"s_cmp_eq_u32 {s('hasA')}, 0")
+    E("s_cbranch_scc1 L_noA")
+    probe("A", QP, True, (s('Q', 4), s('Q', 5)), V['wa0'], V['wa1'], XA_, CA_, sp('haveA'), False,
+          ("" if (ZBC or Z8C) else "s_waitcnt vmcnt(4)") if ZB else "s_nop 0")
+    reduce4(FnV)
+    if W4:
+        xchg(FnV, 0)
 E(f"""
 // ---- Metropolis step in row layout (SMC.c:326-335); DdV = displacement of this move per row
 v_add_f64 {vp('D',0)}, {FnV}, -{vp('FmV')}
@@ -1761,6 +1963,7 @@ else:
     """)
 E(f"""
 // accepted: E += Un - Um = 4 (eA - eB) (row 0 of g), particle n takes the proposal
+{f"s_mov_b32 {s('accf')}, 1" if TT else ""}
 v_readlane_b32 {st(0)}, {v('D',0)}, 0
 v_readlane_b32 {st(1)}, {v('D',1)}, 0
 s_add_u32 {s('jacc')}, {s('jacc')}, 1
@@ -1823,7 +2026,8 @@ else:
     if W4:   # the cell, its copy in Rs and its group's range belong to one wave
         E(f"""
         s_lshr_b32 {st(1)}, {s('locA')}, {WSH}
-        s_cmp_lg_u32 {st(1)}, {WAVE}
+        {f"s_and_b32 {st(4)}, {WAVE}, {KS - 1}" if TT else ""}
+        s_cmp_lg_u32 {st(1)}, {st(4) if TT else WAVE}
         s_cbranch_scc1 L_notmine
         """)
     E(f"""
@@ -1879,39 +2083,55 @@ L_noA:
 # ---------------------------------------------------------------------------------------------- probe B
 E(f"s_cmp_eq_u32 {s('hasB')}, 0")
 E("s_cbranch_scc1 L_noB")
-E(f"""
-// per-row component offset: rows 1..3 -> 0, 8, 16 (row 0 idles along with component 0)
-v_lshrrev_b32 {v('T')}, 4, {LANE}
-v_add_u32 {v('T')}, -1, {v('T')}
-v_max_i32 {v('T')}, 0, {v('T')}
-v_lshlrev_b32 {v('T')}, 3, {v('T')}
-s_add_u32 {st(1)}, {s('i')}, 1
-{f"s_lshl_b32 {st(0)}, {st(1)}, 3" if Z8 else ""}
-{f"s_load_dwordx2 {sp('lu')}, {sp('uK')}, {st(0)}" if Z8 else ""}
-s_mul_i32 {st(1)}, {st(1)}, 24
-v_add_u32 {v('S6')}, {st(1)}, {v('T')}
-// the side pair's source on lane 30: particle n where the move left it = p0[tl]
-s_cmp_eq_u32 {s_hasAw()}, 0
-s_cbranch_scc1 L_nosrc
-s_mul_i32 {st(0)}, {s('tl')}, 24
-{f"v_add_u32 {v('T')}, {st(0)}, v1" if W4 else f"v_mov_b32 {v('T')}, {st(0)}"}
-{f"s_lshl_b64 {stp(2)}, 1, {s('sideL')}" if ZB else ""}
-s_mov_b64 exec, {stp(2) if ZB else sp('sideM')}
-ds_read_b64 v[{XB_}:{XB_+1}], {v('T')} offset:{LDS_P0}
-ds_read_b64 v[{XB_+2}:{XB_+3}], {v('T')} offset:{LDS_P0 + 8}
-ds_read_b64 v[{XB_+4}:{XB_+5}], {v('T')} offset:{LDS_P0 + 16}
-s_mov_b64 exec, -1
-L_nosrc:
-// displacement of move i+1 per row: asked for now, needed after probe B
-global_load_dwordx2 {vp('DdV')}, {v('S6')}, {sp('dK')}
-s_waitcnt lgkmcnt(0)
-""")
-BP = ["v[14:15]", "v[16:17]", "v[18:19]"]
-probe("B", BP, False, "v[18:19]", V['wb0'], V['wb1'], XB_, CB_, sp('haveB'), True, "s_waitcnt vmcnt(1)",
-      sp('wallB') if ZB else None, sp('planeB') if ZB else None)
-reduce4(vp('FmV'))
-if W4:
-    xchg(vp('FmV'), 1)
+if TT:
+    # probe B was evaluated before the decision (team B): Fm of particle n+1 = its total without the side pair + the
+    # side result that applies (n where the move left it): row r reads component r of [accepted ? new : old]
+    E(f"""
+    s_add_u32 {st(1)}, {s('i')}, 1
+    s_lshl_b32 {st(0)}, {st(1)}, 3
+    s_load_dwordx2 {sp('lu')}, {sp('uK')}, {st(0)}
+    v_mov_b32 {v('FmV')}, v{V['dr2']}
+    v_mov_b32 {v('FmV',1)}, v{V['dr2'] + 1}
+    s_cmp_eq_u32 {s('hasA')}, 0
+    s_cbranch_scc1 L_noside2
+    s_lshl_b32 {st(0)}, {s('accf')}, 5
+    s_and_b32 {st(1)}, {s('i')}, 1
+    s_lshl_b32 {st(1)}, {st(1)}, 6
+    s_add_u32 {st(0)}, {st(0)}, {st(1)}
+    v_lshrrev_b32 {v('T')}, 4, {LANE}
+    v_lshl_add_u32 {v('T')}, {v('T')}, 3, {st(0)}
+    ds_read_b64 {vp('ir2')}, {v('T')} offset:{LDS_SIDE}
+    s_waitcnt lgkmcnt(0)
+    v_add_f64 {vp('FmV')}, {vp('FmV')}, {vp('ir2')}
+    L_noside2:
+    s_waitcnt vmcnt(0)
+    v_mov_b32 {v('DdV')}, v{V['M'] + 2}
+    v_mov_b32 {v('DdV',1)}, v{V['M'] + 3}
+    """)
+else:
+    E(f"""
+    // per-row component offset: rows 1..3 -> 0, 8, 16 (row 0 idles along with component 0)
+    v_lshrrev_b32 {v('T')}, 4, {LANE}
+    v_add_u32 {v('T')}, -1, {v('T')}
+    v_max_i32 {v('T')}, 0, {v('T')}
+    v_lshlrev_b32 {v('T')}, 3, {v('T')}
+    s_add_u32 {st(1)}, {s('i')}, 1
+    {f"s_lshl_b32 {st(0)}, {st(1)}, 3" if Z8 else ""}
+    {f"s_load_dwordx2 {sp('lu')}, {sp('uK')}, {st(0)}" if Z8 else ""}
+    s_mul_i32 {st(1)}, {st(1)}, 24
+    v_add_u32 {v('S6')}, {st(1)}, {v('T')}
+    """)
+    side_sources()
+    E(f"""
+    // displacement of move i+1 per row: asked for now, needed after probe B
+    global_load_dwordx2 {vp('DdV')}, {v('S6')}, {sp('dK')}
+    s_waitcnt lgkmcnt(0)
+    """)
+    probe("B", BP, False, "v[18:19]", V['wb0'], V['wb1'], XB_, CB_, sp('haveB'), True, "s_waitcnt vmcnt(1)",
+          sp('wallB') if ZB else None, sp('planeB') if ZB else None)
+    reduce4(vp('FmV'))
+    if W4:
+        xchg(vp('FmV'), 1)
 E(f"""
 // ---- proposal of particle n+1 in row layout (SMC.c:307-316): q = p + (Fm A/T + displ)
 // rows 1..3 read component row-1 of p0[rowB] and of displ[3 (i+1) ..]; row 0 idles along with component 0
@@ -1989,7 +2209,8 @@ if ZB:
 E(f"""
 s_add_u32 {s('i')}, {s('i')}, 1
 s_mov_b32 {s('hasA')}, 1
-{f"s_cmp_eq_u32 {WAVE}, 0" if W4 else ""}
+{f"s_and_b32 {st(0)}, {WAVE}, {KS - 1}" if TT else ""}
+{f"s_cmp_eq_u32 {st(0) if TT else WAVE}, 0" if W4 else ""}
 {f"s_cselect_b32 {s('hasAw')}, 1, 0" if W4 else ""}
 s_add_u32 {st(0)}, {s('i')}, 1
 s_cmp_lt_i32 {st(0)}, {s('len')}

@@ -176,7 +176,7 @@ static int validate(const smcx_params *p)
     if (!(p->L > 0) || !(p->Lz > 0) || !(p->T > 0) || !(p->A > 0) || !(p->cutoff > 0))
         return SMCX_ERR_PARAM;
     if (p->Ncx < 1 || p->Ncz < 1 || p->Ncx > 255 || p->Ncz > 255) return SMCX_ERR_PARAM;
-    if (p->tune_kernel < 0 || p->tune_kernel > SMCX_KERNEL_MC) return SMCX_ERR_PARAM;
+    if (p->tune_kernel < 0 || p->tune_kernel > SMCX_KERNEL_MT) return SMCX_ERR_PARAM;
     if (p->tune_resort < 0 || p->tune_resort > 1024) return SMCX_ERR_PARAM;
     if (p->flags & SMCX_FLAG_WALLS) {
         if (p->M < 1) return SMCX_ERR_PARAM;
@@ -244,6 +244,7 @@ static int choose_geometry(const smcx_params *p, const Tune &t, int *S, int *WPR
     if (p->tune_slots > 0 || p->tune_waves > 0) {
         int s = p->tune_slots > 0 ? p->tune_slots : 16;
         int w = p->tune_waves > 0 ? p->tune_waves : 1;
+        if (plan_for(p, s, w, t, &pl) && pl.form == FORM_MT) { *S = s; *WPR = w; return SMCX_OK; } // (16 x 2, 64 x 8)
         if (!geometry_supported(s, w) || (long)s * w * 64 < p->N) return SMCX_ERR_UNSUPPORTED;
         if (p->tune_kernel == 1 && !fp64_supported(s, w)) return SMCX_ERR_UNSUPPORTED;
         if (p->tune_kernel >= 2 && !mx_supported(s, w)) return SMCX_ERR_UNSUPPORTED;
@@ -259,6 +260,11 @@ static int choose_geometry(const smcx_params *p, const Tune &t, int *S, int *WPR
     // chip has about two waves per SIMD to work on.
     auto pow2_at_least = [](long v) { int r = 1; while (r < v) r *= 2; return r; };
     int s, w;
+    if (p->tune_kernel == SMCX_KERNEL_MT) { // asked for by name: the two-team geometry of this N, if there is one
+        for (auto &g : {std::pair<int, int>(16, 2), std::pair<int, int>(64, 8)})
+            if (plan_for(p, g.first, g.second, t, &pl) && pl.form == FORM_MT) { *S = g.first; *WPR = g.second; return SMCX_OK; }
+        return SMCX_ERR_UNSUPPORTED;
+    }
     const bool fp64_only = (p->tune_kernel == 1);
     if (!fp64_only && (p->N > 512 || p->tune_kernel >= 2)) {
         s = pow2_at_least((p->N + 63) / 64); w = 1;

@@ -52,7 +52,8 @@ struct SweepTimer {
 // Which sweep kernel a handle runs is decided ONCE, in smcx_create, from smcx_params (tune_kernel, tune_resort) and --
 // only when SMCX_ALLOW_ENV_TUNING=1 -- from the SMCX_* measurement switches; allocation, every launcher and
 // smcx_kernel_form read this plan, nothing re-derives it.  The forms are a ladder: a cap stops the choice below it.
-enum SweepForm { FORM_NONE = 0, FORM_FP64 = 1, FORM_MX = 3, FORM_MI = 4, FORM_MA = 5, FORM_MB = 6, FORM_MC = 7 };
+enum SweepForm { FORM_NONE = 0, FORM_FP64 = 1, FORM_MX = 3, FORM_MI = 4, FORM_MA = 5, FORM_MB = 6, FORM_MC = 7,
+                 FORM_MT = 8 }; // MT: the mc kernel with two teams of wavefronts per replica (latency-bound configurations)
 struct Tune {
     int kernel = 0;      // smcx_params.tune_kernel: 0 auto, 1 fp64, 2 screened (auto), 3..7 highest SweepForm allowed
     int lead = -1;       // fp64 kernels with several wavefronts, leader/follower form: -1 auto, 0 never, 1 always
@@ -98,6 +99,9 @@ int ma_cap(const Tune &t, int S);              // highest form the build offers 
 const char *ma_kernel_name(int form, int S, int WPR);
 bool mc_box_supported(double L, double Lz, double cutoff2);
 bool mcw_built(int S, int WPR, int N, int M2, double L, double Lz, double cutoff2);
+bool mt_built(int S, int WPR, int N, int M2, double L, double Lz, double cutoff2);
+hipError_t launch_sweeps_mt(const SweepArgs &s, const DevCtx &c, const KernelPlan &pl, int nsweeps, double A, hipStream_t st,
+                            SweepTimer *tm);
 hipError_t launch_sweeps_mcw(const SweepArgs &s, const DevCtx &c, int WPR, int nsweeps, double A, hipStream_t st,
                              SweepTimer *tm);
 void mc_bound_values(double L, double cutoff2, double *toFix, double *zsafe, int *negT, int *RZ);

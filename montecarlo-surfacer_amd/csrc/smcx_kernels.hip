@@ -802,6 +802,13 @@ bool plan_kernel(int N, int M2, double L, double Lz, double cutoff2, int S, int 
 {
     KernelPlan p;
     p.S = S; p.WPR = WPR; p.tune = t;
+    if (mt_built(S, WPR, N, M2, L, Lz, cutoff2) && (t.kernel == FORM_MT || t.kernel == 0 || t.kernel == 2) &&
+        ma_cap(t, S) >= FORM_MC) { // the two-team geometries (16 x 2, 64 x 8) exist for this form only
+        p.form = FORM_MT;
+        p.name = ma_kernel_name(FORM_MT, S, WPR);
+        *out = p;
+        return true;
+    }
     const bool have64 = lookup(S, WPR) != nullptr, havemx = mx_supported(S, WPR);
     if (!have64 && !havemx) return false;
     if ((t.kernel == 1 && have64) || !havemx) {
@@ -811,8 +818,8 @@ bool plan_kernel(int N, int M2, double L, double Lz, double cutoff2, int S, int 
         *out = p;
         return true;
     }
+    if (t.kernel == FORM_MT) return false; // asked for the two-team form in a geometry that has none
     int cap = t.kernel >= FORM_MX ? t.kernel : FORM_MC;
-    if (cap > FORM_MC) cap = FORM_MC;
     p.form = FORM_MX;
     if (WPR == 1 && cap >= FORM_MI) {
         const int zs = mi_built(S, L, Lz, cutoff2);
@@ -850,6 +857,7 @@ hipError_t launch_sweeps(const DevCtx &c, const KernelPlan &pl, int nsweeps, dou
 #ifdef SMCX_CHECK
     a.dbg = c.dbg;
 #endif
+    if (pl.form == FORM_MT) return launch_sweeps_mt(a, c, pl, nsweeps, A, st, tm);
     if (pl.form >= FORM_MI && WPR == 1) return launch_sweeps_mi(a, c, pl, nsweeps, A, st, tm);
     if (pl.form == FORM_MC) {
         if (!c.Rs || !c.loc) return hipErrorInvalidValue;

@@ -203,6 +203,46 @@ __global__ void __launch_bounds__(256, 1) sweep_kernel_mc32x4(MaArgs a)
         :
         : "memory", "vcc", "scc", "m0", SMCX_MA_SGPRS, SMCX_MA_V95);
 }
+// TWO TEAMS of wavefronts per replica (gen_sweep_ma.py ... z8t): team A (waves 0..K-1) evaluates probe A while team B
+// (waves K..2K-1) evaluates probe B; both hold all cells, wave w owns slab w mod K of the z order; one exchange per move
+__global__ void __launch_bounds__(128, 1) sweep_kernel_mt16x2(MaArgs a)
+{
+    unsigned lane = threadIdx.x & 63;
+    unsigned long long kp = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
+    unsigned rep = blockIdx.x;
+    unsigned wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    asm volatile(
+#ifdef SMCX_CHECK
+#include "smcx_sweep_mtc_body16.inc"
+#else
+#include "smcx_sweep_mt_body16.inc"
+#endif
+        : "+v"(lane), "+s"(kp), "+s"(rep), "+s"(wv)
+        :
+        : "memory", "vcc", "scc", "m0", SMCX_MA_SGPRS, SMCX_MA_V79);
+}
+__global__ void __launch_bounds__(512, 1) sweep_kernel_mt64x8(MaArgs a)
+{
+    unsigned lane = threadIdx.x & 63;
+    unsigned long long kp = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
+    unsigned rep = blockIdx.x;
+    unsigned wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    asm volatile(
+#ifdef SMCX_CHECK
+#include "smcx_sweep_mtc_body64.inc"
+#else
+#include "smcx_sweep_mt_body64.inc"
+#endif
+        : "+v"(lane), "+s"(kp), "+s"(rep), "+s"(wv)
+        :
+        : "memory", "vcc", "scc", "m0", SMCX_MA_SGPRS, SMCX_MA_V127);
+}
+// LDS of the two-team kernels: a row cache per wave, the exchange area [2][waves][64] doubles, the side area
+#ifdef SMCX_CHECK
+constexpr unsigned mt_lds_bytes(int wpr) { return (unsigned)wpr * 2048u + 2u * (unsigned)wpr * 512u + 128u + (unsigned)wpr * 32u; }
+#else
+constexpr unsigned mt_lds_bytes(int wpr) { return (unsigned)wpr * 2048u + 2u * (unsigned)wpr * 512u + 128u; }
+#endif
 #ifdef SMCX_CHECK
 constexpr unsigned mcw_lds_bytes(int wpr) { return (unsigned)wpr * 2048u + 2u * (unsigned)wpr * 512u + (unsigned)wpr * 32u; }
 #else
@@ -364,6 +404,52 @@ bool mcw_built(int S, int WPR, int N, int M2, double L, double Lz, double cutoff
     return (big || mid) && M2 + 1 <= 30 && mc_box_supported(L, Lz, cutoff2);
 }
 
+// two teams of wavefronts per replica: 16 cells per lane x 2 waves (512 < N <= 1024) or 64 x 8 (8192 < N <= 16384)
+bool mt_built(int S, int WPR, int N, int M2, double L, double Lz, double cutoff2)
+{
+    const bool small = S == 16 && WPR == 2 && N > 512 && N <= 1024;
+    const bool big = S == 64 && WPR == 8 && N > 8192 && N <= 16384;
+    return (small || big) && M2 + 2 <= 30 && mc_box_supported(L, Lz, cutoff2);
+}
+
+hipError_t launch_sweeps_mt(const SweepArgs &s, const DevCtx &c, const KernelPlan &pl, int nsweeps, double A, hipStream_t st,
+                            SweepTimer *tm)
+{
+    if (!c.Rs || !c.loc) return hipErrorInvalidValue;
+    MaArgs a;
+    a.R = s.R; a.displ = s.displ; a.uni = s.uni; a.offs = s.offs; a.obs = s.obs; a.rec = s.rec;
+    a.wtab = c.wtab; a.clk = s.clk;
+    a.L = s.L; a.invL = s.invL; a.cutoff2 = s.cutoff2; a.invT = s.invT;
+    a.AoT = A * s.invT; a.Ao4T = A * 0.25 * s.invT;
+    a.halfLz = c.halfLz; a.Lz = c.Lz; a.invLz = c.invLz;
+    a.N = s.N; a.chunk = s.chunk; a.nsweeps = 1;
+    a.M2 = (c.flags & 0x1u) ? c.M2 : -1;
+    mc_bound_values(c.L, c.cutoff2, &a.toFix, &a.zsafe, &a.negC, &a.RZ);
+    a.zFix = a.toFix;
+    a.Rs = c.Rs; a.loc = c.loc; a.pad0 = 0; a.dbg = nullptr; a.prio = c.prio;
+#ifdef SMCX_CHECK
+    a.dbg = s.dbg;
+#endif
+    const double toFix16 = 65536.0 / c.L;
+    for (int sw = 0; sw < nsweeps; sw++) {
+        if (pl.S == 16)
+            hipLaunchKernelGGL((zsort_kernel<16 * 64, 256>), dim3(c.nrep), dim3(256), 0, st, (const double *)s.R, c.Rs, c.loc, s.N, toFix16);
+        else
+            hipLaunchKernelGGL((zsort_kernel<4 * 64 * 64, 1024>), dim3(c.nrep), dim3(1024), 0, st, (const double *)s.R, c.Rs, c.loc, s.N, toFix16);
+        a.sw0 = sw;
+        hipError_t rc = tm ? tm->mark(st) : hipSuccess;
+        if (rc != hipSuccess) return rc;
+        if (pl.S == 16)
+            hipLaunchKernelGGL(sweep_kernel_mt16x2, dim3(c.nrep), dim3(128), mt_lds_bytes(2), st, a);
+        else
+            hipLaunchKernelGGL(sweep_kernel_mt64x8, dim3(c.nrep), dim3(512), mt_lds_bytes(8), st, a);
+        rc = hipGetLastError();
+        if (rc == hipSuccess && tm) rc = tm->mark(st);
+        if (rc != hipSuccess) return rc;
+    }
+    return hipSuccess;
+}
+
 // the multi-wave form has its own launcher: no int16-screen numbers are needed (the byte screen's come from mc_bound)
 hipError_t launch_sweeps_mcw(const SweepArgs &s, const DevCtx &c, int WPR, int nsweeps, double A, hipStream_t st,
                              SweepTimer *tm)
@@ -432,6 +518,7 @@ void mc_bound(double L, double cutoff2, double *toFix, double *zsafe, int *negC,
 
 const char *ma_kernel_name(int form, int S, int WPR)
 {
+    if (form == FORM_MT) return S == 16 ? "smcx::sweep_kernel_mt16x2" : "smcx::sweep_kernel_mt64x8";
     if (form == FORM_MC && WPR == 4 && S == 32) return "smcx::sweep_kernel_mc32x4";
     if (form == FORM_MC && WPR == 4) return "smcx::sweep_kernel_mc64x4";
     if (form == FORM_MC && WPR == 8) return "smcx::sweep_kernel_mc32x8";

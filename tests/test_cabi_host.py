@@ -74,7 +74,7 @@ def test_parameter_validation_and_loud_failure_without_gpu(S):
     for kw, want in ((dict(N=107), S.ERR_PARAM), (dict(N=0), S.ERR_PARAM), (dict(nrep=0), S.ERR_PARAM),
                      (dict(L=-1.0), S.ERR_PARAM), (dict(T=0.0), S.ERR_PARAM), (dict(Ncz=300), S.ERR_PARAM),
                      (dict(M=6), S.ERR_UNSUPPORTED), (dict(M=0), S.ERR_PARAM),
-                     (dict(tune_kernel=8), S.ERR_PARAM), (dict(tune_kernel=-1), S.ERR_PARAM),
+                     (dict(tune_kernel=9), S.ERR_PARAM), (dict(tune_kernel=-1), S.ERR_PARAM),
                      (dict(tune_resort=-1), S.ERR_PARAM),
                      (dict(flags=S.FLAGS_REFERENCE | S.FLAG_CLUSTERS, lca_time=0), S.ERR_PARAM),
                      (dict(flags=S.FLAGS_REFERENCE | S.FLAG_CLUSTERS, lca_cutoff=0.0), S.ERR_PARAM)):

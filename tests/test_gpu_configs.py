@@ -360,7 +360,9 @@ def test_ranged_screen_sets_every_bit_of_the_full_screen(tmp_path, N, lat, nrep,
     (2048, (8, 8), 32, 3, 1, 32, 1, "mc32"),
     (16384, (16, 16), 4, 2, 1, 64, 4, "mc64x4"), (16384, (16, 16), 4, 2, 1, 32, 8, "mc32x8"),   # config 5's kernels
     (9000, (15, 10), 4, 2, 2, 64, 4, "mc64x4"), (10000, (10, 25), 4, 2, 1, 32, 8, "mc32x8"),    # ragged, tall
-    (8192, (16, 8), 4, 2, 1, 32, 4, "mc32x4"), (4800, (10, 12), 4, 2, 2, 32, 4, "mc32x4")])      # 4096 < N <= 8192
+    (8192, (16, 8), 4, 2, 1, 32, 4, "mc32x4"), (4800, (10, 12), 4, 2, 2, 32, 4, "mc32x4"),      # 4096 < N <= 8192
+    (1024, (8, 4), 16, 3, 1, 16, 2, "mt16x2"), (1000, (5, 10), 8, 3, 1, 16, 2, "mt16x2"),        # two teams of wavefronts
+    (16384, (16, 16), 4, 2, 1, 64, 8, "mt64x8"), (9000, (15, 10), 4, 2, 1, 64, 8, "mt64x8")])
 def test_byte_screen_kernel_misses_no_pair_inside_the_cutoff(tmp_path, N, lat, nrep, nsw, gl, slots, waves, kernel):
     """sweep_kernel_mc64 (the benchmark's kernel), mc16 / mc32 (N <= 2048) and the several-wavefront forms mc64x4 /
     mc32x8 (8192 < N <= 16384): one word per cell screened by v_dot4_i32_i8, only the groups in
@@ -379,7 +381,9 @@ def test_byte_screen_kernel_misses_no_pair_inside_the_cutoff(tmp_path, N, lat, n
     assert d["name"] == "smcx::sweep_kernel_" + kernel
     assert d["miss"] == 0
     # the executed-work counters: two passes per move and wavefront (+ one per run start), at most all groups each
-    assert 2 * moves * waves <= d["passes"] <= 2 * (moves + 4 * nrep * nsw) * waves
+    # (the two-team kernels: ONE pass per move and wavefront)
+    ppm = 1 if kernel.startswith("mt") else 2
+    assert ppm * moves * waves <= d["passes"] <= ppm * (moves + 4 * nrep * nsw) * waves
     assert 0 < d["groups"] <= d["passes"] * (slots // 4)
     assert d["inside"] > moves and d["cand"] >= d["inside"] and d["acc"] > 0
     assert d["cand"] < 3 * d["inside"] + 40 * moves
