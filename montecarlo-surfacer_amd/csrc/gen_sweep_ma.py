@@ -1463,7 +1463,7 @@ def xchg(dst, buf):
 
 
 def side_capture():
-    """z8t, team B's slab-0 wave after probe B's rounds: the accumulators of the two side lanes (each holds that one
+    """z8t, team B's slab-0 wave after round 0 of probe B: the accumulators of the two side lanes (each holds that one
     item) go to the side area of this move's buffer -- [old, new][e, fx, fy, fz] -- and are zeroed, so that the reduction
     carries probe B WITHOUT the pair (n, n+1); every wave adds the one that applies after the decision"""
     a = [vp('acc', j) for j in range(4)]
@@ -1554,6 +1554,8 @@ def probe(tag, P, pz_sgpr, pz, w0, w1, X, C, have, side, wait, wl=None, pl=None)
         E(f"L_noside_{tag}:")
     E(wait)
     body(tag + "r0", P, X, C, stp(6), True, wl, pl)
+    if side and TT:   # now, while the side lanes hold nothing but their side item (the fixed-lane fallback gives them
+        side_capture()  # candidates of their own in later rounds)
     E(f"""
     L_more_{tag}:
     v_cmp_ne_u64 vcc, 0, v[{w0}:{w1}]
@@ -1874,7 +1876,6 @@ if TT:
     E("s_waitcnt lgkmcnt(0)")
     probe("B", BP, False, "v[18:19]", V['wb0'], V['wb1'], XB_, CB_, sp('haveB'), True, "s_waitcnt vmcnt(0)",
           sp('wallB'), sp('planeB'))
-    side_capture()
     reduce4(FnV)
     E(f"""
     L_xchg:
