@@ -99,7 +99,7 @@ Z8C = MODE in ("z8c", "z8wc", "z8tc")
 # same Metropolis decision); operand %3 = the wave's index
 W4 = MODE in ("z8w", "z8wc") or TT
 WPR = (int(sys.argv[4]) if len(sys.argv) > 4 else 256 // NS) if W4 else 1   # wavefronts per replica: 4 (NS = 64) or 8 (NS = 32)
-assert WPR in (1, 2, 4, 8)                                # (NS = 32 with 4: 4096 < N <= 8192; two teams: 16 x 2, 64 x 8)
+assert WPR in (1, 2, 4, 8, 16)                            # (NS = 32 with 4: 4096 < N <= 8192; two teams: 16 x 2, 64 x 8, 32 x 16)
 KS = WPR // 2 if TT else WPR                              # slabs of the z order = wavefronts that share out the cells
 WSH = (NS * 64).bit_length() - 1                          # cell >> WSH = the wave that owns it
 SLOTF = ((NS.bit_length() - 1) << 16) | 6                 # s_bfe field of the slot inside a cell index

@@ -261,7 +261,7 @@ static int choose_geometry(const smcx_params *p, const Tune &t, int *S, int *WPR
     auto pow2_at_least = [](long v) { int r = 1; while (r < v) r *= 2; return r; };
     int s, w;
     if (p->tune_kernel == SMCX_KERNEL_MT) { // asked for by name: the two-team geometry of this N, if there is one
-        for (auto &g : {std::pair<int, int>(16, 2), std::pair<int, int>(64, 8)})
+        for (auto &g : {std::pair<int, int>(16, 2), std::pair<int, int>(32, 16), std::pair<int, int>(64, 8)})
             if (plan_for(p, g.first, g.second, t, &pl) && pl.form == FORM_MT) { *S = g.first; *WPR = g.second; return SMCX_OK; }
         return SMCX_ERR_UNSUPPORTED;
     }

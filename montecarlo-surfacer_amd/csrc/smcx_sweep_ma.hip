@@ -237,6 +237,24 @@ __global__ void __launch_bounds__(512, 1) sweep_kernel_mt64x8(MaArgs a)
         :
         : "memory", "vcc", "scc", "m0", SMCX_MA_SGPRS, SMCX_MA_V127);
 }
+// sixteen wavefronts: eight slabs of 32 cells per lane x two teams (thinner slabs: a probe's candidates spread over more
+// wavefronts, fewer second rounds on dense states)
+__global__ void __launch_bounds__(1024, 1) sweep_kernel_mt32x16(MaArgs a)
+{
+    unsigned lane = threadIdx.x & 63;
+    unsigned long long kp = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
+    unsigned rep = blockIdx.x;
+    unsigned wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    asm volatile(
+#ifdef SMCX_CHECK
+#include "smcx_sweep_mtc_body32.inc"
+#else
+#include "smcx_sweep_mt_body32.inc"
+#endif
+        : "+v"(lane), "+s"(kp), "+s"(rep), "+s"(wv)
+        :
+        : "memory", "vcc", "scc", "m0", SMCX_MA_SGPRS, SMCX_MA_V95);
+}
 // LDS of the two-team kernels: a row cache per wave, the exchange area [2][waves][64] doubles, the side area
 #ifdef SMCX_CHECK
 constexpr unsigned mt_lds_bytes(int wpr) { return (unsigned)wpr * 2048u + 2u * (unsigned)wpr * 512u + 128u + (unsigned)wpr * 32u; }
@@ -408,7 +426,7 @@ bool mcw_built(int S, int WPR, int N, int M2, double L, double Lz, double cutoff
 bool mt_built(int S, int WPR, int N, int M2, double L, double Lz, double cutoff2)
 {
     const bool small = S == 16 && WPR == 2 && N > 512 && N <= 1024;
-    const bool big = S == 64 && WPR == 8 && N > 8192 && N <= 16384;
+    const bool big = ((S == 64 && WPR == 8) || (S == 32 && WPR == 16)) && N > 8192 && N <= 16384;
     return (small || big) && M2 + 2 <= 30 && mc_box_supported(L, Lz, cutoff2);
 }
 
@@ -441,6 +459,8 @@ hipError_t launch_sweeps_mt(const SweepArgs &s, const DevCtx &c, const KernelPla
         if (rc != hipSuccess) return rc;
         if (pl.S == 16)
             hipLaunchKernelGGL(sweep_kernel_mt16x2, dim3(c.nrep), dim3(128), mt_lds_bytes(2), st, a);
+        else if (pl.S == 32)
+            hipLaunchKernelGGL(sweep_kernel_mt32x16, dim3(c.nrep), dim3(1024), mt_lds_bytes(16), st, a);
         else
             hipLaunchKernelGGL(sweep_kernel_mt64x8, dim3(c.nrep), dim3(512), mt_lds_bytes(8), st, a);
         rc = hipGetLastError();
@@ -518,7 +538,7 @@ void mc_bound(double L, double cutoff2, double *toFix, double *zsafe, int *negC,
 
 const char *ma_kernel_name(int form, int S, int WPR)
 {
-    if (form == FORM_MT) return S == 16 ? "smcx::sweep_kernel_mt16x2" : "smcx::sweep_kernel_mt64x8";
+    if (form == FORM_MT) return S == 16 ? "smcx::sweep_kernel_mt16x2" : S == 32 ? "smcx::sweep_kernel_mt32x16" : "smcx::sweep_kernel_mt64x8";
     if (form == FORM_MC && WPR == 4 && S == 32) return "smcx::sweep_kernel_mc32x4";
     if (form == FORM_MC && WPR == 4) return "smcx::sweep_kernel_mc64x4";
     if (form == FORM_MC && WPR == 8) return "smcx::sweep_kernel_mc32x8";

@@ -362,7 +362,8 @@ def test_ranged_screen_sets_every_bit_of_the_full_screen(tmp_path, N, lat, nrep,
     (9000, (15, 10), 4, 2, 2, 64, 4, "mc64x4"), (10000, (10, 25), 4, 2, 1, 32, 8, "mc32x8"),    # ragged, tall
     (8192, (16, 8), 4, 2, 1, 32, 4, "mc32x4"), (4800, (10, 12), 4, 2, 2, 32, 4, "mc32x4"),      # 4096 < N <= 8192
     (1024, (8, 4), 16, 3, 1, 16, 2, "mt16x2"), (1000, (5, 10), 8, 3, 1, 16, 2, "mt16x2"),        # two teams of wavefronts
-    (16384, (16, 16), 4, 2, 1, 64, 8, "mt64x8"), (9000, (15, 10), 4, 2, 1, 64, 8, "mt64x8")])
+    (16384, (16, 16), 4, 2, 1, 64, 8, "mt64x8"), (9000, (15, 10), 4, 2, 1, 64, 8, "mt64x8"),
+    (16384, (16, 16), 4, 2, 1, 32, 16, "mt32x16"), (10000, (10, 25), 4, 2, 1, 32, 16, "mt32x16")])
 def test_byte_screen_kernel_misses_no_pair_inside_the_cutoff(tmp_path, N, lat, nrep, nsw, gl, slots, waves, kernel):
     """sweep_kernel_mc64 (the benchmark's kernel), mc16 / mc32 (N <= 2048) and the several-wavefront forms mc64x4 /
     mc32x8 (8192 < N <= 16384): one word per cell screened by v_dot4_i32_i8, only the groups in

@@ -9,8 +9,8 @@ S = smcx_loader.load()
 for label, N, nrep, lat, sweeps, geoms in (("config 2: N=1024 x 1024 replicas", 1024, 1024, (8, 4), 40, ((16, 1), (16, 2))),
                                            ("N=1024 x 2048 replicas", 1024, 2048, (8, 4), 40, ((16, 1), (16, 2))),
                                            ("N=1024 x 4096 replicas", 1024, 4096, (8, 4), 20, ((16, 1), (16, 2))),
-                                           ("config 5: N=16384 x 256 replicas", 16384, 256, (16, 16), 4, ((32, 8), (64, 4), (64, 8))),
-                                           ("N=16384 x 512 replicas", 16384, 512, (16, 16), 4, ((32, 8), (64, 4), (64, 8)))):
+                                           ("config 5: N=16384 x 256 replicas", 16384, 256, (16, 16), 4, ((32, 8), (64, 8), (32, 16))),
+                                           ("N=16384 x 512 replicas", 16384, 512, (16, 16), 4, ((32, 8), (64, 8), (32, 16)))):
     for s_, w_ in geoms:
         p = S.default_params(N, nrep, tune_slots=s_, tune_waves=w_)
         with S.Engine(p) as e:
