@@ -281,6 +281,14 @@ static int choose_geometry(const smcx_params *p, const Tune &t, int *S, int *WPR
             one_wave = true;                                                     // 32 x 8 while the chip has room
             if ((long)p->nrep * 8 <= 2048) { s = 32; w = 8; }                    // (44.6 against 47.3 ms per sweep at 256)
         }
+        // latency-bound shares (few replicas: at most two wavefronts per SIMD): the two-team form of the same kernel --
+        // probe A and probe B on different wavefronts, one exchange per move (measured, tools/probes/tt_probe.py:
+        // N = 16384 x 256 replicas 37.0 ms per sweep against 44.0 for 32 x 8; N = 1024 x 1024 1.64 against 1.69; with twice
+        // the replicas the one-probe-after-the-other forms win: 57 against 74 ms, 1.89 against 2.24)
+        if (p->tune_kernel == 0 || p->tune_kernel == SMCX_KERNEL_SCREENED) {
+            if (p->N > 8192 && (long)p->nrep * 8 <= 2048 && plan_for(p, 64, 8, t, &pl) && pl.form == FORM_MT) { s = 64; w = 8; one_wave = true; }
+            if (p->N <= 1024 && p->nrep <= 1024 && plan_for(p, 16, 2, t, &pl) && pl.form == FORM_MT) { s = 16; w = 2; one_wave = true; }
+        }
         while (!one_wave && (long)p->nrep * w < 2048 && s > 16 && w < 8 && geometry_supported(s / 2, w * 2)) { s /= 2; w *= 2; }
     } else {
         if (p->N <= 1024) { s = pow2_at_least((p->N + 63) / 64); w = 1; }
@@ -290,6 +298,7 @@ static int choose_geometry(const smcx_params *p, const Tune &t, int *S, int *WPR
         }
         while ((long)p->nrep * w < 2048 && s > 4 && w < 8 && geometry_supported(s / 2, w * 2)) { s /= 2; w *= 2; }
     }
+    if (plan_for(p, s, w, t, &pl) && pl.form == FORM_MT) { *S = s; *WPR = w; return SMCX_OK; }
     if (geometry_supported(s, w) && (long)s * w * 64 >= p->N) { *S = s; *WPR = w; return SMCX_OK; }
     static const int cand[][2] = {{1, 1}, {2, 1}, {4, 1}, {8, 1}, {8, 2}, {16, 2}, {16, 4},
                                   {32, 4}, {32, 8}, {32, 16}};
