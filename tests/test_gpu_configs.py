@@ -40,8 +40,10 @@ def oracle_chains(O, s, seeds, R0, eq, nsw, gl, workers=16):
 @pytest.mark.parametrize("slots,waves,name", [
     (64, 4, "smcx::sweep_kernel_mc64x4"),                # 4 wavefronts x 64 cells per lane, z-ordered, byte screen: the
                                                          # geometry rule's choice at this N
-    (32, 8, "smcx::sweep_kernel_mc32x8"),                # the same with 8 wavefronts x 32 cells (the rule's choice up to
-                                                         # 256 replicas per GPU)
+    (32, 8, "smcx::sweep_kernel_mc32x8"),                # the same with 8 wavefronts x 32 cells
+    (64, 8, "smcx::sweep_kernel_mt64x8"),                # two teams of 4 wavefronts x 64 cells (round 3): the rule's choice
+                                                         # up to 256 replicas per GPU
+    (32, 16, "smcx::sweep_kernel_mt32x16"),              # two teams of 8 wavefronts x 32 cells
 ])
 def test_config5_N16384_against_oracle(S, O, slots, waves, name):
     """BASELINE configs[4]: N=16384 + wall, fcc(16,16) (the reference's own dense lattice),
@@ -69,7 +71,7 @@ def test_config5_N16384_against_oracle(S, O, slots, waves, name):
         assert np.array_equal(ob["zhist"][r], ref["zhist"])
 
 
-@pytest.mark.parametrize("slots,waves", [(64, 4), (32, 8)])
+@pytest.mark.parametrize("slots,waves", [(64, 4), (32, 8), (64, 8), (32, 16)])
 def test_several_wavefront_kernel_with_many_accepted_moves(S, O, slots, waves):
     """config 5's lattice is a crystal (66 of 16384 moves accepted per sweep).  The same N in the widest box the byte
     screen serves (L = 48: fcc(16,16) at spacing 3, a third of the density) accepts thousands of moves per sweep, so
@@ -80,7 +82,8 @@ def test_several_wavefront_kernel_with_many_accepted_moves(S, O, slots, waves):
     nsw, nrep = 2, 2
     p = S.default_params(16384, nrep, L=L, flags=S.FLAGS_REFERENCE | S.FLAG_SERIES, tune_slots=slots, tune_waves=waves)
     with S.Engine(p) as eng:
-        assert eng.kernel_form[1] == ("smcx::sweep_kernel_mc64x4" if waves == 4 else "smcx::sweep_kernel_mc32x8")
+        assert eng.kernel_form[1] == {(64, 4): "smcx::sweep_kernel_mc64x4", (32, 8): "smcx::sweep_kernel_mc32x8",
+                                      (64, 8): "smcx::sweep_kernel_mt64x8", (32, 16): "smcx::sweep_kernel_mt32x16"}[(slots, waves)]
         eng.upload(R0, O.W_FIXTURE)
         eng.run(0, nsw, 1)
         ob = eng.observables()
@@ -102,7 +105,8 @@ def test_config5_N16384_x256_invariants(S, O):
     p = S.default_params(16384, nrep, flags=S.FLAG_WALLS)
     with S.Engine(p) as eng:
         form, name = eng.kernel_form
-        assert form == 2 and eng.geometry[0] * eng.geometry[1] * 64 == 16384, (name, eng.geometry)
+        # (the two-team kernel: both teams of four wavefronts hold all cells)
+        assert form == 2 and name == "smcx::sweep_kernel_mt64x8" and eng.geometry[:2] == (64, 8), (name, eng.geometry)
         eng.upload(R0, O.W_FIXTURE)
         eng.run(1, 2, 1)
         ob = eng.observables()
@@ -130,7 +134,7 @@ def test_config2_N1024_x1024(S, O):
         Es, jj = eng.series(nsw)
         g, oob = eng.hist_info()
         Erec = eng.total_energy()
-    assert form == 2, name
+    assert form == 2 and name == "smcx::sweep_kernel_mt16x2", name      # (round 3: two teams of one wavefront each)
     assert np.all(rel(ob["E_last"], Erec) < 1e-9)
     assert np.all(g == nsw) and np.all(oob == 0) and np.all(ob["zhist"].sum(axis=1) == nsw * 1024)
     pick = [0, 1, 127, 128, 511, 640, 1000, 1023]
