@@ -106,11 +106,16 @@ SLOTF = ((NS.bit_length() - 1) << 16) | 6                 # s_bfe field of the s
 Z8 = Z8C or W4 or MODE == "z8"
 ZB = ZBC or Z8 or MODE == "zb"
 NG = NS // 4                                              # 4-slot groups
-LDS_P0 = 0 if Z8 else (NS // 2) * 256                     # after the int16 z words
+# z8t with 16 cells per lane ("LP"): the fp64 positions of all cells (24 KB, what candidates are fetched from) and the
+# wall table live in LDS at offset 0, shared by the two wavefronts of the replica; every other LDS area moves up
+LP = TT and NS == 16
+LDS_RS, LDS_WT = 0, NS * 64 * 24
+LDS_BASE = LDS_WT + 1024 if LP else 0
+LDS_P0 = LDS_BASE if Z8 else (NS // 2) * 256              # after the int16 z words
 LDS_GB = LDS_P0                                           # zb: (min, max) z of each group while the copies are built (p0 is filled afterwards)
 LDS_CNT = LDS_P0 + 65 * 24 + 8                            # zbc: per lane (candidates, bits missing from the ranged pass)
 LDS_WAVE = 2048                                           # z8w: each wave's copy of the row cache (v1 = wave * LDS_WAVE)
-LDS_X = WPR * LDS_WAVE                                    # z8w: exchange area [2 buffers][WPR waves][64 lanes] doubles
+LDS_X = LDS_BASE + WPR * LDS_WAVE                         # z8w: exchange area [2 buffers][WPR waves][64 lanes] doubles
 LDS_SIDE = LDS_X + 2 * WPR * 512                          # z8t: [2 buffers][old, new][e, fx, fy, fz] of the side pair
 if W4:
     LDS_CNT = LDS_X + 2 * WPR * 512 + (128 if TT else 0)  # z8wc: 8 counter words per wave behind the exchange area
@@ -394,6 +399,26 @@ ds_max_i32 v26, v24 offset:{LDS_GB + 4}
 s_mov_b64 exec, -1
 """
 
+if LP:   # the wall table rows (site x, y, two coefficients; the plane last) into LDS: lanes 0 .. M2
+    E(f"""
+    s_cmp_lt_i32 {s('M2')}, 0
+    s_cbranch_scc1 L_nowt
+    s_add_u32 {st(0)}, {s('M2')}, 1
+    s_lshl_b64 {stp(2)}, 1, {st(0)}
+    s_sub_u32 {st(2)}, {st(2)}, 1
+    s_subb_u32 {st(3)}, {st(3)}, 0
+    s_mov_b64 exec, {stp(2)}
+    v_lshlrev_b32 v14, 5, {LANE}
+    global_load_dwordx4 v[16:19], v14, {sp('wtab')}
+    global_load_dwordx4 v[20:23], v14, {sp('wtab')} offset:16
+    s_waitcnt vmcnt(0)
+    ds_write_b64 v14, v[16:17] offset:{LDS_WT}
+    ds_write_b64 v14, v[18:19] offset:{LDS_WT + 8}
+    ds_write_b64 v14, v[20:21] offset:{LDS_WT + 16}
+    ds_write_b64 v14, v[22:23] offset:{LDS_WT + 24}
+    s_mov_b64 exec, -1
+    L_nowt:
+    """)
 # ---- compact copies: 64 passes, each loads logical slot k of this lane, packs it, and shifts it in at the
 # top of the register file (xy[j] <- xy[j+1], xy[63] <- new): after 64 passes slot k sits in xy[k]
 E(f"""
@@ -412,6 +437,9 @@ s_and_saveexec_b64 {stp(2)}, vcc
 global_load_dwordx4 v[16:19], v15, {SRC}
 global_load_dwordx2 v[20:21], v15, {SRC} offset:16
 s_waitcnt vmcnt(0)
+{f"ds_write_b64 v15, v[16:17] offset:{LDS_RS}" if LP else ""}
+{f"ds_write_b64 v15, v[18:19] offset:{LDS_RS + 8}" if LP else ""}
+{f"ds_write_b64 v15, v[20:21] offset:{LDS_RS + 16}" if LP else ""}
 s_mov_b64 exec, -1
 v_mul_f64 v[22:23], v[16:17], {sp('toFix')}
 v_mul_f64 v[24:25], v[18:19], {sp('toFix')}
@@ -1254,8 +1282,8 @@ def pick_fetch(w0, w1, X, spec_mask, have):
     {"" if ZB else f"v_cmp_gt_u32 vcc, {s('N')}, v44"}
     v_mul_u32_u24 v45, 24, v44
     {"" if ZB else "s_and_b64 exec, exec, vcc"}
-    global_load_dwordx4 v[{X}:{X+3}], v45, {SRC}
-    global_load_dwordx2 v[{X+4}:{X+5}], v45, {SRC} offset:16
+    {f"ds_read2_b64 v[{X}:{X+3}], v45 offset1:1" if LP else f"global_load_dwordx4 v[{X}:{X+3}], v45, {SRC}"}
+    {f"ds_read_b64 v[{X+4}:{X+5}], v45 offset:16" if LP else f"global_load_dwordx2 v[{X+4}:{X+5}], v45, {SRC} offset:16"}
     s_mov_b64 {have}, exec
     s_mov_b64 exec, -1
     """)
@@ -1564,7 +1592,7 @@ def probe(tag, P, pz_sgpr, pz, w0, w1, X, C, have, side, wait, wl=None, pl=None)
     """)
     coeff_one(C)
     pick_fetch(w0, w1, X, "0", stp(6))
-    E("s_waitcnt vmcnt(0)")
+    E("s_waitcnt lgkmcnt(0)" if LP else "s_waitcnt vmcnt(0)")
     body(tag + "rm", P, X, C, stp(6), False)
     E(f"s_branch L_more_{tag}")
     E(f"L_done_{tag}:")
@@ -1622,17 +1650,27 @@ def assign_specials(tag, w0, w1, X, C, wl, pl, with_side, have):
     s_mov_b64 exec, {have}
     v_and_b32 v{w0}, v{w0}, v46
     v_and_b32 v{w1}, v{w1}, v47
-    global_load_dwordx4 v[{X}:{X+3}], v45, {SRC}
-    global_load_dwordx2 v[{X+4}:{X+5}], v45, {SRC} offset:16
+    {f"ds_read2_b64 v[{X}:{X+3}], v45 offset1:1" if LP else f"global_load_dwordx4 v[{X}:{X+3}], v45, {SRC}"}
+    {f"ds_read_b64 v[{X+4}:{X+5}], v45 offset:16" if LP else f"global_load_dwordx2 v[{X+4}:{X+5}], v45, {SRC} offset:16"}
     s_mov_b64 exec, -1
     """)
     coeff_one(C)
-    E(f"""
-    s_mov_b64 exec, {wl}
-    global_load_dwordx4 v[{X}:{X+3}], v49, {sp('wtab')}
-    global_load_dwordx4 v[{C}:{C+3}], v49, {sp('wtab')} offset:16
-    s_mov_b64 exec, -1
-    """)
+    if LP:
+        E(f"""
+        s_mov_b64 exec, {wl}
+        ds_read_b64 v[{X}:{X+1}], v49 offset:{LDS_WT}
+        ds_read_b64 v[{X+2}:{X+3}], v49 offset:{LDS_WT + 8}
+        ds_read_b64 v[{C}:{C+1}], v49 offset:{LDS_WT + 16}
+        ds_read_b64 v[{C+2}:{C+3}], v49 offset:{LDS_WT + 24}
+        s_mov_b64 exec, -1
+        """)
+    else:
+        E(f"""
+        s_mov_b64 exec, {wl}
+        global_load_dwordx4 v[{X}:{X+3}], v49, {sp('wtab')}
+        global_load_dwordx4 v[{C}:{C+3}], v49, {sp('wtab')} offset:16
+        s_mov_b64 exec, -1
+        """)
     COLD(f"""
     L_sps_{tag}:
     s_lshl_b64 {wl}, 1, {st(3)}
@@ -1864,7 +1902,8 @@ if TT:
     s_cmp_eq_u32 {s('hasA')}, 0
     s_cbranch_scc1 L_xchg
     """)
-    probe("A", QP, True, (s('Q', 4), s('Q', 5)), V['wa0'], V['wa1'], XA_, CA_, sp('haveA'), False, "s_waitcnt vmcnt(0)")
+    probe("A", QP, True, (s('Q', 4), s('Q', 5)), V['wa0'], V['wa1'], XA_, CA_, sp('haveA'), False,
+          "s_waitcnt lgkmcnt(0)" if LP else "s_waitcnt vmcnt(0)")
     reduce4(FnV)
     E(f"""
     s_branch L_xchg
@@ -1874,8 +1913,8 @@ if TT:
     """)
     side_sources()
     E("s_waitcnt lgkmcnt(0)")
-    probe("B", BP, False, "v[18:19]", V['wb0'], V['wb1'], XB_, CB_, sp('haveB'), True, "s_waitcnt vmcnt(0)",
-          sp('wallB'), sp('planeB'))
+    probe("B", BP, False, "v[18:19]", V['wb0'], V['wb1'], XB_, CB_, sp('haveB'), True,
+          "s_waitcnt lgkmcnt(0)" if LP else "s_waitcnt vmcnt(0)", sp('wallB'), sp('planeB'))
     reduce4(FnV)
     E(f"""
     L_xchg:
@@ -2034,6 +2073,9 @@ else:
     E(f"""
     global_store_dwordx4 {v('T')}, v[50:53], {sp('Rs')}
     global_store_dwordx2 {v('T')}, v[54:55], {sp('Rs')} offset:16
+    {f"ds_write_b64 {v('T')}, v[50:51] offset:{LDS_RS}" if LP else ""}
+    {f"ds_write_b64 {v('T')}, v[52:53] offset:{LDS_RS + 8}" if LP else ""}
+    {f"ds_write_b64 {v('T')}, v[54:55] offset:{LDS_RS + 16}" if LP else ""}
     {f"s_bfe_u32 {st(1)}, {s('locA')}, {SLOTF}" if W4 else f"s_lshr_b32 {st(1)}, {s('locA')}, 6"}
     s_lshl_b64 {stp(2)}, 1, {s('locA')}
     s_lshl_b64 {stp(4)}, 1, {st(1)}

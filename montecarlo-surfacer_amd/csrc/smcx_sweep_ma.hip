@@ -458,7 +458,7 @@ hipError_t launch_sweeps_mt(const SweepArgs &s, const DevCtx &c, const KernelPla
         hipError_t rc = tm ? tm->mark(st) : hipSuccess;
         if (rc != hipSuccess) return rc;
         if (pl.S == 16)
-            hipLaunchKernelGGL(sweep_kernel_mt16x2, dim3(c.nrep), dim3(128), mt_lds_bytes(2), st, a);
+            hipLaunchKernelGGL(sweep_kernel_mt16x2, dim3(c.nrep), dim3(128), mt_lds_bytes(2) + 16u * 64u * 24u + 1024u, st, a); // + positions, wall table
         else if (pl.S == 32)
             hipLaunchKernelGGL(sweep_kernel_mt32x16, dim3(c.nrep), dim3(1024), mt_lds_bytes(16), st, a);
         else

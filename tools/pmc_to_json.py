@@ -28,7 +28,7 @@ for f in glob.glob(os.path.join(d, "*", "*", "*_counter_collection.csv")):
         e["launch_ns"][cnt] = ns
 for name, e in res.items():
     c = e["counters"]
-    if "kernel_mb" in name or "kernel_mc" in name:      # one launch per z sort: tune_resort sweeps (default 1)
+    if "kernel_mb" in name or "kernel_mc" in name or "kernel_mt" in name:      # one launch per z sort: tune_resort sweeps (default 1)
         sweeps = int(os.environ.get("SMCX_RESORT", "1"))
     moves = float(nrep) * sweeps * N * wpr              # wave-moves: every wavefront of a replica runs every move
     e["workload"] = {"N": N, "replicas": nrep, "sweeps_in_launch": sweeps, "wave_moves": moves, "waves_per_replica": wpr}
