@@ -242,6 +242,8 @@ def main():
     ap.add_argument("--N", type=int, default=4096, choices=[256, 1024, 4096, 16384])
     ap.add_argument("--slots", type=int, default=0)
     ap.add_argument("--waves", type=int, default=0)
+    ap.add_argument("--resort", type=int, default=0, help="measurement switch: smcx_params.tune_resort (sweeps per z sort)")
+    ap.add_argument("--kernel", type=int, default=0, help="measurement switch: smcx_params.tune_kernel (SMCX_KERNEL_*)")
     ap.add_argument("--no-cpu", action="store_true",
                     help="skip the reference legs after the timed region (cpu_baseline, all-fp64 kernels): profiling runs")
     a = ap.parse_args()
@@ -278,7 +280,7 @@ def main():
     N, nrep = a.N, a.replicas
     first, _ = D.shard(nrep * world, rank, world)
     p = S.default_params(N, nrep, device=local_rank, first_replica=first,
-                         tune_slots=a.slots, tune_waves=a.waves)
+                         tune_slots=a.slots, tune_waves=a.waves, tune_resort=a.resort, tune_kernel=a.kernel)
     eng = S.Engine(p)
     eng.upload(S.fcc_init(*lattice), S.W_REFERENCE)   # inputs resident in HBM before timing
     gather_lapse = 10                                  # SURVEY.md 8d throughput runs
