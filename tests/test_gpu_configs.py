@@ -171,17 +171,18 @@ def test_screen_ab_against_fp64_kernel_at_scale(S, O, N, lat, nrep, nsw, mx_geom
     difference grows about tenfold per sweep from 1e-14 relative (2e-13 after five sweeps, 2e-8 after
     ten) and eventually flips an accept decision.  A pair dropped by the screen would instead shift E
     by >= 4|V(rc)| = 5e-3 at once.  Required: over the first three sweeps |dE| <= 1e-9 (1 + |E|) for
-    every replica -- seven orders of magnitude below one missed pair --, |dE| < 1e-3 through sweep five
-    (the z-ordered cells of sweep_kernel_mb64 / mc64 sum in yet another order: 3e-6 at most after four
-    sweeps, measured over 256 replicas) and equal accept counts over those sweeps; over all sweeps at most
+    every replica -- seven orders of magnitude below one missed pair --, |dE| < 5e-5 through sweep four (a hundred
+    times below one missed pair for as long as it is asserted; the z-ordered cells of sweep_kernel_mb64 / mc64 sum in
+    yet another order: 3e-6 at most after four sweeps, measured over 256 replicas) and equal accept counts over those
+    sweeps; over all sweeps at most
     2 % of the replicas with a differing accept count.  (The counters of the diagnostic build, below, test
     every cell on every move directly.)"""
     (Ea, ja), (Eb, jb) = _ab_kernels(S, O, N, lat, nrep, nsw, mx_geom, fp_geom)
     k = min(nsw, 3)
     assert np.all(np.abs(Ea[:, :k + 1] - Eb[:, :k + 1]) <= 1e-9 * (1.0 + np.abs(Ea[:, :k + 1]))), \
         np.abs(Ea[:, :k + 1] - Eb[:, :k + 1]).max()
-    k = min(nsw, 5)
-    assert np.abs(Ea[:, :k + 1] - Eb[:, :k + 1]).max() < 1e-3
+    k = min(nsw, 4)
+    assert np.abs(Ea[:, :k + 1] - Eb[:, :k + 1]).max() < 5e-5      # 100 x below one missed pair (5e-3); measured <= 3e-6
     assert np.array_equal(ja[:, :k], jb[:, :k]) and ja.sum() > 0
     diverged = int((ja != jb).any(axis=1).sum())
     assert diverged <= max(1, nrep // 50), diverged
