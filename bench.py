@@ -228,7 +228,7 @@ def side_config(S, label, N, nrep, lattice, sweeps, device, kernel=0, executed=T
     rl = issue_roofline(kname, ms / sweeps, nrep, N, ghz, start="fcc(%d,%d)" % tuple(lattice))
     out["roofline"] = rl if rl else {"bound": "valu_issue", "frac": None, "clock_ghz": ghz,
                                      "note": "no PMC counters committed for this kernel and workload"}
-    if executed and "kernel_mc" in kname:
+    if executed and ("kernel_mc" in kname or "kernel_mt" in kname):
         out["executed"] = executed_work(kname, N, lattice, s_, w_, device, nrep=min(nrep, 64 if N <= 4096 else 8))
     return out
 
@@ -393,7 +393,7 @@ def main():
                                                 "unit": "pair-evals/s (sweep kernels only)"}
             except Exception as e:
                 out["fp64_only_kernels"] = {"value": None, "note": "failed: %r" % (e,)}
-        if world == 1 and not a.no_cpu and "kernel_mc" in kname:
+        if world == 1 and not a.no_cpu and ("kernel_mc" in kname or "kernel_mt" in kname):
             # what the timed kernel executed per probe (diagnostic build, sample of the same start)
             eng.close()
             out["executed"] = executed_work(kname, N, lattice, S_, W_, local_rank, nrep=64 if N <= 4096 else 8)
