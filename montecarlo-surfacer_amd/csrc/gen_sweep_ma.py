@@ -90,6 +90,8 @@ ZBC = MODE == "zbc"                                       # diagnostic: every pa
 TT = MODE in ("z8t", "z8tc")                              # two teams of wavefronts per replica (see above)
 PRIO = MODE not in ("z8w", "z8wc", "z8t", "z8tc")         # issue priority from the SIMD neighbours' progress (one-wave kernels)
 PRIO_MODE = os.environ.get("SMCX_GEN_PRIO_MODE", "rotate")
+NT = " nt" if os.environ.get("SMCX_GEN_NT") == "1" else ""   # experiment: streaming hint on once-per-sweep data
+FAKE = os.environ.get("SMCX_GEN_FAKEFETCH") == "1"          # TIMING experiment only (wrong results): every candidate fetch reads cell 0
 PRIO_SHIFT = int(os.environ.get("SMCX_GEN_PRIO_SHIFT", "14"))   # ... every 2^14 ticks of the 100 MHz clock (164 us)
 Z8C = MODE in ("z8c", "z8wc", "z8tc")
 # "z8w": z8 for FOUR wavefronts per replica (8192 < N <= 16384): wave w owns the cells 4096 w .. 4096 w + 4095 of the
@@ -562,8 +564,8 @@ def fill_p0(tag):
         """)
     E(f"""
     s_and_saveexec_b64 {stp(2)}, vcc
-    global_load_dwordx4 v[16:19], v15, {sp('Rg')}
-    global_load_dwordx2 v[20:21], v15, {sp('Rg')} offset:16
+    global_load_dwordx4 v[16:19], v15, {sp('Rg')}{NT}
+    global_load_dwordx2 v[20:21], v15, {sp('Rg')} offset:16{NT}
     {f"global_load_ushort v24, v23, {stp(4)}" if ZB else ""}
     s_waitcnt vmcnt(0)
     ds_write_b64 v22, v[16:17] offset:{LDS_P0}
@@ -582,8 +584,8 @@ def fill_p0(tag):
     {f"s_lshl_b32 {st(1)}, {st(0)}, 1" if ZB else ""}
     {f"v_mov_b32 v23, {st(1)}" if ZB else ""}
     s_nop 1
-    global_load_dwordx4 v[16:19], v15, {sp('Rg')}
-    global_load_dwordx2 v[20:21], v15, {sp('Rg')} offset:16
+    global_load_dwordx4 v[16:19], v15, {sp('Rg')}{NT}
+    global_load_dwordx2 v[20:21], v15, {sp('Rg')} offset:16{NT}
     {f"global_load_ushort v24, v23, {stp(4)}" if ZB else ""}
     {f"v_add_u32 v22, {LDS_P0 + 64 * 24}, v1" if W4 else f"v_mov_b32 v22, {LDS_P0 + 64 * 24}"}
     s_waitcnt vmcnt(0)
@@ -1281,6 +1283,7 @@ def pick_fetch(w0, w1, X, spec_mask, have):
     v_lshl_or_b32 v44, v44, 6, {LANE}
     {"" if ZB else f"v_cmp_gt_u32 vcc, {s('N')}, v44"}
     v_mul_u32_u24 v45, 24, v44
+    {"v_mov_b32 v45, 0" if FAKE else ""}
     {"" if ZB else "s_and_b64 exec, exec, vcc"}
     {f"ds_read2_b64 v[{X}:{X+3}], v45 offset1:1" if LP else f"global_load_dwordx4 v[{X}:{X+3}], v45, {SRC}"}
     {f"ds_read_b64 v[{X+4}:{X+5}], v45 offset:16" if LP else f"global_load_dwordx2 v[{X+4}:{X+5}], v45, {SRC} offset:16"}
@@ -1645,6 +1648,7 @@ def assign_specials(tag, w0, w1, X, C, wl, pl, with_side, have):
     v_min_u32 v44, v44, v45
     v_lshl_or_b32 v44, v44, 6, {LANE}
     v_mul_u32_u24 v45, 24, v44
+    {"v_mov_b32 v45, 0" if FAKE else ""}
     v_lshlrev_b32 v49, 5, v48
     // only the lanes that evaluate their candidate now take it out of w (the fixed-lane fallback keeps some waiting)
     s_mov_b64 exec, {have}
@@ -2033,8 +2037,8 @@ if not ZB:
     v_mov_b32 {v('T',1)}, {st(2)}
     v_mul_u32_u24 {v('S6')}, 24, {LANE}
     ds_write_b16 {v('zaddr')}, {v('T')}
-    global_store_dwordx4 {v('T',1)}, v[50:53], {sp('Rg')}
-    global_store_dwordx2 {v('T',1)}, v[54:55], {sp('Rg')} offset:16
+    global_store_dwordx4 {v('T',1)}, v[50:53], {sp('Rg')}{NT}
+    global_store_dwordx2 {v('T',1)}, v[54:55], {sp('Rg')} offset:16{NT}
     ds_write_b64 {v('S6')}, v[50:51] offset:{LDS_P0}
     ds_write_b64 {v('S6')}, v[52:53] offset:{LDS_P0 + 8}
     ds_write_b64 {v('S6')}, v[54:55] offset:{LDS_P0 + 16}
@@ -2057,8 +2061,8 @@ else:
     v_mov_b32 {v('T',1)}, {st(2)}
     v_mov_b32 {v('T')}, {st(3)}
     {f"v_mad_u32_u24 {v('S6')}, {LANE}, 24, v1" if W4 else f"v_mul_u32_u24 {v('S6')}, 24, {LANE}"}
-    global_store_dwordx4 {v('T',1)}, v[50:53], {sp('Rg')}
-    global_store_dwordx2 {v('T',1)}, v[54:55], {sp('Rg')} offset:16
+    global_store_dwordx4 {v('T',1)}, v[50:53], {sp('Rg')}{NT}
+    global_store_dwordx2 {v('T',1)}, v[54:55], {sp('Rg')} offset:16{NT}
     ds_write_b64 {v('S6')}, v[50:51] offset:{LDS_P0}
     ds_write_b64 {v('S6')}, v[52:53] offset:{LDS_P0 + 8}
     ds_write_b64 {v('S6')}, v[54:55] offset:{LDS_P0 + 16}
@@ -2167,7 +2171,7 @@ else:
     side_sources()
     E(f"""
     // displacement of move i+1 per row: asked for now, needed after probe B
-    global_load_dwordx2 {vp('DdV')}, {v('S6')}, {sp('dK')}
+    global_load_dwordx2 {vp('DdV')}, {v('S6')}, {sp('dK')}{NT}
     s_waitcnt lgkmcnt(0)
     """)
     probe("B", BP, False, "v[18:19]", V['wb0'], V['wb1'], XB_, CB_, sp('haveB'), True, "s_waitcnt vmcnt(1)",
