@@ -89,6 +89,27 @@ int smcx_host_sMC_multi(const smcx_params *p, int ndev, const int *devices, cons
                         int maxsteps, int gather_lapse, int eqsteps, smcx_sim *out);
 const char *smcx_host_multi_error(void);
 
+/* ---- BASELINE config 1: the older single-file variant SMC_noMPI_noWall.c, "N=256 LJ particles, 1 chain, CPU reference
+ * (plumbing, no GPU)".  One chain on the HOST, by definition of that configuration -- not a fallback of the GPU engine,
+ * which serves the walls variant only.  Cubic box L = cbrt(N/rho) periodic in x, y and z, cutoff L/2, neighbour loops
+ * from particle 1, fixed visiting order, its own Box-Muller; every quirk of the file kept (host/smcx_host_nowall.c).
+ * energySingle :599-619, force :501-529, energy :573-591, pressure :664-684, initializeBox :359-394,
+ * oneParticleMoves :266-316, the loop of sMC :196-219. */
+double smcx_host_nowall_energy_single(int N, const double *r, double L, int i);
+void smcx_host_nowall_force(int N, const double *r, double L, int i, double F[3]);
+double smcx_host_nowall_energy(int N, const double *r, double L);
+double smcx_host_nowall_pressure(int N, const double *r, double L);
+int smcx_host_nowall_fcc(int N, double L, double *X);
+/* R, Rn [3N] updated in place, *j += accepted moves; returns an smcx status */
+int smcx_host_nowall_sweep(int N, smcx_host_rng *g, double *R, double *Rn, double L, double A, double T, int *j);
+/* the box of a run: L = cbrt(N / rho) (:165) */
+double smcx_host_nowall_box(int N, double rho);
+/* one chain seeded srand(seed) in the box L: E[k], P[k] = energy / pressure BEFORE sweep n when n % gather_lapse == 0 (k = n /
+ * gather_lapse; ceil(maxsteps / gather_lapse) entries, either may be NULL), jj[n] accepted moves of sweep n (may be NULL);
+ * R [3N]: in = start, out = final positions.  The reference's main uses rho = 0.1, T = 0.4 (:80-81), sMC A = 4e-8 (:192). */
+int smcx_host_nowall_sMC(int N, double L, double T, double A, unsigned int seed, int maxsteps, int gather_lapse,
+                         double *R, double *E, double *P, int *jj);
+
 /* The reference's result files for the last smcx_run of `h`, one set per replica with
  * the replica's global index as the `_rank` suffix (SMC.c:66-95 names them per MPI rank):
  *   data_N%d_M%d_r%0.4f_T%0.2f_rank%d.csv    "E, P, jj"  one row per gather   (SMC.c:75-77, 214-215)

@@ -64,7 +64,10 @@ EXPORTS = [
 ]
 HOST_EXPORTS = ["smcx_host_sMC", "smcx_host_sMC_multi", "smcx_host_multi_error", "smcx_host_sim_free", "smcx_host_fcc_init",
                 "smcx_host_initialize_box", "smcx_host_initialize_walls", "smcx_host_box_for_N", "smcx_host_write_csv",
-                "smcx_host_read_last_state", "smcx_host_srand", "smcx_host_rand", "smcx_host_vec_box_muller"]
+                "smcx_host_read_last_state", "smcx_host_srand", "smcx_host_rand", "smcx_host_vec_box_muller",
+                "smcx_host_nowall_energy_single", "smcx_host_nowall_force", "smcx_host_nowall_energy",
+                "smcx_host_nowall_pressure", "smcx_host_nowall_fcc", "smcx_host_nowall_sweep", "smcx_host_nowall_sMC",
+                "smcx_host_nowall_box"]
 
 
 def _lib():
@@ -434,6 +437,17 @@ def _host():
         H.smcx_host_sMC_multi.argtypes = [C.POINTER(Params), C.c_int, C.POINTER(C.c_int), _dp, _dp, C.c_int, C.c_int, C.c_int,
                                           C.POINTER(HostSim)]
         H.smcx_host_multi_error.restype = C.c_char_p
+        H.smcx_host_nowall_energy_single.argtypes = [C.c_int, _dp, C.c_double, C.c_int]
+        H.smcx_host_nowall_energy_single.restype = C.c_double
+        H.smcx_host_nowall_force.argtypes = [C.c_int, _dp, C.c_double, C.c_int, _dp]
+        H.smcx_host_nowall_force.restype = None
+        H.smcx_host_nowall_energy.argtypes = [C.c_int, _dp, C.c_double]
+        H.smcx_host_nowall_energy.restype = C.c_double
+        H.smcx_host_nowall_pressure.argtypes = [C.c_int, _dp, C.c_double]
+        H.smcx_host_nowall_pressure.restype = C.c_double
+        H.smcx_host_nowall_fcc.argtypes = [C.c_int, C.c_double, _dp]
+        H.smcx_host_nowall_sMC.argtypes = [C.c_int, C.c_double, C.c_double, C.c_double, C.c_uint, C.c_int, C.c_int, _dp, _dp, _dp,
+                                           _i32p]
         H.smcx_host_sim_free.argtypes = [C.POINTER(HostSim)]
         H.smcx_host_sim_free.restype = None
         _HOST = H
@@ -496,6 +510,40 @@ def host_sMC(p, W, R0, maxsteps, gather_lapse, eqsteps, gpus=0, devices=None):
     out["Rfinal"] = np.ctypeslib.as_array(sim.Rfinal, (n, 3 * sim.N)).copy()
     _host().smcx_host_sim_free(C.byref(sim))
     return out
+
+
+class NoWall:
+    """BASELINE config 1 (SMC_noMPI_noWall.c): one chain on the host CPU, C host library (host/smcx_host_nowall.c)"""
+
+    def __init__(self, N, rho):
+        self.N, self.rho, self.L = N, rho, float(np.cbrt(N / rho))
+
+    def fcc(self):
+        X = np.zeros(3 * self.N)
+        placed = _host().smcx_host_nowall_fcc(self.N, self.L, _p(X, C.c_double))
+        return X, placed
+
+    def energy(self, R):
+        return _host().smcx_host_nowall_energy(self.N, _p(R, C.c_double), self.L)
+
+    def pressure(self, R):
+        return _host().smcx_host_nowall_pressure(self.N, _p(R, C.c_double), self.L)
+
+    def single(self, R, i):
+        F = np.zeros(3)
+        e = _host().smcx_host_nowall_energy_single(self.N, _p(R, C.c_double), self.L, int(i))
+        _host().smcx_host_nowall_force(self.N, _p(R, C.c_double), self.L, int(i), _p(F, C.c_double))
+        return e, F
+
+    def sMC(self, R, T, A, seed, maxsteps, gather_lapse=1):
+        """runs the chain in place on R; returns (E[k], P[k], jj[n])"""
+        ng = (maxsteps + gather_lapse - 1) // gather_lapse
+        E = np.zeros(max(ng, 1)); P = np.zeros(max(ng, 1)); jj = np.zeros(max(maxsteps, 1), dtype=np.int32)
+        rc = _host().smcx_host_nowall_sMC(self.N, self.L, T, A, int(seed), maxsteps, gather_lapse, _p(R, C.c_double),
+                                          _p(E, C.c_double), _p(P, C.c_double), _p(jj, C.c_int32))
+        if rc != OK:
+            raise SmcxError(rc, "smcx_host_nowall_sMC")
+        return E[:ng], P[:ng], jj[:maxsteps]
 
 
 def read_last_state(path, N):

@@ -6,6 +6,9 @@
  * or, with --gpus G, dealt over GPUs 0..G-1 with the observables gathered by RCCL
  * (smcx_host_sMC_multi: the reference's MPI ranks, SMC.c:40, 66-95) -- and prints
  * the ensemble results (main.c:126-131).
+ *   smcx_main --nowall maxsteps gather_lapse [N [seed]]
+ * is BASELINE config 1: the older variant SMC_noMPI_noWall.c (its main: rho = 0.1, T = 0.4, :80-81; sMC: A = 4e-8,
+ * :192), one chain on the host CPU.
  */
 #include "../../include/smcx_host.h"
 
@@ -17,6 +20,27 @@
 int main(int argc, char **argv)
 {
     int gpus = 0;
+    if (argc > 3 && strcmp(argv[1], "--nowall") == 0) { /* SMC_noMPI_noWall.c main :74-143 */
+        const int maxsteps = (int)strtol(argv[2], NULL, 10), gl = (int)strtol(argv[3], NULL, 10);
+        const int N = argc > 4 ? (int)strtol(argv[4], NULL, 10) : 256;
+        const unsigned seed = argc > 5 ? (unsigned)strtoul(argv[5], NULL, 10) : 12345u;
+        if (maxsteps < 1 || gl < 1 || N < 8) { fprintf(stderr, "usage: smcx_main --nowall maxsteps gather_lapse [N [seed]]\n"); return 2; }
+        const double rho = 0.1, T = 0.4, A = 4e-8, L = smcx_host_nowall_box(N, rho);
+        double *R = (double *)calloc(3 * (size_t)N, sizeof(double));
+        const int ng = (maxsteps + gl - 1) / gl;
+        double *E = (double *)calloc(ng, sizeof(double)), *P = (double *)calloc(ng, sizeof(double));
+        int *jj = (int *)calloc(maxsteps, sizeof(int));
+        if (!R || !E || !P || !jj || smcx_host_nowall_fcc(N, L, R) != N) { fprintf(stderr, "Can't make a cubic FCC crystal with this N\n"); return 2; }
+        int rc = smcx_host_nowall_sMC(N, L, T, A, seed, maxsteps, gl, R, E, P, jj);
+        if (rc != SMCX_OK) { fprintf(stderr, "smcx_host_nowall_sMC: %s\n", smcx_strerror(rc)); return 1; }
+        double mE = 0, mP = 0, acc = 0;
+        for (int k = 0; k < ng; k++) { mE += E[k] / ng; mP += P[k] / ng; }
+        for (int n = 0; n < maxsteps; n++) acc += (double)jj[n] / maxsteps;
+        printf("noWall variant, host CPU: N=%d L=%0.6f T=%0.2f rho=%0.2f A=%g, %d sweeps\n", N, L, T, rho, A, maxsteps);
+        printf("E[0] = %0.12f, mean E = %0.12f, mean P = %0.12f, acceptance ratio %f\n", E[0], mE, mP, acc / N);
+        free(R); free(E); free(P); free(jj);
+        return 0;
+    }
     if (argc > 2 && strcmp(argv[1], "--gpus") == 0) {
         gpus = (int)strtol(argv[2], NULL, 10);
         if (gpus < 1) { fprintf(stderr, "--gpus needs a positive count\n"); return 2; }

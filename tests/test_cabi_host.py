@@ -47,6 +47,52 @@ def test_host_library_exports_every_declared_symbol(S):
     assert f(S.ERR_RCCL) == b"RCCL collective failed"
 
 
+def test_nowall_host_path_equals_the_real_reference(S):
+    """BASELINE config 1 (SMC_noMPI_noWall.c, one chain on the host CPU) through the C host library against the
+    outputs of the REAL file (oracle/_ref/libref_nw_N*.so -> tests/golden/ref_smc.json, cases "nw"): start lattice,
+    E0, P0, energySingle/force of three particles, accepted moves of every sweep, energy and positions after every
+    sweep, final pressure -- bit for bit."""
+    import hashlib
+    import json
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "ref_smc.json")))["cases"]
+    cases = [e for e in gold if e["case"]["kind"] == "nw"]
+    assert len(cases) >= 4
+    dig = lambda a: "%s:%s" % (a.dtype.str, hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest())
+    for e in cases:
+        c, exp = e["case"], e["expect"]
+        nw = S.NoWall(c["N"], c["rho"])
+        assert float(nw.L).hex() == exp["L"]
+        X, placed = nw.fcc()
+        assert placed == c["N"] and dig(X) == exp["X"]
+        assert float(nw.energy(X)).hex() == exp["E0"] and float(nw.pressure(X)).hex() == exp["P0"]
+        for i, want in zip((0, 1, c["N"] - 1), exp["single"]):
+            en, F = nw.single(X, i)
+            assert [float(v).hex() for v in (en, *F)] == want, (c, i)
+        # sweep by sweep: the energy after sweep n is E[k] of the NEXT gather with gather_lapse = 1
+        R = X.copy()
+        E, P, jj = nw.sMC(R, c["T"], c["A"], c["seed"], c["steps"], 1)
+        assert [int(v) for v in jj] == exp["jj"], c
+        assert float(E[0]).hex() == exp["E0"]
+        assert [float(v).hex() for v in E[1:]] == exp["Es"][:-1], c      # E[k] is taken BEFORE sweep k
+        assert dig(R) == exp["Rs"][-1] and float(nw.energy(R)).hex() == exp["Es"][-1]
+        assert float(nw.pressure(R)).hex() == exp["P_end"]
+        # a shorter chain lands on the intermediate positions
+        R2 = X.copy()
+        nw.sMC(R2, c["T"], c["A"], c["seed"], 3, 1)
+        assert dig(R2) == exp["Rs"][2]
+    # the command-line form with the reference main's own parameters (rho 0.1, T 0.4, A 4e-8) and ITS box:
+    # L = cbrt(N/rho) by this libc's cbrt, as the reference's main computes it (:82) -- one ulp below numpy's here,
+    # which moves pairs across the cutoff L/2 of the perfect lattice (E0 = -36.1924 instead of SURVEY 8c's -36.1886)
+    box = S._host().smcx_host_nowall_box
+    box.restype, box.argtypes = C.c_double, [C.c_int, C.c_double]
+    nw = S.NoWall(256, 0.1)
+    nw.L = box(256, 0.1)
+    X, _ = nw.fcc()
+    exe = os.path.join(os.path.dirname(S.LIB_PATH), "smcx_main")
+    r = subprocess.run([exe, "--nowall", "10", "2", "256", "12345"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and ("E[0] = %0.12f" % nw.energy(X)) in r.stdout, r.stdout + r.stderr
+
+
 def test_no_oracle_in_product():
     """the product never links or imports the oracle"""
     pkg = os.path.join(ROOT, "montecarlo-surfacer_amd")
