@@ -122,16 +122,8 @@ LDS_SIDE = LDS_X + 2 * WPR * 512                          # z8t: [2 buffers][old
 if W4:
     LDS_CNT = LDS_X + 2 * WPR * 512 + (128 if TT else 0)  # z8wc: 8 counter words per wave behind the exchange area
 LANE, KARG, REP, WAVE = "%0", "%1", "%2", "%3"
-# z8t: the slab of a wave is wave mod K (team B = waves K .. 2K-1), formed in a scratch register where it is needed
-# (the inline-asm statement has no SGPR operand to spare); otherwise slab = wave
-
-
-def slab(tmp):
-    """-> the register that holds this wave's slab index (z8t: computed into `tmp`)"""
-    if not TT:
-        return WAVE
-    E(f"s_and_b32 {tmp}, {WAVE}, {KS - 1}")
-    return tmp
+# z8t: the slab of a wave is wave mod K (team B = waves K .. 2K-1), formed with s_and_b32 in a scratch register where
+# it is needed (the inline-asm statement has no SGPR operand to spare); otherwise slab = wave
 
 V = dict(zaddr=1, uns0=2, uns1=3, wa0=4, wa1=5, wb0=6, wb1=7, axy=8, bxy=9,
          zA=10, zB=12,            # z words of the screen: two pairs
