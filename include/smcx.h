@@ -213,6 +213,8 @@ int smcx_last_clock(smcx_handle *h, double *ghz, double *wave_cycles);
  * from the first start to the last end.  With four wavefronts per SIMD the kernel lasts as long as its slowest
  * wavefront; sweep_kernel_mb64 / mc* steer their issue priorities so that all finish together. */
 int smcx_debug_wave_spread(smcx_handle *h, double *out4);
+/* diagnostics: the raw stamps behind smcx_last_clock / smcx_debug_wave_spread, out[nrep][4] */
+int smcx_debug_clk_rows(smcx_handle *h, uint64_t *out);
 /* device time of the whole last smcx_run (RNG pre-pass and bookkeeping kernels included) */
 int smcx_last_run_ms(smcx_handle *h, double *ms);
 /* the launch geometry chosen for this handle */

@@ -61,6 +61,7 @@ EXPORTS = [
     "smcx_rng_seed", "smcx_one_particle_moves",
     "smcx_cluster_counts", "smcx_cluster_update", "smcx_cluster_analysis", "smcx_kernel_form", "smcx_screen_bound",
     "smcx_screen_bound_int", "smcx_screen_bound_byte", "smcx_last_clock", "smcx_debug_wave_spread",
+    "smcx_debug_clk_rows",
 ]
 HOST_EXPORTS = ["smcx_host_sMC", "smcx_host_sMC_multi", "smcx_host_multi_error", "smcx_host_sim_free", "smcx_host_fcc_init",
                 "smcx_host_initialize_box", "smcx_host_initialize_walls", "smcx_host_box_for_N", "smcx_host_write_csv",
@@ -110,6 +111,7 @@ def _lib():
         L.smcx_last_run_ms.argtypes = [vp, _dp]
         L.smcx_last_clock.argtypes = [vp, _dp, _dp]
         L.smcx_debug_wave_spread.argtypes = [vp, _dp]
+        L.smcx_debug_clk_rows.argtypes = [vp, _u64p]
         L.smcx_geometry.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.smcx_kernel_form.argtypes = [vp, C.POINTER(C.c_int), C.c_char_p, C.c_int]
         L.smcx_screen_bound.argtypes = [C.POINTER(Params), C.c_int, _dp, _dp, _dp, _dp]
@@ -388,6 +390,11 @@ class Engine:
         out = (C.c_double * 4)()
         self._chk(_lib().smcx_debug_wave_spread(self._h, out), "smcx_debug_wave_spread")
         return tuple(out)
+
+    def clk_rows(self):
+        out = np.zeros((self.p.nrep, 4), dtype=np.uint64)
+        self._chk(_lib().smcx_debug_clk_rows(self._h, _p(out, C.c_uint64)), "smcx_debug_clk_rows")
+        return out
 
     def last_kernel_ms(self):
         ms, n = C.c_double(), C.c_int()

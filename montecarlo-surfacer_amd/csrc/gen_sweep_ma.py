@@ -91,6 +91,7 @@ TT = MODE in ("z8t", "z8tc")                              # two teams of wavefro
 PRIO = MODE not in ("z8w", "z8wc", "z8t", "z8tc")         # issue priority from the SIMD neighbours' progress (one-wave kernels)
 PRIO_MODE = os.environ.get("SMCX_GEN_PRIO_MODE", "rotate")
 NT = " nt" if os.environ.get("SMCX_GEN_NT") == "1" else ""   # experiment: streaming hint on once-per-sweep data
+STAMPS = os.environ.get("SMCX_GEN_TT_STAMPS") == "1"        # z8t diagnostic: where a move's time goes (before / at the barrier)
 FAKE = os.environ.get("SMCX_GEN_FAKEFETCH") == "1"          # TIMING experiment only (wrong results): every candidate fetch reads cell 0
 PRIO_SHIFT = int(os.environ.get("SMCX_GEN_PRIO_SHIFT", "14"))   # ... every 2^14 ticks of the 100 MHz clock (164 us)
 Z8C = MODE in ("z8c", "z8wc", "z8tc")
@@ -110,6 +111,8 @@ ZB = ZBC or Z8 or MODE == "zb"
 NG = NS // 4                                              # 4-slot groups
 # z8t with 16 cells per lane ("LP"): the fp64 positions of all cells (24 KB, what candidates are fetched from) and the
 # wall table live in LDS at offset 0, shared by the two wavefronts of the replica; every other LDS area moves up
+PF2 = TT and NS >= 32     # z8t with many cells: the first TWO candidates of a lane are fetched together (dense states: the
+                          # second round's memory round trip was the longest stretch of the slowest wavefront's move)
 LP = TT and NS == 16
 LDS_RS, LDS_WT = 0, NS * 64 * 24
 LDS_BASE = LDS_WT + 1024 if LP else 0
@@ -121,6 +124,7 @@ LDS_X = LDS_BASE + WPR * LDS_WAVE                         # z8w: exchange area [
 LDS_SIDE = LDS_X + 2 * WPR * 512                          # z8t: [2 buffers][old, new][e, fx, fy, fz] of the side pair
 if W4:
     LDS_CNT = LDS_X + 2 * WPR * 512 + (128 if TT else 0)  # z8wc: 8 counter words per wave behind the exchange area
+LDS_TM = LDS_SIDE + 128                                   # z8t stamps variant: per wave {t0, cycles before the barrier, cycles at it}
 LANE, KARG, REP, WAVE = "%0", "%1", "%2", "%3"
 # z8t: the slab of a wave is wave mod K (team B = waves K .. 2K-1), formed with s_and_b32 in a scratch register where
 # it is needed (the inline-asm statement has no SGPR operand to spare); otherwise slab = wave
@@ -311,21 +315,32 @@ def clk_ptr(dst):
     return dst
 
 
-CLK0 = clk_ptr(stp(2))
-E(f"""
-// start stamp: clk[rep][0..1] = s_memtime, s_memrealtime
-s_memtime {stp(4)}
-s_memrealtime {stp(6)}
-s_waitcnt lgkmcnt(0)
-v_mov_b32 v14, 0
-v_mov_b32 v16, {st(4)}
-v_mov_b32 v17, {st(5)}
-v_mov_b32 v18, {st(6)}
-v_mov_b32 v19, {st(7)}
-s_mov_b64 exec, 1
-global_store_dwordx4 v14, v[16:19], {CLK0}
-s_mov_b64 exec, -1
-""")
+if TT and STAMPS:   # the clk row collects the phase sums of this variant: no start stamp; zero this wave's LDS sums
+    E(f"""
+    s_lshl_b32 {st(4)}, {WAVE}, 5
+    v_mov_b32 v14, {st(4)}
+    v_mov_b32 v16, 0
+    v_mov_b32 v17, 0
+    s_mov_b64 exec, 1
+    ds_write_b64 v14, v[16:17] offset:{LDS_TM + 4}
+    s_mov_b64 exec, -1
+    """)
+else:
+    CLK0 = clk_ptr(stp(2))
+    E(f"""
+    // start stamp: clk[rep][0..1] = s_memtime, s_memrealtime
+    s_memtime {stp(4)}
+    s_memrealtime {stp(6)}
+    s_waitcnt lgkmcnt(0)
+    v_mov_b32 v14, 0
+    v_mov_b32 v16, {st(4)}
+    v_mov_b32 v17, {st(5)}
+    v_mov_b32 v18, {st(6)}
+    v_mov_b32 v19, {st(7)}
+    s_mov_b64 exec, 1
+    global_store_dwordx4 v14, v[16:19], {CLK0}
+    s_mov_b64 exec, -1
+    """)
 if not ZB:
     E(f"""
     // masks of the special lanes: wall sites + plane = lanes 0..M2 (none if M2 < 0), plane = lane M2, side pair = lane 30
@@ -856,6 +871,17 @@ if ZB:
     E("s_branch L_move")
     COLD_AT = len(out)
 E("L_move:")
+if TT and STAMPS:
+    E(f"""
+    s_memtime {stp(0)}
+    s_lshl_b32 {st(2)}, {WAVE}, 5
+    s_waitcnt lgkmcnt(0)
+    v_mov_b32 v14, {st(0)}
+    v_mov_b32 v15, {st(2)}
+    s_mov_b64 exec, 1
+    ds_write_b32 v15, v14 offset:{LDS_TM}
+    s_mov_b64 exec, -1
+    """)
 cold = []
 
 
@@ -1354,11 +1380,13 @@ def body(tag, P, X, C, items, round0, wl=None, pl=None):
     the plane's rules, cutoff test, lj_acc's sequence (SMC.c:567-578, 601-614, 740-761, 787-809)"""
     wl = wl or sp('wallM')
     pl = pl or sp('planeM')
+    Xp = X if isinstance(X, (list, tuple)) else [f"v[{X}:{X+1}]", f"v[{X+2}:{X+3}]", f"v[{X+4}:{X+5}]"]
+    ca, cb = ("1.0", "1.0") if C is None else (f"v[{C}:{C+1}]", f"v[{C+2}:{C+3}]")
     E(f"""
     s_mov_b64 exec, {items}
-    v_add_f64 {vp('D',0)}, {P[0]}, -v[{X}:{X+1}]
-    v_add_f64 {vp('D',1)}, {P[1]}, -v[{X+2}:{X+3}]
-    v_add_f64 {vp('D',2)}, {P[2]}, -v[{X+4}:{X+5}]
+    v_add_f64 {vp('D',0)}, {P[0]}, -{Xp[0]}
+    v_add_f64 {vp('D',1)}, {P[1]}, -{Xp[1]}
+    v_add_f64 {vp('D',2)}, {P[2]}, -{Xp[2]}
     """)
     if round0 and ZB:
         E(f"""
@@ -1415,8 +1443,8 @@ def body(tag, P, X, C, items, round0, wl=None, pl=None):
     v_fma_f64 {vp('ir2')}, {vp('T')}, {vp('ir2')}, {vp('ir2')}
     v_mul_f64 {vp('T')}, {vp('ir2')}, {vp('ir2')}
     v_mul_f64 {vp('S6')}, {vp('T')}, {vp('ir2')}
-    v_mul_f64 {vp('T')}, v[{C}:{C+1}], {vp('S6')}
-    v_mul_f64 {vp('F')}, v[{C+2}:{C+3}], {vp('S6')}
+    v_mul_f64 {vp('T')}, {ca}, {vp('S6')}
+    v_mul_f64 {vp('F')}, {cb}, {vp('S6')}
     v_mul_f64 {vp('T')}, {vp('T')}, {vp('S6')}
     v_add_f64 {vp('S6')}, {vp('T')}, -{vp('F')}
     v_mul_f64 {vp('F')}, {vp('F')}, {sp('neg24')}
@@ -1530,8 +1558,29 @@ def xchg2(part, fn, fb):
     v_lshl_add_u32 v45, {LANE}, 3, {st(1)}
     ds_write_b64 v44, {part} offset:{LDS_X}
     s_waitcnt lgkmcnt(0)
-    s_barrier
     """)
+    if STAMPS:   # cycles from the start of the move to here, and those spent at the barrier
+        E(f"""
+        s_memtime {stp(2)}
+        s_lshl_b32 {st(4)}, {WAVE}, 5
+        v_mov_b32 v47, {st(4)}
+        s_mov_b64 exec, 1
+        ds_read_b32 v46, v47 offset:{LDS_TM}
+        s_waitcnt lgkmcnt(0)
+        v_sub_u32 v46, {st(2)}, v46
+        ds_add_u32 v47, v46 offset:{LDS_TM + 4}
+        v_mov_b32 v46, {st(2)}
+        s_mov_b64 exec, -1
+        s_barrier
+        s_memtime {stp(2)}
+        s_waitcnt lgkmcnt(0)
+        s_mov_b64 exec, 1
+        v_sub_u32 v46, {st(2)}, v46
+        ds_add_u32 v47, v46 offset:{LDS_TM + 8}
+        s_mov_b64 exec, -1
+        """)
+    else:
+        E("s_barrier")
     for dst, w0_ in ((fn, 0), (fb, KS)):
         if KS == 1:
             E(f"ds_read_b64 {dst}, v45 offset:{LDS_X + 512 * w0_}")
@@ -1579,6 +1628,13 @@ def probe(tag, P, pz_sgpr, pz, w0, w1, X, C, have, side, wait, wl=None, pl=None)
     body(tag + "r0", P, X, C, stp(6), True, wl, pl)
     if side and TT:   # now, while the side lanes hold nothing but their side item (the fixed-lane fallback gives them
         side_capture()  # candidates of their own in later rounds)
+    if PF2:           # the second candidates, fetched together with the first
+        X2, _, _, have2 = second_regs(tag)
+        E(f"""
+        s_cmp_eq_u64 {have2}, 0
+        s_cbranch_scc1 L_more_{tag}
+        """)
+        body(tag + "r0b", P, X2, None, have2, False)
     E(f"""
     L_more_{tag}:
     v_cmp_ne_u64 vcc, 0, v[{w0}:{w1}]
@@ -1591,6 +1647,14 @@ def probe(tag, P, pz_sgpr, pz, w0, w1, X, C, have, side, wait, wl=None, pl=None)
     body(tag + "rm", P, X, C, stp(6), False)
     E(f"s_branch L_more_{tag}")
     E(f"L_done_{tag}:")
+
+
+def second_regs(tag):
+    """z8t (PF2): where a lane's SECOND candidate goes -- registers the team does not use: (three pairs, dwordx4 base,
+    dwordx2 base, mask pair of the lanes that have one)"""
+    if tag == "A":   # team A never touches probe B's registers
+        return ["v[20:21]", "v[22:23]", "v[24:25]"], 20, 24, sp('haveB')
+    return ["v[26:27]", "v[28:29]", "v[4:5]"], 26, 4, sp('wallM')    # team B: probe A's coefficients and flag words
 
 
 def assign_specials(tag, w0, w1, X, C, wl, pl, with_side, have):
@@ -1648,6 +1712,25 @@ def assign_specials(tag, w0, w1, X, C, wl, pl, with_side, have):
     v_and_b32 v{w1}, v{w1}, v47
     {f"ds_read2_b64 v[{X}:{X+3}], v45 offset1:1" if LP else f"global_load_dwordx4 v[{X}:{X+3}], v45, {SRC}"}
     {f"ds_read_b64 v[{X+4}:{X+5}], v45 offset:16" if LP else f"global_load_dwordx2 v[{X+4}:{X+5}], v45, {SRC} offset:16"}
+    """)
+    if PF2:   # the lanes that still hold a candidate take that one too, its load travelling with the first
+        _, b4, b2, have2 = second_regs(tag)
+        E(f"""
+        v_cmp_ne_u64 {have2}, 0, v[{w0}:{w1}]
+        s_mov_b64 exec, {have2}
+        v_ffbl_b32 v44, v{w0}
+        v_ffbl_b32 v45, v{w1}
+        v_lshl_add_u64 v[46:47], v[{w0}:{w1}], 0, -1
+        v_or_b32 v45, 32, v45
+        v_min_u32 v44, v44, v45
+        v_and_b32 v{w0}, v{w0}, v46
+        v_and_b32 v{w1}, v{w1}, v47
+        v_lshl_or_b32 v44, v44, 6, {LANE}
+        v_mul_u32_u24 v45, 24, v44
+        global_load_dwordx4 v[{b4}:{b4+3}], v45, {SRC}
+        global_load_dwordx2 v[{b2}:{b2+1}], v45, {SRC} offset:16
+        """)
+    E(f"""
     s_mov_b64 exec, -1
     """)
     coeff_one(C)
@@ -2340,6 +2423,25 @@ if ZBC:
     s_waitcnt vmcnt(0)
     """)
 CLK1 = clk_ptr(stp(2))
+if TT and STAMPS:   # add this wave's sums to clk[rep][team * 2 + {{0, 1}}] instead of the end stamp (the start stamp is skipped too)
+    E(f"""
+    s_lshl_b32 {st(4)}, {WAVE}, 5
+    v_mov_b32 v20, {st(4)}
+    ds_read_b32 v22, v20 offset:{LDS_TM + 4}
+    ds_read_b32 v24, v20 offset:{LDS_TM + 8}
+    s_cmp_ge_u32 {WAVE}, {KS}
+    s_cselect_b32 {st(5)}, 16, 0
+    v_mov_b32 v21, {st(5)}
+    v_mov_b32 v23, 0
+    v_mov_b32 v25, 0
+    s_waitcnt lgkmcnt(0)
+    s_mov_b64 exec, 1
+    global_atomic_add_x2 v21, v[22:23], {CLK1}
+    global_atomic_add_x2 v21, v[24:25], {CLK1} offset:8
+    s_mov_b64 exec, -1
+    s_waitcnt vmcnt(0)
+    s_endpgm
+    """)
 E(f"""
 // end stamp
 s_memtime {stp(4)}

@@ -771,6 +771,18 @@ extern "C" int smcx_debug_wave_spread(smcx_handle *hh, double *out4)
     return SMCX_OK;
 }
 
+// diagnostics: the raw clock rows of the last sweep launch, [nrep][4] (start s_memtime, s_memrealtime, end s_memtime,
+// s_memrealtime; the two-team stamps variant of tools/probes/tt_phases.py: team A / team B cycle sums)
+extern "C" int smcx_debug_clk_rows(smcx_handle *hh, uint64_t *out)
+{
+    if (!hh || !out) return SMCX_ERR_PARAM;
+    Handle &h = hh->h;
+    if (!h.c.clk) return SMCX_ERR_STATE;
+    HIPCHK(&h, hipSetDevice(h.p.device));
+    HIPCHK(&h, hipMemcpy(out, h.c.clk, (size_t)h.p.nrep * 4 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    return SMCX_OK;
+}
+
 extern "C" int smcx_last_run_ms(smcx_handle *hh, double *ms)
 {
     if (!hh || !ms) return SMCX_ERR_PARAM;
