@@ -260,10 +260,19 @@ else:
     if W4:
         # Rs points at this wave's 4096 cells; Nw = how many of them hold a particle; walls and side pair: wave 0
         E(f"""
-        {f"s_and_b32 {st(0)}, {WAVE}, {KS - 1}" if TT else ""}
-        s_lshl_b32 {st(0)}, {st(0) if TT else WAVE}, {WSH}
-        s_sub_i32 {s('Nw')}, {s('N')}, {st(0)}
-        s_max_i32 {s('Nw')}, {s('Nw')}, 0
+        // the groups of 256 cells are dealt to the KS wavefronts round-robin (zsort_kernel: group g = local group g / KS of
+        // wave g % KS): this wave's real cells = its full groups + the partial last group if that one is its own
+        s_and_b32 {st(0)}, {WAVE}, {KS - 1}
+        s_lshr_b32 {st(4)}, {s('N')}, 8
+        s_and_b32 {st(5)}, {s('N')}, 255
+        s_add_u32 {st(6)}, {st(4)}, {KS - 1}
+        s_sub_u32 {st(6)}, {st(6)}, {st(0)}
+        s_lshr_b32 {st(6)}, {st(6)}, {KS.bit_length() - 1}
+        s_lshl_b32 {st(6)}, {st(6)}, 8
+        s_and_b32 {st(4)}, {st(4)}, {KS - 1}
+        s_cmp_eq_u32 {st(4)}, {st(0)}
+        s_cselect_b32 {st(5)}, {st(5)}, 0
+        s_add_u32 {s('Nw')}, {st(6)}, {st(5)}
         s_min_i32 {s('Nw')}, {s('Nw')}, {NS * 64}
         {f"s_and_b32 {st(0)}, {WAVE}, {KS - 1}" if TT else ""}
         s_cmp_eq_u32 {st(0) if TT else WAVE}, 0

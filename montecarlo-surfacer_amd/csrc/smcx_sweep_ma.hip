@@ -344,7 +344,7 @@ __device__ inline void bitonic_lds(unsigned *key, int kmax)
 #endif
 template <int CELLS, int TPB>
 __global__ void __launch_bounds__(TPB) zsort_kernel(const double *__restrict__ R, double *__restrict__ Rs,
-                                                    unsigned short *__restrict__ loc, int N, double toFix)
+                                                    unsigned short *__restrict__ loc, int N, double toFix, int K = 1)
 {
     // bits of the particle index in the keys; second keys: 32 - NB - (bits of the group) are left for the Morton code
     constexpr int NB = CELLS <= 4096 ? 12 : 14, GB = CELLS <= 4096 ? 4 : 6, MB = 32 - NB - GB;
@@ -381,7 +381,10 @@ __global__ void __launch_bounds__(TPB) zsort_kernel(const double *__restrict__ R
     for (int p = threadIdx.x; p < CELLS; p += TPB) {
         const unsigned k = key[p];
         const int g = p >> 8, r = p & 255;
-        const int c = g < full ? (4 * g + (r >> 6)) * 64 + ((r + ZSORT_DEAL * g) & 63) : p;
+        int c = g < full ? (4 * g + (r >> 6)) * 64 + ((r + ZSORT_DEAL * g) & 63) : p;
+        if (K > 1) // K wavefronts share the cells: group g is local group g / K of wave g % K (its cells start at
+            c = (g % K) * (CELLS / K) + (g / K) * 256 + (c & 255); // (g % K) CELLS / K) -- a probe's 3-4 groups in reach
+                                                                    // then lie on different wavefronts
         double *d = Rs + ((size_t)blockIdx.x * CELLS + c) * 3;
         if (k != ~0u) {
             const unsigned n = k & ((1u << NB) - 1u);
@@ -453,9 +456,10 @@ hipError_t launch_sweeps_mt(const SweepArgs &s, const DevCtx &c, const KernelPla
     const double toFix16 = 65536.0 / c.L;
     for (int sw = 0; sw < nsweeps; sw++) {
         if (pl.S == 16)
-            hipLaunchKernelGGL((zsort_kernel<16 * 64, 256>), dim3(c.nrep), dim3(256), 0, st, (const double *)s.R, c.Rs, c.loc, s.N, toFix16);
+            hipLaunchKernelGGL((zsort_kernel<16 * 64, 256>), dim3(c.nrep), dim3(256), 0, st, (const double *)s.R, c.Rs, c.loc, s.N, toFix16, 1);
         else
-            hipLaunchKernelGGL((zsort_kernel<4 * 64 * 64, 1024>), dim3(c.nrep), dim3(1024), 0, st, (const double *)s.R, c.Rs, c.loc, s.N, toFix16);
+            hipLaunchKernelGGL((zsort_kernel<4 * 64 * 64, 1024>), dim3(c.nrep), dim3(1024), 0, st, (const double *)s.R, c.Rs, c.loc, s.N, toFix16,
+                               pl.WPR / 2);
         a.sw0 = sw;
         hipError_t rc = tm ? tm->mark(st) : hipSuccess;
         if (rc != hipSuccess) return rc;
@@ -495,10 +499,10 @@ hipError_t launch_sweeps_mcw(const SweepArgs &s, const DevCtx &c, int WPR, int n
     for (int sw = 0; sw < nsweeps; sw++) {
         if (mid)
             hipLaunchKernelGGL((zsort_kernel<2 * 64 * 64, 1024>), dim3(c.nrep), dim3(1024), 0, st, (const double *)s.R, c.Rs, c.loc,
-                               s.N, toFix16);
+                               s.N, toFix16, WPR);
         else
             hipLaunchKernelGGL((zsort_kernel<4 * 64 * 64, 1024>), dim3(c.nrep), dim3(1024), 0, st, (const double *)s.R, c.Rs, c.loc,
-                               s.N, toFix16);
+                               s.N, toFix16, WPR);
         a.sw0 = sw;
         hipError_t rc = tm ? tm->mark(st) : hipSuccess;
         if (rc != hipSuccess) return rc;
