@@ -283,8 +283,8 @@ static int choose_geometry(const smcx_params *p, const Tune &t, int *S, int *WPR
         }
         // latency-bound shares (few replicas: at most two wavefronts per SIMD): the two-team form of the same kernel --
         // probe A and probe B on different wavefronts, one exchange per move (measured, tools/probes/tt_probe.py:
-        // N = 16384 x 256 replicas 37.0 ms per sweep against 44.0 for 32 x 8; N = 1024 x 1024 1.64 against 1.69; with twice
-        // the replicas the one-probe-after-the-other forms win: 57 against 74 ms, 1.89 against 2.24)
+        // N = 16384 x 256 replicas 28.2 ms per sweep against 36.4 for 32 x 8; N = 1024 x 1024 1.59 against 1.68; with twice
+        // the replicas the one-probe-after-the-other forms win: 50 against 57 ms, 1.89 against 2.24)
         if (p->tune_kernel == 0 || p->tune_kernel == SMCX_KERNEL_SCREENED) {
             if (p->N > 8192 && (long)p->nrep * 8 <= 2048 && plan_for(p, 64, 8, t, &pl) && pl.form == FORM_MT) { s = 64; w = 8; one_wave = true; }
             if (p->N <= 1024 && p->nrep <= 1024 && plan_for(p, 16, 2, t, &pl) && pl.form == FORM_MT) { s = 16; w = 2; one_wave = true; }
