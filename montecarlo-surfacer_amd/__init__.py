@@ -391,8 +391,9 @@ class Engine:
         self._chk(_lib().smcx_debug_wave_spread(self._h, out), "smcx_debug_wave_spread")
         return tuple(out)
 
-    def clk_rows(self):
-        out = np.zeros((self.p.nrep, 4), dtype=np.uint64)
+    def clk_rows(self, cols=4):
+        """cols = 32 with the two-team stamps variant of the library (tools/probes/tt_phases.py)"""
+        out = np.zeros((self.p.nrep, cols), dtype=np.uint64)
         self._chk(_lib().smcx_debug_clk_rows(self._h, _p(out, C.c_uint64)), "smcx_debug_clk_rows")
         return out
 

@@ -316,7 +316,7 @@ def clk_ptr(dst):
     lo, hi = (int(x) for x in dst[2:-1].split(":"))
     E(f"""
     s_load_dwordx2 {dst}, {KARG}, {K_CLK}
-    s_lshl_b32 {st(0)}, {REP}, 5
+    s_lshl_b32 {st(0)}, {REP}, {8 if (TT and STAMPS) else 5}
     s_waitcnt lgkmcnt(0)
     s_add_u32 s{lo}, s{lo}, {st(0)}
     s_addc_u32 s{hi}, s{hi}, 0
@@ -324,14 +324,13 @@ def clk_ptr(dst):
     return dst
 
 
-if TT and STAMPS:   # the clk row collects the phase sums of this variant: no start stamp; zero this wave's LDS sums
+if TT and STAMPS:   # the clk row collects the phase sums of this variant: no start stamp; zero this wave's 16 LDS words
     E(f"""
-    s_lshl_b32 {st(4)}, {WAVE}, 5
-    v_mov_b32 v14, {st(4)}
+    s_lshl_b32 {st(4)}, {WAVE}, 6
+    v_lshl_add_u32 v14, {LANE}, 2, {st(4)}
     v_mov_b32 v16, 0
-    v_mov_b32 v17, 0
-    s_mov_b64 exec, 1
-    ds_write_b64 v14, v[16:17] offset:{LDS_TM + 4}
+    s_mov_b64 exec, 0xffff
+    ds_write_b32 v14, v16 offset:{LDS_TM}
     s_mov_b64 exec, -1
     """)
 else:
@@ -372,6 +371,28 @@ v_mov_b32 {v('uns1')}, 0
 s_mov_b32 {s('rot')}, 0
 """)
 SRC = sp('Rs') if ZB else sp('Rg')    # what the compact copies are built from / candidates are fetched from
+
+
+def mark(k):
+    """z8t stamps variant: the cycles since this wave's previous mark are added to its LDS word k (1..15); word 0 = the
+    time of the previous mark.  Uses st(4..6), v46, v47 and drains the LDS/scalar counter: only where those are dead and
+    exec is full.  A mark costs about 100 cycles itself, charged to the interval that follows it."""
+    if not (TT and STAMPS):
+        return
+    E(f"""
+    s_memtime {stp(4)}
+    s_lshl_b32 {st(6)}, {WAVE}, 6
+    v_mov_b32 v47, {st(6)}
+    s_waitcnt lgkmcnt(0)
+    s_mov_b64 exec, 1
+    ds_read_b32 v46, v47 offset:{LDS_TM}
+    s_waitcnt lgkmcnt(0)
+    v_sub_u32 v46, {st(4)}, v46
+    {f"ds_add_u32 v47, v46 offset:{LDS_TM + 4 * k}" if k else ""}
+    v_mov_b32 v46, {st(4)}
+    ds_write_b32 v47, v46 offset:{LDS_TM}
+    s_mov_b64 exec, -1
+    """)
 
 
 def cnt_addr(vreg):
@@ -880,17 +901,7 @@ if ZB:
     E("s_branch L_move")
     COLD_AT = len(out)
 E("L_move:")
-if TT and STAMPS:
-    E(f"""
-    s_memtime {stp(0)}
-    s_lshl_b32 {st(2)}, {WAVE}, 5
-    s_waitcnt lgkmcnt(0)
-    v_mov_b32 v14, {st(0)}
-    v_mov_b32 v15, {st(2)}
-    s_mov_b64 exec, 1
-    ds_write_b32 v15, v14 offset:{LDS_TM}
-    s_mov_b64 exec, -1
-    """)
+mark(0)
 cold = []
 
 
@@ -1568,28 +1579,9 @@ def xchg2(part, fn, fb):
     ds_write_b64 v44, {part} offset:{LDS_X}
     s_waitcnt lgkmcnt(0)
     """)
-    if STAMPS:   # cycles from the start of the move to here, and those spent at the barrier
-        E(f"""
-        s_memtime {stp(2)}
-        s_lshl_b32 {st(4)}, {WAVE}, 5
-        v_mov_b32 v47, {st(4)}
-        s_mov_b64 exec, 1
-        ds_read_b32 v46, v47 offset:{LDS_TM}
-        s_waitcnt lgkmcnt(0)
-        v_sub_u32 v46, {st(2)}, v46
-        ds_add_u32 v47, v46 offset:{LDS_TM + 4}
-        v_mov_b32 v46, {st(2)}
-        s_mov_b64 exec, -1
-        s_barrier
-        s_memtime {stp(2)}
-        s_waitcnt lgkmcnt(0)
-        s_mov_b64 exec, 1
-        v_sub_u32 v46, {st(2)}, v46
-        ds_add_u32 v47, v46 offset:{LDS_TM + 8}
-        s_mov_b64 exec, -1
-        """)
-    else:
-        E("s_barrier")
+    mark(5)
+    E("s_barrier")
+    mark(6)
     for dst, w0_ in ((fn, 0), (fb, KS)):
         if KS == 1:
             E(f"ds_read_b64 {dst}, v45 offset:{LDS_X + 512 * w0_}")
@@ -1637,6 +1629,7 @@ def probe(tag, P, pz_sgpr, pz, w0, w1, X, C, have, side, wait, wl=None, pl=None)
     body(tag + "r0", P, X, C, stp(6), True, wl, pl)
     if side and TT:   # now, while the side lanes hold nothing but their side item (the fixed-lane fallback gives them
         side_capture()  # candidates of their own in later rounds)
+    mark(3)
     if PF2:           # the second candidates, fetched together with the first
         X2, _, _, have2 = second_regs(tag)
         E(f"""
@@ -1806,6 +1799,7 @@ if TT:   # team A screens and fetches for probe A only, team B for probe B only
     """)
 if Z8:
     screen_ranged8("A", s('axys'), v('wa0'), v('wa1'))
+    mark(1)
 elif ZB:
     screen_ranged("A", s('axys'), s('azz'), v('wa0'), v('wa1'))
     if ZBC:
@@ -1854,6 +1848,7 @@ if TT:
     """)
 if Z8:
     screen_ranged8("B", s('bxys'), v('wb0'), v('wb1'))
+    mark(1)
 elif ZB:
     screen_ranged("B", s('bxys'), s('bzz'), v('wb0'), v('wb1'))
     if ZBC:
@@ -1990,20 +1985,26 @@ if TT:
     s_cmp_eq_u32 {s('hasA')}, 0
     s_cbranch_scc1 L_xchg
     """)
+    mark(2)
     probe("A", QP, True, (s('Q', 4), s('Q', 5)), V['wa0'], V['wa1'], XA_, CA_, sp('haveA'), False,
           "s_waitcnt lgkmcnt(0)" if LP else "s_waitcnt vmcnt(0)")
+    mark(4)
     reduce4(FnV)
+    mark(11)
     E(f"""
     s_branch L_xchg
     L_evalB:
     s_cmp_eq_u32 {s('hasB')}, 0
     s_cbranch_scc1 L_xchg
     """)
+    mark(2)
     side_sources()
     E("s_waitcnt lgkmcnt(0)")
     probe("B", BP, False, "v[18:19]", V['wb0'], V['wb1'], XB_, CB_, sp('haveB'), True,
           "s_waitcnt lgkmcnt(0)" if LP else "s_waitcnt vmcnt(0)", sp('wallB'), sp('planeB'))
+    mark(4)
     reduce4(FnV)
+    mark(11)
     E(f"""
     L_xchg:
     // displacement of move i+1 per row (rows 1..3 -> components 0, 8, 16 of displ[3 (i+1) ..]): asked for now, it
@@ -2021,7 +2022,15 @@ if TT:
     L_nodd:
     """)
     xchg2(FnV, FnV, FbV)
+    # this move's dX = Fm A/T + displ (D2; harmless without a move to decide), then the displacement of move i+1 (asked
+    # for before the exchange) takes DdV's place NOW, before the accepted move's stores: vmcnt counts loads and stores in
+    # issue order, and a wait further down would cover those stores as well (config 5: 28.3 -> 27.5 ms per sweep; config 2,
+    # where half the moves accept, unchanged: the stores' acknowledgements were not what it waited for)
     E(f"""
+    v_fma_f64 {vp('D',2)}, {vp('FmV')}, {sp('AoT')}, {vp('DdV')}
+    s_waitcnt vmcnt(0)
+    v_mov_b32 {v('DdV')}, v{V['M'] + 2}
+    v_mov_b32 {v('DdV',1)}, v{V['M'] + 3}
     s_mov_b32 {s('accf')}, 0
     s_cmp_eq_u32 {s('hasA')}, 0
     s_cbranch_scc1 L_noA
@@ -2038,7 +2047,7 @@ E(f"""
 // ---- Metropolis step in row layout (SMC.c:326-335); DdV = displacement of this move per row
 v_add_f64 {vp('D',0)}, {FnV}, -{vp('FmV')}
 v_add_f64 {vp('D',1)}, {FnV}, {vp('FmV')}
-v_fma_f64 {vp('D',2)}, {vp('FmV')}, {sp('AoT')}, {vp('DdV')}
+{"" if TT else f"v_fma_f64 {vp('D',2)}, {vp('FmV')}, {sp('AoT')}, {vp('DdV')}"}
 v_mul_f64 {vp('D',2)}, {vp('D',2)}, 0.5
 v_fma_f64 {vp('D',2)}, {vp('D',0)}, {sp('Ao4T')}, {vp('D',2)}
 v_mul_f64 {vp('D',2)}, {vp('D',2)}, {vp('D',1)}
@@ -2063,6 +2072,9 @@ if ZB:
     v_add_f64 {vp('D',2)}, {vp('D',2)}, {vp('T')}
     v_mul_f64 {vp('D',2)}, {vp('D',2)}, -{sp('invT')}
     v_cmp_lt_f64 vcc, {sp('lu')}, {vp('D',2)}
+    """)
+    mark(7)
+    E(f"""
     s_bitcmp1_b32 vcc_hi, 31
     s_cbranch_scc0 L_reject
     """)
@@ -2210,6 +2222,7 @@ E(f"""
 L_reject:
 L_noA:
 """)
+mark(8)
 
 # ---------------------------------------------------------------------------------------------- probe B
 E(f"s_cmp_eq_u32 {s('hasB')}, 0")
@@ -2235,10 +2248,8 @@ if TT:
     s_waitcnt lgkmcnt(0)
     v_add_f64 {vp('FmV')}, {vp('FmV')}, {vp('ir2')}
     L_noside2:
-    s_waitcnt vmcnt(0)
-    v_mov_b32 {v('DdV')}, v{V['M'] + 2}
-    v_mov_b32 {v('DdV',1)}, v{V['M'] + 3}
     """)
+    mark(9)
 else:
     E(f"""
     // per-row component offset: rows 1..3 -> 0, 8, 16 (row 0 idles along with component 0)
@@ -2274,7 +2285,7 @@ s_add_u32 {st(0)}, {s('tl')}, 1
 s_mul_i32 {st(0)}, {st(0)}, 24
 {f"v_add3_u32 {v('T',1)}, {st(0)}, {v('T')}, v1" if W4 else f"v_add_u32 {v('T',1)}, {st(0)}, {v('T')}"}
 ds_read_b64 {vp('D',0)}, {v('T',1)} offset:{LDS_P0}
-s_waitcnt vmcnt(0) lgkmcnt(0)
+{"s_waitcnt lgkmcnt(0)" if TT else "s_waitcnt vmcnt(0) lgkmcnt(0)"}
 {'' if Z8 else f"s_mov_b64 {sp('lu')}, {sp('nlu')}"}
 v_fma_f64 {vp('D',1)}, {vp('FmV')}, {sp('AoT')}, {vp('DdV')}
 v_add_f64 {vp('D',0)}, {vp('D',0)}, {vp('D',1)}
@@ -2335,6 +2346,7 @@ E(f"s_mov_b32 {s('tl')}, -1")
 E("L_nocross:")
 E(f"s_add_u32 {s('tl')}, {s('tl')}, 1")
 E("L_noB:")
+mark(10)
 if ZB:
     E(f"s_mov_b32 {s('locA')}, {s('locB')}")
 E(f"""
@@ -2432,21 +2444,18 @@ if ZBC:
     s_waitcnt vmcnt(0)
     """)
 CLK1 = clk_ptr(stp(2))
-if TT and STAMPS:   # add this wave's sums to clk[rep][team * 2 + {{0, 1}}] instead of the end stamp (the start stamp is skipped too)
+if TT and STAMPS:   # add this wave's 16 words to clk[rep][team * 16 + k] instead of the end stamp (no start stamp either)
     E(f"""
-    s_lshl_b32 {st(4)}, {WAVE}, 5
-    v_mov_b32 v20, {st(4)}
-    ds_read_b32 v22, v20 offset:{LDS_TM + 4}
-    ds_read_b32 v24, v20 offset:{LDS_TM + 8}
+    s_lshl_b32 {st(4)}, {WAVE}, 6
+    v_lshl_add_u32 v20, {LANE}, 2, {st(4)}
     s_cmp_ge_u32 {WAVE}, {KS}
-    s_cselect_b32 {st(5)}, 16, 0
-    v_mov_b32 v21, {st(5)}
+    s_cselect_b32 {st(5)}, 128, 0
+    v_lshl_add_u32 v21, {LANE}, 3, {st(5)}
     v_mov_b32 v23, 0
-    v_mov_b32 v25, 0
+    s_mov_b64 exec, 0xffff
+    ds_read_b32 v22, v20 offset:{LDS_TM}
     s_waitcnt lgkmcnt(0)
-    s_mov_b64 exec, 1
     global_atomic_add_x2 v21, v[22:23], {CLK1}
-    global_atomic_add_x2 v21, v[24:25], {CLK1} offset:8
     s_mov_b64 exec, -1
     s_waitcnt vmcnt(0)
     s_endpgm

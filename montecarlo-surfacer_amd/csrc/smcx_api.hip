@@ -14,6 +14,13 @@
 #include <algorithm>
 #include <vector>
 
+// qwords per replica in the clock rows (the two-team stamps variant keeps 16 phase sums per team there)
+#ifdef SMCX_TT_STAMPS
+constexpr size_t CLK_COLS = 32;
+#else
+constexpr size_t CLK_COLS = 4;
+#endif
+
 using namespace smcx;
 
 namespace {
@@ -411,8 +418,8 @@ extern "C" int smcx_create(const smcx_params *p, smcx_handle **out)
     CRT(hipMalloc(&c.rec, nrep * h.chunk * sizeof(SweepRec)));
     CRT(hipMalloc(&c.zhist, nrep * p->Ncz * sizeof(unsigned long long)));
     CRT(hipMalloc((void **)&c.wtab, (size_t)(c.M2 + 1) * 4 * sizeof(double)));
-    CRT(hipMalloc(&c.clk, nrep * 4 * sizeof(unsigned long long)));
-    CRT(hipMemset(c.clk, 0, nrep * 4 * sizeof(unsigned long long)));
+    CRT(hipMalloc(&c.clk, nrep * CLK_COLS * sizeof(unsigned long long)));
+    CRT(hipMemset(c.clk, 0, nrep * CLK_COLS * sizeof(unsigned long long)));
     // progress table of the SIMDs' wavefronts (hand-scheduled kernels): 8 XCDs x 128 (SE, SH, CU) x 4 SIMDs rows of
     // 4 words; the kernels build the index from exact-width register fields (gen_sweep_ma.py, PRIO)
     CRT(hipMalloc(&c.prio, 16384 * sizeof(unsigned)));
@@ -772,14 +779,14 @@ extern "C" int smcx_debug_wave_spread(smcx_handle *hh, double *out4)
 }
 
 // diagnostics: the raw clock rows of the last sweep launch, [nrep][4] (start s_memtime, s_memrealtime, end s_memtime,
-// s_memrealtime; the two-team stamps variant of tools/probes/tt_phases.py: team A / team B cycle sums)
+// s_memrealtime); the two-team stamps variant of tools/probes/tt_phases.py: [nrep][32] = 16 phase sums of team A, 16 of team B
 extern "C" int smcx_debug_clk_rows(smcx_handle *hh, uint64_t *out)
 {
     if (!hh || !out) return SMCX_ERR_PARAM;
     Handle &h = hh->h;
     if (!h.c.clk) return SMCX_ERR_STATE;
     HIPCHK(&h, hipSetDevice(h.p.device));
-    HIPCHK(&h, hipMemcpy(out, h.c.clk, (size_t)h.p.nrep * 4 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    HIPCHK(&h, hipMemcpy(out, h.c.clk, (size_t)h.p.nrep * CLK_COLS * sizeof(uint64_t), hipMemcpyDeviceToHost));
     return SMCX_OK;
 }
 

@@ -258,8 +258,8 @@ __global__ void __launch_bounds__(1024, 1) sweep_kernel_mt32x16(MaArgs a)
 // LDS of the two-team kernels: a row cache per wave, the exchange area [2][waves][64] doubles, the side area
 #ifdef SMCX_CHECK
 constexpr unsigned mt_lds_bytes(int wpr) { return (unsigned)wpr * 2048u + 2u * (unsigned)wpr * 512u + 128u + (unsigned)wpr * 32u; }
-#elif defined(SMCX_TT_STAMPS) // measurement variant (SMCX_GEN_TT_STAMPS=1 make VARIANT=stamps EXTRA=-DSMCX_TT_STAMPS): + phase sums
-constexpr unsigned mt_lds_bytes(int wpr) { return (unsigned)wpr * 2048u + 2u * (unsigned)wpr * 512u + 128u + (unsigned)wpr * 32u; }
+#elif defined(SMCX_TT_STAMPS) // measurement variant (SMCX_GEN_TT_STAMPS=1 make VARIANT=stamps EXTRA=-DSMCX_TT_STAMPS): + 16 phase words per wave
+constexpr unsigned mt_lds_bytes(int wpr) { return (unsigned)wpr * 2048u + 2u * (unsigned)wpr * 512u + 128u + (unsigned)wpr * 64u; }
 #else
 constexpr unsigned mt_lds_bytes(int wpr) { return (unsigned)wpr * 2048u + 2u * (unsigned)wpr * 512u + 128u; }
 #endif
