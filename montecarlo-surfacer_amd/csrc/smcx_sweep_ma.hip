@@ -362,22 +362,28 @@ __global__ void __launch_bounds__(TPB) zsort_kernel(const double *__restrict__ R
         key[n] = k;
     }
     __syncthreads();
+#ifndef SMCX_ZSORT_NOSORT
     bitonic_lds<CELLS, TPB, false>(key, CELLS);
+#endif
     const int full = N >> 8; // groups with 256 particles
     for (int p = threadIdx.x; p < CELLS; p += TPB) {
         const unsigned k = key[p];
         if (k == ~0u) continue;
         const unsigned n = k & ((1u << NB) - 1u);
         unsigned sub = (unsigned)(p & 255) << (MB - 8); // a partial group keeps z order
+#ifndef SMCX_ZSORT_NOMORTON // (measurement builds: make VARIANT=x EXTRA=-DSMCX_ZSORT_NOMORTON, likewise _NOGATHER, _NOSORT)
         if ((p >> 8) < full) {
             const unsigned ix = ((unsigned)(int)rint(Rr[3 * n] * toFix) + 0x8000u) >> 8;     // 8 bits of the wrapped x
             const unsigned iy = ((unsigned)(int)rint(Rr[3 * n + 1] * toFix) + 0x8000u) >> 8;
             sub = (spread8(ix) | (spread8(iy) << 1)) >> (16 - MB);                            // the top MB bits of the code
         }
+#endif
         key[p] = ((unsigned)(p >> 8) << (32 - GB)) | (sub << NB) | n;
     }
     __syncthreads();
+#ifndef SMCX_ZSORT_NOSORT
     bitonic_lds<CELLS, TPB, true>(key, 256);
+#endif
     for (int p = threadIdx.x; p < CELLS; p += TPB) {
         const unsigned k = key[p];
         const int g = p >> 8, r = p & 255;
@@ -389,7 +395,11 @@ __global__ void __launch_bounds__(TPB) zsort_kernel(const double *__restrict__ R
         if (k != ~0u) {
             const unsigned n = k & ((1u << NB) - 1u);
             loc[(size_t)blockIdx.x * N + n] = (unsigned short)c;
+#ifdef SMCX_ZSORT_NOGATHER
+            d[0] = d[1] = d[2] = 1.0;
+#else
             d[0] = Rr[3 * n]; d[1] = Rr[3 * n + 1]; d[2] = Rr[3 * n + 2];
+#endif
         } else {
             d[0] = d[1] = d[2] = 0.0;
         }
