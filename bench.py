@@ -144,6 +144,55 @@ def executed_work(kname, N, lattice, slots, waves, device, nrep=64, sweeps=2):
                       "of the same start, after the timed region" % (nrep, sweeps)}
 
 
+def cpu_model():
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def host_cores():
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    return max(1, min(cores, 16))  # the GPU box's CPU share for one GPU
+
+
+def cpu_baseline_reference(N, Na, Nz, seconds_target=12.0):
+    """The REAL reference (kind "reference"): oneParticleMoves of SMC.c compiled where it lies by oracle/build_ref.sh into
+    oracle/_ref/libref_smc_N<n>_O3.so (prebuilt; travels with the snapshot), one chain per PROCESS and core -- the
+    reference's own MPI fan-out, and its libc rand() state is per process.  None when the library is not there."""
+    import subprocess
+    so = os.path.join(ROOT, "oracle", "_ref", "libref_smc_N%d_O3.so" % N)
+    script = os.path.join(ROOT, "oracle", "time_ref.py")
+    if not (os.path.exists(so) and os.path.exists(script)):
+        return None
+    cores = host_cores()
+
+    def run(seed, sweeps):
+        return subprocess.Popen([sys.executable, script, str(N), str(Na), str(Nz), str(seed), str(sweeps)],
+                                stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
+    try:
+        out, _ = run(12345, 1).communicate(timeout=120)          # calibrate: one sweep on one core
+        t1 = float(out.split()[0])
+        sweeps = max(1, int(seconds_target / max(t1, 1e-3) / 1.3))  # cores slow down when all are busy
+        procs = [run(12345 + i, sweeps) for i in range(cores)]
+        secs = [float(pr.communicate(timeout=600)[0].split()[0]) for pr in procs]
+    except Exception:
+        return None
+    wall = max(secs)                                             # the slowest chain's time inside its sweep loop
+    pe = cores * sweeps * 2.0 * N * (N - 1.0)
+    return {"value": pe / wall, "unit": "pair-evals/s", "cores": cores, "kind": "reference", "cpu_model": cpu_model(),
+            "per_core": pe / wall / cores,
+            "sample": "%d independent chains (one process per core) x %d sweeps of N=%d, fcc(%d,%d) start, the reference's "
+                      "own oneParticleMoves (SMC.c:278-351 compiled where it lies, gcc -O3 -march=x86-64-v3), slowest chain "
+                      "%.1f s" % (cores, sweeps, N, Na, Nz, wall)}
+
+
 def cpu_baseline(N, Na, Nz, seconds_target=12.0):
     """The oracle (CPU restatement, kind "port") timed on this box's host cores: one
     independent chain per core, the reference's intended MPI fan-out."""
@@ -169,11 +218,7 @@ def cpu_baseline(N, Na, Nz, seconds_target=12.0):
     except Exception:
         lib = O.lib()
         flags = "gcc -O2 -ffp-contract=off"
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except AttributeError:
-        cores = os.cpu_count() or 1
-    cores = max(1, min(cores, 16))  # the GPU box's CPU share for one GPU
+    cores = host_cores()
     R0 = O.fcc(Na, Nz)
     s = O.make_sys(N)
 
@@ -191,15 +236,7 @@ def cpu_baseline(N, Na, Nz, seconds_target=12.0):
         list(ex.map(one, [(12345 + i, sweeps) for i in range(cores)]))
     wall = time.perf_counter() - t0
     pe = cores * sweeps * 2.0 * N * (N - 1.0)
-    model = "unknown"
-    try:
-        for ln in open("/proc/cpuinfo"):
-            if ln.startswith("model name"):
-                model = ln.split(":", 1)[1].strip()
-                break
-    except OSError:
-        pass
-    return {"value": pe / wall, "unit": "pair-evals/s", "cores": cores, "kind": "port", "cpu_model": model,
+    return {"value": pe / wall, "unit": "pair-evals/s", "cores": cores, "kind": "port", "cpu_model": cpu_model(),
             "per_core": pe / wall / cores,
             "sample": "%d independent chains (one per core) x %d sweeps of N=%d, fcc(%d,%d) start, "
                       "oracle/smc_oracle.c built %s, %.1f s wall" % (cores, sweeps, N, Na, Nz, flags, wall)}
@@ -420,7 +457,13 @@ def main():
                     out["other_configs"].append({"workload": label, "value": None, "note": "failed: %r" % (e,)})
         if world == 1 and not a.no_cpu:
             try:
-                out["cpu_baseline"] = cpu_baseline(N, *lattice)
+                # the reference itself where its prebuilt library is at hand (kind "reference"), with the oracle's rate on
+                # the same cores beside it; the oracle alone (kind "port") otherwise
+                ref = cpu_baseline_reference(N, *lattice)
+                port = cpu_baseline(N, *lattice, seconds_target=6.0 if ref else 12.0)
+                if ref:
+                    ref["oracle_port"] = {k: port[k] for k in ("value", "per_core", "sample")}
+                out["cpu_baseline"] = ref or port
             except Exception as e:  # the baseline leg must never take the GPU number down
                 out["cpu_baseline"] = {"value": None, "unit": "pair-evals/s", "cores": 0, "kind": "port",
                                        "sample": "failed: %r" % (e,)}

@@ -46,6 +46,25 @@ for n in $SMC_NS; do
     } | $CC $FLAGS -DREF_MATEMATICOSE_C="\"$REF_DIR/matematicose.c\"" -x c - -o "$out" -lm
 done
 
+# timing builds of the same translation unit (bench.py's cpu_baseline leg, kind "reference"): -O3 for a portable
+# AVX2/FMA x86-64 level -- the GPU box's host CPU differs from this container's, so no -march=native here
+TIME_NS="${TIME_NS:-4096}"
+for n in $TIME_NS; do
+    out=_ref/libref_smc_N${n}_O3.so
+    if [ -f "$out" ] && [ "$out" -nt ref_smc_wrap.c ] && [ "$out" -nt ref_smc_prelude.c ] && [ "$out" -nt build_ref.sh ]; then continue; fi
+    {
+        cat ref_smc_prelude.c
+        echo "#line 26 \"$REF_DIR/SMC.h\""
+        sed -n '26,121p' "$REF_DIR/SMC.h" | sed "s/^#define N 108\$/#define N $n/"
+        echo "#line 269 \"$REF_DIR/SMC.c\""
+        sed -n '269,1049p' "$REF_DIR/SMC.c"
+        echo "#line 1094 \"$REF_DIR/SMC.c\""
+        sed -n '1094,1169p' "$REF_DIR/SMC.c"
+        echo "#line 1 \"ref_smc_wrap.c\""
+        cat ref_smc_wrap.c
+    } | $CC -O3 -march=x86-64-v3 -fPIC -w -std=gnu11 -shared -Wl,-Bsymbolic -DREF_MATEMATICOSE_C="\"$REF_DIR/matematicose.c\"" -x c - -o "$out" -lm
+done
+
 for n in $NW_NS; do
     out=_ref/libref_nw_N$n.so
     if [ -f "$out" ] && [ "$out" -nt ref_nw_wrap.c ] && [ "$out" -nt build_ref.sh ]; then continue; fi

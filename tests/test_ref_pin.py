@@ -97,3 +97,25 @@ def test_reference_libraries_are_the_reference(oracle_backend):
     assert r.walls_energy(X, W, 33.0, 200.0) == -4.0581627260515186e-14
     E, jj = r.sweeps(12345, X, W, 33.0, 200.0, 1.1, 1.1, 20, E0)
     assert E[-1] == -3.8631457699032183 and int(jj.sum()) == 2048
+
+
+def test_timing_build_of_the_reference_equals_the_oracle_on_one_sweep():
+    """bench.py's cpu_baseline leg, kind "reference": oracle/time_ref.py runs the -O3 build of the REAL oneParticleMoves
+    (oracle/_ref/libref_smc_N4096_O3.so).  It is a timing leg, but what it times must be the sweep the bench's GPU side runs:
+    same start, same seed -> the accepted count of the oracle, the energy to contraction-level rounding."""
+    import subprocess
+    import sys
+    import numpy as np
+    import oracle_lib as O
+    so = os.path.join(ref_lib.REF_DIR, "libref_smc_N4096_O3.so")
+    if not os.path.exists(so):
+        pytest.skip("oracle/_ref/libref_smc_N4096_O3.so not built (no reference tree here)")
+    out = subprocess.run([sys.executable, os.path.join(os.path.dirname(HERE), "oracle", "time_ref.py"), "4096", "8", "16",
+                          "12345", "1"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    secs, acc, E1 = out.stdout.split()
+    assert float(secs) > 0.0
+    s = O.make_sys(4096)
+    ch = O.chain(s, 12345, O.fcc(8, 16), O.W_FIXTURE, 1.1, 1.1, 0, 1, 10)
+    assert int(acc) == int(ch["jj"][0])
+    assert abs(float(E1) - ch["E"][1]) < 1e-9 * max(1.0, abs(ch["E"][1]))
