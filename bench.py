@@ -45,7 +45,8 @@ def issue_roofline(kname, sweep_ms_per_sweep, nrep, N, clock_ghz, start=None):
     path = os.path.join(ROOT, "profiles", "kernel_counters.json")
     if not os.path.exists(path) or not clock_ghz:
         return None
-    kc = json.load(open(path)).get(kname)
+    allk = json.load(open(path))
+    kc = (allk.get("%s@%s" % (kname, start)) if start else None) or allk.get(kname)   # a second start state of a kernel: "name@start"
     if not kc:
         return None
     if kc["workload"]["replicas"] != nrep or kc["workload"]["N"] != N or \
@@ -281,6 +282,8 @@ def main():
     ap.add_argument("--waves", type=int, default=0)
     ap.add_argument("--resort", type=int, default=0, help="measurement switch: smcx_params.tune_resort (sweeps per z sort)")
     ap.add_argument("--kernel", type=int, default=0, help="measurement switch: smcx_params.tune_kernel (SMCX_KERNEL_*)")
+    ap.add_argument("--lattice", default="", help="measurement switch: fcc start Na,Nz other than the configuration's (e.g. 16,4: the "
+                                                  "dense film of other_configs, for its PMC passes)")
     ap.add_argument("--no-cpu", action="store_true",
                     help="skip the reference legs after the timed region (cpu_baseline, all-fp64 kernels): profiling runs")
     a = ap.parse_args()
@@ -314,6 +317,10 @@ def main():
         torch.cuda.set_device(local_rank)
         dist.init_process_group(backend, rank=rank, world_size=world)  # "nccl" = RCCL over xGMI
     lattice = {256: (4, 4), 1024: (8, 4), 4096: (8, 16), 16384: (16, 16)}[a.N]
+    if a.lattice:
+        lattice = tuple(int(x) for x in a.lattice.split(","))
+        if 4 * lattice[0] * lattice[0] * lattice[1] != a.N:
+            raise SystemExit("--lattice %s does not hold N=%d particles" % (a.lattice, a.N))
     N, nrep = a.N, a.replicas
     first, _ = D.shard(nrep * world, rank, world)
     p = S.default_params(N, nrep, device=local_rank, first_replica=first,

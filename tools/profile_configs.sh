@@ -1,6 +1,6 @@
 #!/bin/bash
 # PMC instruction mix, activity and HBM counters of the sweep kernel of BASELINE configs 3, 2 and 5 (per-GPU share):
-#   tools/profile_configs.sh <tag>      (through gpurun, from the repo root; 15 rocprofv3 --pmc passes, counters only)
+#   tools/profile_configs.sh <tag>      (through gpurun, from the repo root; 20 rocprofv3 --pmc passes, counters only)
 # Writes gpurun_out/prof_<tag>_c{3,2,5}/ and merges the three kernel_counters.json into
 # gpurun_out/kernel_counters_<tag>.json (copy to profiles/kernel_counters.json to make bench.py use it).
 set -e
@@ -10,15 +10,20 @@ cd "$ROOT"
 tools/profile_valu.sh ${TAG}_c3 > gpurun_out/pmc_${TAG}_c3.txt 2>&1
 PMC_N=1024 PMC_NREP=1024 PMC_WPR=2 tools/profile_valu.sh ${TAG}_c2 --N 1024 --replicas 1024 > gpurun_out/pmc_${TAG}_c2.txt 2>&1
 PMC_N=16384 PMC_NREP=256 PMC_WPR=8 tools/profile_valu.sh ${TAG}_c5 --N 16384 --replicas 256 > gpurun_out/pmc_${TAG}_c5.txt 2>&1
+# the adverse start of other_configs (dense film, most groups in reach): same kernel as config 3, keyed "kernel@start"
+tools/profile_valu.sh ${TAG}_dense --lattice 16,4 > gpurun_out/pmc_${TAG}_dense.txt 2>&1
 python3 - "$TAG" <<'PY'
 import json, sys
 tag = sys.argv[1]
 out = {}
-for c in ("c3", "c2", "c5"):
+START = {"c3": "fcc(8,16)", "c2": "fcc(8,4)", "c5": "fcc(16,16)", "dense": "fcc(16,4)"}
+for c in ("c3", "c2", "c5", "dense"):
     d = json.load(open("gpurun_out/prof_%s_%s/kernel_counters.json" % (tag, c)))
     for k, v in d.items():
-        v["source"] = "tools/profile_configs.sh %s (rocprofv3 --pmc, 5 passes of bench.py --steps 9 --warmup 1 --no-cpu), config %s" % (tag, c[1])
-        out[k] = v
+        v["source"] = "tools/profile_configs.sh %s (rocprofv3 --pmc, 5 passes of bench.py --steps 9 --warmup 1 --no-cpu), %s" % (
+            tag, "config " + c[1] if c != "dense" else "dense film")
+        v["workload"]["start"] = START[c]
+        out[k if c != "dense" else k + "@" + START[c]] = v
 json.dump(out, open("gpurun_out/kernel_counters_%s.json" % tag, "w"), indent=1, sort_keys=True)
 print("kernels:", sorted(out))
 PY
