@@ -371,6 +371,32 @@ v_mov_b32 {v('uns1')}, 0
 s_mov_b32 {s('rot')}, 0
 """)
 SRC = sp('Rs') if ZB else sp('Rg')    # what the compact copies are built from / candidates are fetched from
+if TT:
+    # z8t: per-lane constants of the part that follows the exchange, in the registers behind the cells: row r = lane >> 4
+    # carries component r - 1 (row 0: the energies); inside a row, lanes 0-7 work for the outcome "rejected", lanes 8-15
+    # for "accepted" (the side pair's two results), so the next proposal is formed for BOTH before the decision is known
+    KR = XY0 + NS
+    KINV, KFIX, KPROW, KSIDE = f"v[{KR}:{KR+1}]", f"v[{KR+2}:{KR+3}]", f"v{KR+4}", f"v{KR+5}"
+    E(f"""
+    v_lshrrev_b32 v14, 4, {LANE}
+    v_add_u32 v15, -1, v14
+    v_max_i32 v15, 0, v15
+    v_lshlrev_b32 {KPROW}, 3, v15
+    v_bfe_u32 v15, {LANE}, 3, 1
+    v_lshlrev_b32 v15, 5, v15
+    v_lshl_add_u32 {KSIDE}, v14, 3, v15
+    v_mov_b32 v{KR}, {s('invL')}
+    v_mov_b32 v{KR+1}, {s('invL',1)}
+    v_mov_b32 v{KR+2}, {s('toFix')}
+    v_mov_b32 v{KR+3}, {s('toFix',1)}
+    s_mov_b32 exec_lo, 0x0000ffff
+    s_mov_b32 exec_hi, 0xffff0000
+    v_mov_b32 v{KR}, 0
+    v_mov_b32 v{KR+1}, 0
+    v_mov_b32 v{KR+2}, {s('zFix')}
+    v_mov_b32 v{KR+3}, {s('zFix',1)}
+    s_mov_b64 exec, -1
+    """)
 
 
 def mark(k):
@@ -1564,7 +1590,7 @@ def side_capture():
     """)
 
 
-def xchg2(part, fn, fb):
+def xchg2(part, fn, fb, extra=""):
     """z8t: the ONE exchange of a move.  `part` (row layout) = this wave's partial sums of ITS team's probe; afterwards
     fn = sum over team A's waves (probe A), fb = sum over team B's (probe B without the side pair), added in wave order
     by every wave alike.  Two buffers alternate with the parity of the move counter, so that a wave that is already in
@@ -1582,6 +1608,7 @@ def xchg2(part, fn, fb):
     mark(5)
     E("s_barrier")
     mark(6)
+    E(extra)      # further LDS reads of the caller: they travel with the exchange reads
     for dst, w0_ in ((fn, 0), (fb, KS)):
         if KS == 1:
             E(f"ds_read_b64 {dst}, v45 offset:{LDS_X + 512 * w0_}")
@@ -2011,17 +2038,29 @@ if TT:
     // travels during the exchange and the Metropolis step (DdV itself is still this move's)
     s_cmp_eq_u32 {s('hasB')}, 0
     s_cbranch_scc1 L_nodd
-    v_lshrrev_b32 {v('T')}, 4, {LANE}
-    v_add_u32 {v('T')}, -1, {v('T')}
-    v_max_i32 {v('T')}, 0, {v('T')}
-    v_lshlrev_b32 {v('T')}, 3, {v('T')}
     s_add_u32 {st(1)}, {s('i')}, 1
     s_mul_i32 {st(1)}, {st(1)}, 24
-    v_add_u32 {v('S6')}, {st(1)}, {v('T')}
+    v_add_u32 {v('S6')}, {st(1)}, {KPROW}
     global_load_dwordx2 {DdN}, {v('S6')}, {sp('dK')}
     L_nodd:
+    // what the part after the exchange reads from LDS, per lane: component (row - 1) of particle n+1's position (row cache)
+    // and the side pair's result [row][rejected | accepted] of this move's buffer
+    s_add_u32 {st(0)}, {s('tl')}, 1
+    s_mul_i32 {st(0)}, {st(0)}, 24
+    v_add3_u32 v22, {st(0)}, {KPROW}, v1
+    s_and_b32 {st(1)}, {s('i')}, 1
+    s_lshl_b32 {st(1)}, {st(1)}, 6
+    v_add_u32 v23, {st(1)}, {KSIDE}
+    v_mov_b32 v14, 0
+    v_mov_b32 v15, 0
     """)
-    xchg2(FnV, FnV, FbV)
+    xchg2(FnV, FnV, FbV, f"""
+    ds_read_b64 v[16:17], v22 offset:{LDS_P0}
+    s_cmp_lg_u32 {s('hasA')}, 0
+    s_cselect_b64 exec, -1, 0
+    ds_read_b64 v[14:15], v23 offset:{LDS_SIDE}
+    s_mov_b64 exec, -1
+    """)
     # this move's dX = Fm A/T + displ (D2; harmless without a move to decide), then the displacement of move i+1 (asked
     # for before the exchange) takes DdV's place NOW, before the accepted move's stores: vmcnt counts loads and stores in
     # issue order, and a wait further down would cover those stores as well (config 5: 28.3 -> 27.5 ms per sweep; config 2,
@@ -2031,9 +2070,72 @@ if TT:
     s_waitcnt vmcnt(0)
     v_mov_b32 {v('DdV')}, v{V['M'] + 2}
     v_mov_b32 {v('DdV',1)}, v{V['M'] + 3}
+    s_mov_b64 {stp(0)}, 0xffff
+    """)
+    # Two chains that do not depend on each other, issued alternately (a wavefront with its SIMD almost to itself waits
+    # out the latency of every dependent instruction): M = the Metropolis argument of this move (SMC.c:326-335; row 0:
+    # 4 (eA - eB), by selection instead of an exec mask), P = the proposal of particle n+1 (SMC.c:307-316) for both
+    # outcomes: Fm = team B's total + the side result of the lane's half, q = p + (Fm A/T + displ), wrap of rows 1-2 by the
+    # per-row constants (0 in rows 0 and 3: no wrap), fixed point; the unsafe-z test of every lane goes to planeM's pair
+    Mc = f"""
+    v_add_f64 {vp('D',0)}, {FnV}, -{vp('FmV')}
+    v_add_f64 {vp('D',1)}, {FnV}, {vp('FmV')}
+    v_mul_f64 {vp('D',2)}, {vp('D',2)}, 0.5
+    v_fma_f64 {vp('D',2)}, {vp('D',0)}, {sp('Ao4T')}, {vp('D',2)}
+    v_mul_f64 {vp('D',2)}, {vp('D',2)}, {vp('D',1)}
+    v_mul_f64 {vp('T')}, {vp('D',0)}, 4.0
+    v_cndmask_b32 {v('D',4)}, {v('D',4)}, {v('T')}, {stp(0)}
+    v_cndmask_b32 {v('D',5)}, {v('D',5)}, {v('T',1)}, {stp(0)}
+    v_mov_b32 {v('T')}, 0
+    v_mov_b32 {v('T',1)}, 0
+    v_mov_b32_dpp {v('T')}, {v('D',4)} row_bcast:15 row_mask:0xa bank_mask:0xf
+    v_mov_b32_dpp {v('T',1)}, {v('D',5)} row_bcast:15 row_mask:0xa bank_mask:0xf
+    v_add_f64 {vp('D',2)}, {vp('D',2)}, {vp('T')}
+    s_nop 1
+    v_mov_b32_dpp {v('T')}, {v('D',4)} row_bcast:31 row_mask:0xc bank_mask:0xf
+    v_mov_b32_dpp {v('T',1)}, {v('D',5)} row_bcast:31 row_mask:0xc bank_mask:0xf
+    v_add_f64 {vp('D',2)}, {vp('D',2)}, {vp('T')}
+    v_mul_f64 {vp('D',2)}, {vp('D',2)}, -{sp('invT')}
+    """
+    Pc = f"""
+    v_add_f64 v[14:15], {FbV}, v[14:15]
+    v_fma_f64 v[18:19], v[14:15], {sp('AoT')}, {vp('DdV')}
+    v_add_f64 v[16:17], v[16:17], v[18:19]
+    v_mul_f64 v[18:19], v[16:17], {KINV}
+    v_rndne_f64 v[18:19], v[18:19]
+    v_fma_f64 v[16:17], -v[18:19], {sp('L')}, v[16:17]
+    v_mul_f64 v[18:19], v[16:17], {KFIX}
+    v_cmp_nlt_f64 {sp('planeM')}, |v[16:17]|, {sp('zsafe')}
+    v_rndne_f64 v[18:19], v[18:19]
+    v_mov_b32 v24, 0x7fff
+    v_mov_b32 v25, 0xffff8001
+    v_cvt_i32_f64 v20, v[18:19]
+    v_med3_i32 v21, v20, v24, v25
+    """
+    Ml = [l.strip() for l in Mc.strip().split("\n") if l.strip()]
+    Pl = [l.strip() for l in Pc.strip().split("\n") if l.strip()]
+    ILV = os.environ.get("SMCX_GEN_NO_ILV") != "1"
+    if ILV:
+        k = 0
+        for j, m in enumerate(Ml):
+            E(m)
+            if not m.startswith("s_nop") and k < len(Pl):
+                E(Pl[k]); k += 1
+        for q in Pl[k:]:
+            E(q)
+    else:
+        for q in Pl + Ml:
+            E(q)
+    E(f"""
     s_mov_b32 {s('accf')}, 0
     s_cmp_eq_u32 {s('hasA')}, 0
     s_cbranch_scc1 L_noA
+    v_cmp_lt_f64 vcc, {sp('lu')}, {vp('D',2)}
+    """)
+    mark(7)
+    E(f"""
+    s_bitcmp1_b32 vcc_hi, 31
+    s_cbranch_scc0 L_reject
     """)
 else:
     E(f"s_cmp_eq_u32 {s('hasA')}, 0")
@@ -2043,11 +2145,11 @@ else:
     reduce4(FnV)
     if W4:
         xchg(FnV, 0)
-E(f"""
-// ---- Metropolis step in row layout (SMC.c:326-335); DdV = displacement of this move per row
+(E if not TT else (lambda t: None))(f"""
+// ---- Metropolis step in row layout (SMC.c:326-335); DdV = displacement of this move per row (z8t: above, interleaved)
 v_add_f64 {vp('D',0)}, {FnV}, -{vp('FmV')}
 v_add_f64 {vp('D',1)}, {FnV}, {vp('FmV')}
-{"" if TT else f"v_fma_f64 {vp('D',2)}, {vp('FmV')}, {sp('AoT')}, {vp('DdV')}"}
+v_fma_f64 {vp('D',2)}, {vp('FmV')}, {sp('AoT')}, {vp('DdV')}
 v_mul_f64 {vp('D',2)}, {vp('D',2)}, 0.5
 v_fma_f64 {vp('D',2)}, {vp('D',0)}, {sp('Ao4T')}, {vp('D',2)}
 v_mul_f64 {vp('D',2)}, {vp('D',2)}, {vp('D',1)}
@@ -2057,7 +2159,9 @@ v_mul_f64 {vp('D',2)}, {vp('D',2)}, {vp('D',1)}
 v_mul_f64 {vp('D',2)}, {vp('D',0)}, 4.0
 s_mov_b64 exec, -1
 """)
-if ZB:
+if TT:
+    pass
+elif ZB:
     # sum over the four rows into row 3 with the row broadcasts of DPP (the rows are uniform after reduce4):
     # rows 1, 3 += lane 15 of rows 0, 2; then rows 2, 3 += lane 31; the decision is row 3's
     E(f"""
@@ -2228,27 +2332,39 @@ mark(8)
 E(f"s_cmp_eq_u32 {s('hasB')}, 0")
 E("s_cbranch_scc1 L_noB")
 if TT:
-    # probe B was evaluated before the decision (team B): Fm of particle n+1 = its total without the side pair + the
-    # side result that applies (n where the move left it): row r reads component r of [accepted ? new : old]
+    # probe B was evaluated before the decision (team B) and the proposal of particle n+1 formed for both outcomes (above):
+    # the half of every row that worked for the outcome that did NOT happen takes the other half's Fm (it is the next move's
+    # Fm and must be uniform in its row); position, fixed-point copies and the unsafe flag are read from the lanes
+    # 16 row + 8 accf
     E(f"""
     s_add_u32 {st(1)}, {s('i')}, 1
     s_lshl_b32 {st(0)}, {st(1)}, 3
     s_load_dwordx2 {sp('lu')}, {sp('uK')}, {st(0)}
-    v_mov_b32 {v('FmV')}, v{V['dr2']}
-    v_mov_b32 {v('FmV',1)}, v{V['dr2'] + 1}
-    s_cmp_eq_u32 {s('hasA')}, 0
-    s_cbranch_scc1 L_noside2
-    s_lshl_b32 {st(0)}, {s('accf')}, 5
-    s_and_b32 {st(1)}, {s('i')}, 1
-    s_lshl_b32 {st(1)}, {st(1)}, 6
-    s_add_u32 {st(0)}, {st(0)}, {st(1)}
-    v_lshrrev_b32 {v('T')}, 4, {LANE}
-    v_lshl_add_u32 {v('T')}, {v('T')}, 3, {st(0)}
-    ds_read_b64 {vp('ir2')}, {v('T')} offset:{LDS_SIDE}
-    s_waitcnt lgkmcnt(0)
-    v_add_f64 {vp('FmV')}, {vp('FmV')}, {vp('ir2')}
-    L_noside2:
+    v_mov_b32_dpp {v('T')}, v14 row_ror:8 row_mask:0xf bank_mask:0xf
+    v_mov_b32_dpp {v('T',1)}, v15 row_ror:8 row_mask:0xf bank_mask:0xf
+    s_xor_b32 {st(2)}, {s('accf')}, 1
+    s_lshl_b32 {st(2)}, {st(2)}, 3
+    s_lshl_b32 {st(2)}, 0x00ff00ff, {st(2)}
+    s_mov_b32 {st(3)}, {st(2)}
+    s_lshl_b32 {st(4)}, {s('accf')}, 3
+    s_add_u32 {st(5)}, {st(4)}, 16
+    s_add_u32 {st(6)}, {st(4)}, 32
+    s_add_u32 {st(7)}, {st(4)}, 48
+    v_cndmask_b32 {v('FmV')}, v14, {v('T')}, {stp(2)}
+    v_cndmask_b32 {v('FmV',1)}, v15, {v('T',1)}, {stp(2)}
+    s_lshr_b64 {stp(2)}, {sp('planeM')}, {st(7)}
+    s_and_b32 {s('ua')}, {st(2)}, 1
+    v_readlane_b32 {s('Q',0)}, v16, {st(5)}
+    v_readlane_b32 {s('Q',1)}, v17, {st(5)}
+    v_readlane_b32 {s('Q',2)}, v16, {st(6)}
+    v_readlane_b32 {s('Q',3)}, v17, {st(6)}
+    v_readlane_b32 {s('Q',4)}, v16, {st(7)}
+    v_readlane_b32 {s('Q',5)}, v17, {st(7)}
+    v_readlane_b32 {st(0)}, v20, {st(5)}
+    v_readlane_b32 {st(1)}, v20, {st(6)}
+    v_readlane_b32 {st(2)}, v21, {st(7)}
     """)
+    # (no wait for lu here: every later wait on this counter is lgkmcnt(0), the first at the latest before the exchange)
     mark(9)
 else:
     E(f"""
@@ -2274,8 +2390,8 @@ else:
     reduce4(vp('FmV'))
     if W4:
         xchg(vp('FmV'), 1)
-E(f"""
-// ---- proposal of particle n+1 in row layout (SMC.c:307-316): q = p + (Fm A/T + displ)
+(E if not TT else (lambda t: None))(f"""
+// ---- proposal of particle n+1 in row layout (SMC.c:307-316): q = p + (Fm A/T + displ)   (z8t: before the decision, above)
 // rows 1..3 read component row-1 of p0[rowB] and of displ[3 (i+1) ..]; row 0 idles along with component 0
 v_lshrrev_b32 {v('T')}, 4, {LANE}
 v_add_u32 {v('T')}, -1, {v('T')}

@@ -219,7 +219,7 @@ __global__ void __launch_bounds__(128, 1) sweep_kernel_mt16x2(MaArgs a)
 #endif
         : "+v"(lane), "+s"(kp), "+s"(rep), "+s"(wv)
         :
-        : "memory", "vcc", "scc", "m0", SMCX_MA_SGPRS, SMCX_MA_V79);
+        : "memory", "vcc", "scc", "m0", SMCX_MA_SGPRS, SMCX_MA_V95); // v80..v85: per-lane constants behind the cells
 }
 __global__ void __launch_bounds__(512, 1) sweep_kernel_mt64x8(MaArgs a)
 {
@@ -235,7 +235,7 @@ __global__ void __launch_bounds__(512, 1) sweep_kernel_mt64x8(MaArgs a)
 #endif
         : "+v"(lane), "+s"(kp), "+s"(rep), "+s"(wv)
         :
-        : "memory", "vcc", "scc", "m0", SMCX_MA_SGPRS, SMCX_MA_V127);
+        : "memory", "vcc", "scc", "m0", SMCX_MA_SGPRS, SMCX_MA_V127, "v128", "v129", "v130", "v131", "v132", "v133");
 }
 // sixteen wavefronts: eight slabs of 32 cells per lane x two teams (thinner slabs: a probe's candidates spread over more
 // wavefronts, fewer second rounds on dense states)
@@ -253,7 +253,7 @@ __global__ void __launch_bounds__(1024, 1) sweep_kernel_mt32x16(MaArgs a)
 #endif
         : "+v"(lane), "+s"(kp), "+s"(rep), "+s"(wv)
         :
-        : "memory", "vcc", "scc", "m0", SMCX_MA_SGPRS, SMCX_MA_V95);
+        : "memory", "vcc", "scc", "m0", SMCX_MA_SGPRS, SMCX_MA_V127);
 }
 // LDS of the two-team kernels: a row cache per wave, the exchange area [2][waves][64] doubles, the side area
 #ifdef SMCX_CHECK
