@@ -176,6 +176,8 @@ if W4:
     S.update(Nw=S['bzz'], M2w=S['az16'], hasAw=S['azz'])
 
 
+if Z8 and not W4:
+    S.update(RZ=S['azz'])     # the reach of a group's z range in z units: azz is not used by the one-word screen
 if TT:
     # team B's waves never use probe A's masks: haveA's low word holds the lane of the side pair evaluated with the
     # PROPOSAL (sideL: with n's current position); its high word carries the accept flag from the Metropolis step to
@@ -377,7 +379,11 @@ if TT:
     # for "accepted" (the side pair's two results), so the next proposal is formed for BOTH before the decision is known
     KR = XY0 + NS
     KINV, KFIX, KPROW, KSIDE = f"v[{KR}:{KR+1}]", f"v[{KR+2}:{KR+3}]", f"v{KR+4}", f"v{KR+5}"
+    KRZ = f"v{KR+6}"          # the reach of a group's z range (an accepted move widens its group's range by it)
     E(f"""
+    s_load_dword {st(0)}, {KARG}, {K_RZ}
+    s_waitcnt lgkmcnt(0)
+    v_mov_b32 {KRZ}, {st(0)}
     v_lshrrev_b32 v14, 4, {LANE}
     v_add_u32 v15, -1, v14
     v_max_i32 v15, 0, v15
@@ -565,6 +571,7 @@ if ZB:
     {f"v_lshl_add_u32 v14, {LANE}, 3, v1" if W4 else f"v_lshlrev_b32 v14, 3, {LANE}"}
     ds_read_b64 v[16:17], v14 offset:{LDS_GB}
     s_waitcnt lgkmcnt(0)
+    {f"s_mov_b32 {s('RZ')}, {st(0)}" if (Z8 and not W4) else ""}
     v_subrev_u32 {v('gloR')}, {st(0)}, v16
     v_add_u32 {v('ghiR')}, {st(0)}, v17
     v_cmp_gt_i32 vcc, v16, v17
@@ -2310,9 +2317,9 @@ else:
     E(f"""
     s_lshr_b32 {st(1)}, {st(1)}, 2
     s_lshl_b64 {stp(2)}, 1, {st(1)}
-    s_load_dword {st(6)}, {KARG}, {K_RZ}
+    {f"v_readfirstlane_b32 {st(6)}, {KRZ}" if TT else f"s_mov_b32 {st(6)}, {s('RZ')}" if (Z8 and not W4) else f"s_load_dword {st(6)}, {KARG}, {K_RZ}"}
     s_sext_i32_i16 {st(0)}, {s('axys') if Z8 else s('az16')}
-    s_waitcnt lgkmcnt(0)
+    {"" if (TT or (Z8 and not W4)) else "s_waitcnt lgkmcnt(0)"}
     s_sub_i32 {st(4)}, {st(0)}, {st(6)}
     s_add_i32 {st(5)}, {st(0)}, {st(6)}
     s_mov_b64 exec, {stp(2)}

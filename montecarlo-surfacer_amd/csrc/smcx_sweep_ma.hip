@@ -235,7 +235,7 @@ __global__ void __launch_bounds__(512, 1) sweep_kernel_mt64x8(MaArgs a)
 #endif
         : "+v"(lane), "+s"(kp), "+s"(rep), "+s"(wv)
         :
-        : "memory", "vcc", "scc", "m0", SMCX_MA_SGPRS, SMCX_MA_V127, "v128", "v129", "v130", "v131", "v132", "v133");
+        : "memory", "vcc", "scc", "m0", SMCX_MA_SGPRS, SMCX_MA_V127, "v128", "v129", "v130", "v131", "v132", "v133", "v134", "v135");
 }
 // sixteen wavefronts: eight slabs of 32 cells per lane x two teams (thinner slabs: a probe's candidates spread over more
 // wavefronts, fewer second rounds on dense states)
