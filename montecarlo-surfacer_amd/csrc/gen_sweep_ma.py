@@ -318,7 +318,7 @@ def clk_ptr(dst):
     lo, hi = (int(x) for x in dst[2:-1].split(":"))
     E(f"""
     s_load_dwordx2 {dst}, {KARG}, {K_CLK}
-    s_lshl_b32 {st(0)}, {REP}, {8 if (TT and STAMPS) else 5}
+    s_lshl_b32 {st(0)}, {REP}, {11 if (TT and STAMPS) else 5}
     s_waitcnt lgkmcnt(0)
     s_add_u32 s{lo}, s{lo}, {st(0)}
     s_addc_u32 s{hi}, s{hi}, 0
@@ -373,6 +373,31 @@ v_mov_b32 {v('uns1')}, 0
 s_mov_b32 {s('rot')}, 0
 """)
 SRC = sp('Rs') if ZB else sp('Rg')    # what the compact copies are built from / candidates are fetched from
+if W4 and not TT and os.environ.get("SMCX_GEN_W0_PRIO", "1") == "1":
+    # z8w: the wavefront that carries the wall sites and the side pair (slab 0) is the last at both exchanges of a move: it
+    # gets the higher issue priority (mc32x4 at N = 8192 x 1024: 29.7 -> 28.9 ms per sweep; mc64x4 at 16384 x 512: 42.4 -> 41.6)
+    E(f"""
+    s_cmp_eq_u32 {WAVE}, 0
+    s_cbranch_scc0 L_prioW
+    s_setprio 3
+    L_prioW:
+    """)
+if TT:
+    # z8t: team B's wavefronts carry the side pair and two exclusions on top of what team A's do and arrive last at the
+    # exchange, and where a SIMD holds wavefronts of both teams its arbiter serves the older -- team A's -- first.  Team B
+    # gets the higher issue priority for the whole kernel: config 2 1.56 -> 1.41 ms per sweep, config 5 27.0 -> 26.1 (any
+    # split of the levels with B above A measured the same; switch for the A/B: SMCX_GEN_TT_PRIO=0)
+    # (measured, config 2 / config 5 ms per sweep: none 1.562 / 27.11; all 1.403 / 25.91; team B until its reduction is
+    # done 1.451 / 25.65; until its probe is done 1.467 / 25.67)
+    # team B always + team A from its probe to the end of its reduction ("allA"): 1.43 / 25.40
+    TTP = os.environ.get("SMCX_GEN_TT_PRIO", "all" if NS == 16 else "allA")     # all | allA | probe | red | 0
+    if TTP in ("all", "allA"):
+        E(f"""
+        s_cmp_ge_u32 {WAVE}, {KS}
+        s_cbranch_scc0 L_prioA
+        s_setprio 3
+        L_prioA:
+        """)
 if TT:
     # z8t: per-lane constants of the part that follows the exchange, in the registers behind the cells: row r = lane >> 4
     # carries component r - 1 (row 0: the energies); inside a row, lanes 0-7 work for the outcome "rejected", lanes 8-15
@@ -1879,6 +1904,7 @@ if TT:
     E(f"""
     s_branch L_nofb
     L_teamB:
+    {"s_setprio 3" if TTP in ("probe", "red") else ""}
     """)
 if Z8:
     screen_ranged8("B", s('bxys'), v('wb0'), v('wb1'))
@@ -2020,10 +2046,14 @@ if TT:
     s_cbranch_scc1 L_xchg
     """)
     mark(2)
+    if TTP == "allA":
+        E("s_setprio 3")
     probe("A", QP, True, (s('Q', 4), s('Q', 5)), V['wa0'], V['wa1'], XA_, CA_, sp('haveA'), False,
           "s_waitcnt lgkmcnt(0)" if LP else "s_waitcnt vmcnt(0)")
     mark(4)
     reduce4(FnV)
+    if TTP == "allA":
+        E("s_setprio 0")
     mark(11)
     E(f"""
     s_branch L_xchg
@@ -2037,7 +2067,11 @@ if TT:
     probe("B", BP, False, "v[18:19]", V['wb0'], V['wb1'], XB_, CB_, sp('haveB'), True,
           "s_waitcnt lgkmcnt(0)" if LP else "s_waitcnt vmcnt(0)", sp('wallB'), sp('planeB'))
     mark(4)
+    if TTP == "probe":
+        E("s_setprio 0")
     reduce4(FnV)
+    if TTP == "red":
+        E("s_setprio 0")
     mark(11)
     E(f"""
     L_xchg:
@@ -2567,12 +2601,11 @@ if ZBC:
     s_waitcnt vmcnt(0)
     """)
 CLK1 = clk_ptr(stp(2))
-if TT and STAMPS:   # add this wave's 16 words to clk[rep][team * 16 + k] instead of the end stamp (no start stamp either)
+if TT and STAMPS:   # add this wave's 16 words to clk[rep][wave * 16 + k] (up to 16 waves) instead of the end stamp (no start stamp either)
     E(f"""
     s_lshl_b32 {st(4)}, {WAVE}, 6
     v_lshl_add_u32 v20, {LANE}, 2, {st(4)}
-    s_cmp_ge_u32 {WAVE}, {KS}
-    s_cselect_b32 {st(5)}, 128, 0
+    s_lshl_b32 {st(5)}, {WAVE}, 7
     v_lshl_add_u32 v21, {LANE}, 3, {st(5)}
     v_mov_b32 v23, 0
     s_mov_b64 exec, 0xffff

@@ -16,7 +16,7 @@
 
 // qwords per replica in the clock rows (the two-team stamps variant keeps 16 phase sums per team there)
 #ifdef SMCX_TT_STAMPS
-constexpr size_t CLK_COLS = 32;
+constexpr size_t CLK_COLS = 256;
 #else
 constexpr size_t CLK_COLS = 4;
 #endif
@@ -779,7 +779,7 @@ extern "C" int smcx_debug_wave_spread(smcx_handle *hh, double *out4)
 }
 
 // diagnostics: the raw clock rows of the last sweep launch, [nrep][4] (start s_memtime, s_memrealtime, end s_memtime,
-// s_memrealtime); the two-team stamps variant of tools/probes/tt_phases.py: [nrep][32] = 16 phase sums of team A, 16 of team B
+// s_memrealtime); the two-team stamps variant of tools/probes/tt_phases.py: [nrep][256] = 16 phase sums of each of up to 16 wavefronts
 extern "C" int smcx_debug_clk_rows(smcx_handle *hh, uint64_t *out)
 {
     if (!hh || !out) return SMCX_ERR_PARAM;

@@ -10,7 +10,7 @@ S = smcx_loader.load()
 which = sys.argv[1].split(",") if len(sys.argv) > 1 else ["c2", "c3", "c5", "dense"]
 W = {"c2": ("config 2: N=1024 x 1024", 1024, 1024, (8, 4), 40), "c3": ("config 3: N=4096 x 4096", 4096, 4096, (8, 16), 8),
      "c5": ("config 5: N=16384 x 256", 16384, 256, (16, 16), 4), "dense": ("dense film fcc(16,4) x 4096", 4096, 4096, (16, 4), 4),
-     "n8192": ("N=8192 x 1024", 8192, 1024, (16, 8), 4)}
+     "n8192": ("N=8192 x 1024", 8192, 1024, (16, 8), 4), "c5x512": ("N=16384 x 512", 16384, 512, (16, 16), 4)}
 for k in which:
     label, N, nrep, lat, sweeps = W[k]
     p = S.default_params(N, nrep)
