@@ -115,8 +115,63 @@ def test_config5_N16384_x256_invariants(S, O):
     assert np.all(rel(ob["E_last"], Erec) < 1e-9)
     assert np.all(g == 2) and np.all(oob == 0) and np.all(ob["zhist"].sum(axis=1) == 2 * 16384)
     assert len(np.unique(ob["accepted"])) > 8          # distinct seeds, distinct chains
-    ref = O.chain(sys_of(O, p), 12345, R0, O.W_FIXTURE, T, A, 1, 2, 1, e0_restart=False)
-    assert int(ob["accepted"][0]) == ref["accepted"] and rel(ob["E_last"][0], ref["Efinal"]) < 1e-9
+    # replicas spread over the launch (first, last, and two inside: all eight wavefronts of a workgroup resident beside
+    # those of other replicas) against the oracle chain (SMC.c:110-118 thermalisation at 2A, :134-195 production)
+    pick = [0, 85, 170, 255]
+    refs = [None] * len(pick)
+    with ThreadPoolExecutor(len(pick)) as ex:
+        refs = list(ex.map(lambda r: O.chain(sys_of(O, p), 12345 + r, R0, O.W_FIXTURE, T, A, 1, 2, 1, e0_restart=False), pick))
+    for r, ref in zip(pick, refs):
+        assert int(ob["accepted"][r]) == ref["accepted"], r
+        assert rel(ob["E_last"][r], ref["Efinal"]) < 1e-9, r
+        assert np.array_equal(ob["zhist"][r], ref["zhist"]), r
+
+
+# ------------------------------------------------------------------ BASELINE config 3: N = 4096 x 4096 (the headline)
+CONFIG3_PICK = [0, 1, 1023, 2047, 2048, 3071, 4094, 4095]
+
+
+def test_config3_N4096_x4096_headline_launch_against_oracle(S, O):
+    """BASELINE configs[2] exactly as bench.py runs it: default parameters, 4096 replicas of N=4096 on one GPU (four
+    wavefronts on every SIMD of the chip, the issue-priority table live, `Rs` cycling through the L2s), gather_lapse 10,
+    kernel sweep_kernel_mc64.  Eight replicas spread over the launch against the oracle chain (SMC.c:278-351 sweeps
+    inside sMC's loop, SMC.c:134-195), three sweeps: accepted counts bit-equal, energies 1e-9, positions 1e-8; then the
+    same launch with a gather before every sweep for the per-sweep series and the z histogram (SMC.c:912-927)."""
+    R0 = O.fcc(8, 16)
+    nrep, nsw, pick = 4096, 3, CONFIG3_PICK
+    p = S.default_params(4096, nrep)                     # bench.py's parameters
+    with S.Engine(p) as eng:
+        assert eng.kernel_form == (2, "smcx::sweep_kernel_mc64"), eng.kernel_form
+        eng.upload(R0, O.W_FIXTURE)
+        eng.run(0, nsw, 10)                              # bench.py: eng.run(0, steps, gather_lapse = 10)
+        ob = eng.observables()
+        Rg = eng.positions()[pick].copy()
+        Erec = eng.total_energy()
+    s = sys_of(O, p)
+    refs = oracle_chains(O, s, [12345 + r for r in pick], R0, 0, nsw, 10)
+    assert np.all(rel(ob["E_last"], Erec) < 1e-9)        # every replica: incremental energy = recomputed energy
+    assert len(np.unique(ob["accepted"])) > nrep // 4
+    for k, (r, ref) in enumerate(zip(pick, refs)):
+        assert int(ob["accepted"][r]) == ref["accepted"], r
+        assert rel(ob["E_last"][r], ref["Efinal"]) < 1e-9, r
+        assert rel(ob["meanE"][r], ref["meanE"]) < 1e-9, r
+        assert abs(ob["acceptance_ratio"][r] - ref["acceptance_ratio"]) < 1e-12, r
+        assert np.abs(Rg[k] - ref["R"]).max() < 1e-8, r
+    # the same full launch with a gather before every sweep: per-sweep series and the wall-normal profile
+    p = S.default_params(4096, nrep, flags=p.flags | S.FLAG_SERIES)
+    with S.Engine(p) as eng:
+        assert eng.kernel_form == (2, "smcx::sweep_kernel_mc64"), eng.kernel_form
+        eng.upload(R0, O.W_FIXTURE)
+        eng.run(0, nsw, 1)
+        ob = eng.observables()
+        Es, jj = eng.series(nsw)
+        g, oob = eng.hist_info()
+    assert np.all(g == nsw) and np.all(oob == 0) and np.all(ob["zhist"].sum(axis=1) == nsw * 4096)
+    refs = oracle_chains(O, s, [12345 + r for r in pick], R0, 0, nsw, 1)
+    for r, ref in zip(pick, refs):
+        assert np.array_equal(jj[r], ref["jj"]), (r, jj[r], ref["jj"])
+        assert np.all(rel(Es[r], ref["E"], scale=1.0) < 1e-9), r
+        assert np.array_equal(ob["zhist"][r], ref["zhist"]), r
 
 
 # ------------------------------------------------------------------ BASELINE config 2: N = 1024 x 1024
