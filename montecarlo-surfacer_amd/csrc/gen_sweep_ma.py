@@ -65,11 +65,28 @@ import sys
 out = []
 
 
-def E(txt=""):
+def E(txt="", tag=""):
     for ln in txt.strip("\n").split("\n"):
         ln = ln.strip()
         if ln and not ln.startswith("//"):
-            out.append(ln)
+            out.append(ln + tag)
+
+
+def GW(txt):
+    """as G where hasAw is hasA (one wavefront per replica); with several, hasAw is 0 on the waves without specials"""
+    (E if W4 else G)(txt)
+
+
+def G(txt):
+    """lines that only the GENERIC copy of the move keeps (tests of hasA / hasB: the steady copy runs the moves that have
+    both a proposal to decide and a next particle, i.e. all but the first and the last of a run)"""
+    E(txt, " @G" if PEEL else "")
+
+
+def SO(txt):
+    """lines that only the STEADY copy of the move keeps"""
+    if PEEL:
+        E(txt, " @S")
 
 
 # ---------------------------------------------------------------------------------------------- registers
@@ -109,6 +126,10 @@ SLOTF = ((NS.bit_length() - 1) << 16) | 6                 # s_bfe field of the s
 Z8 = Z8C or W4 or MODE == "z8"
 ZB = ZBC or Z8 or MODE == "zb"
 NG = NS // 4                                              # 4-slot groups
+# The move loop is emitted twice for the z-ordered kernels: a GENERIC copy that tests hasA (a proposal to decide: not in the
+# first pass of a run, which only evaluates the first particle) and hasB (a next particle: not in the last pass), and a
+# STEADY copy for every other pass without those eight test-and-branch pairs (16 scalar instructions of ~180 per move).
+PEEL = ZB and os.environ.get("SMCX_GEN_NOPEEL") != "1"
 # z8t with 16 cells per lane ("LP"): the fp64 positions of all cells (24 KB, what candidates are fetched from) and the
 # wall table live in LDS at offset 0, shared by the two wavefronts of the replica; every other LDS area moves up
 PF2 = TT and NS >= 32     # z8t with many cells: the first TWO candidates of a lane are fetched together (dense states: the
@@ -829,7 +850,7 @@ if Z8:
     E(f"""
     s_getpc_b64 {sp('nlu')}
     L_jbase:
-    s_add_u32 {s('nlu')}, {s('nlu')}, L_sg{NG-1}_A-L_jbase
+    s_add_u32 {s('nlu')}, {s('nlu')}, L_jb-L_jbase
     s_addc_u32 {s('nlu',1)}, {s('nlu',1)}, 0
     """)
 
@@ -958,8 +979,17 @@ COLD_AT = None
 if ZB:
     E("s_branch L_move")
     COLD_AT = len(out)
+MOVE_AT = len(out)
 E("L_move:")
+G("L_G_move:")
 mark(0)
+# measurement switch SMCX_GEN_PAD=<kind><count>: <count> extra instructions per move (S = SALU, V = fast VALU form, W = slow VALU
+# form, N = s_nop 0, D = fp64 VALU), all on dead registers: what an instruction of each kind costs the running kernel
+PAD = os.environ.get("SMCX_GEN_PAD", "")
+if PAD:
+    for _ in range(int(PAD[1:])):
+        E({"S": f"s_add_u32 {st(7)}, {st(7)}, 1", "V": "v_mov_b32 v14, v15", "W": "v_alignbit_b32 v14, v15, v16, 31",
+           "N": "s_nop 0", "D": "v_add_f64 v[14:15], v[16:17], v[18:19]"}[PAD[0]])
 cold = []
 
 
@@ -1009,9 +1039,11 @@ L_nob1:
 """)
 else:
   # zb: from the row registers (lane tl + 1), or the scalar copy of particle row*64 + 64 when the order crosses rows
-  E(f"""
+  G(f"""
   s_cmp_eq_u32 {s('hasB')}, 0
   s_cbranch_scc1 L_nob0
+  """)
+  E(f"""
   s_add_u32 {s('lb')}, {s('tl')}, 1
   s_cmp_eq_u32 {s('tl')}, 63
   s_cselect_b32 {s('lb')}, 0, {s('lb')}
@@ -1195,13 +1227,16 @@ def screen_ranged8(tag, pws, w0, w1):
     {f"s_add_u32 {st(1)}, {st(4)}, {st(5)}" if Z8C else ""}
     {f"s_sub_u32 {st(1)}, 32, {st(1)}" if Z8C else ""}
     s_mul_i32 {st(5)}, {st(5)}, L_sg{NG-2}_{tag}-L_sg{NG-1}_{tag}
-    s_add_u32 {st(5)}, {st(5)}, L_sg{NG-1}_{tag}-L_sg{NG-1}_A-{32 - NG}*(L_sg{NG-2}_A-L_sg{NG-1}_A)
+    s_add_u32 {st(5)}, {st(5)}, L_sg{NG-1}_{tag}-L_jb-{32 - NG}*(L_sg{NG-2}_A-L_sg{NG-1}_A)
     s_add_u32 {st(2)}, {s('nlu')}, {st(5)}
     s_addc_u32 {st(3)}, {s('nlu',1)}, 0
     s_setpc_b64 {stp(2)}
     """)
     # blocks in descending group order; flbit = 31 - highest group, so block g sits (flbit - (32 - NG)) blocks in
     for g in range(NG - 1, -1, -1):
+        if g == NG - 1 and tag == "A":
+            E("L_jb:", " @S" if PEEL else "")   # what the computed jumps of BOTH copies of the move are relative to (the
+                                                 # steady copy lies first: every offset is positive)
         E(f"L_sg{g}_{tag}:")
         screen_group8(4 * g, v('pxy'), w(g))
         if g > 0:
@@ -1673,8 +1708,8 @@ def probe(tag, P, pz_sgpr, pz, w0, w1, X, C, have, side, wait, wl=None, pl=None)
     E(f"L_nw_{tag}:")
     E(f"s_or_b64 {stp(6)}, {have}, {wl}")
     if side:
-        E(f"s_cmp_eq_u32 {s_hasAw()}, 0")
-        E(f"s_cbranch_scc1 L_noside_{tag}")
+        GW(f"s_cmp_eq_u32 {s_hasAw()}, 0")
+        GW(f"s_cbranch_scc1 L_noside_{tag}")
         if ZB:
             E(f"s_lshl_b64 {stp(0)}, 1, {s('sideL')}")
             E(f"s_or_b64 {stp(6)}, {stp(6)}, {stp(0)}")
@@ -1869,8 +1904,12 @@ E(f"""
 v_or_b32 {v('wa0')}, {v('wa0')}, {v('uns0')}
 v_or_b32 {v('wa1')}, {v('wa1')}, {v('uns1')}
 {'' if ZB else f"s_mov_b64 {sp('haveA')}, 0"}
+""")
+G(f"""
 s_cmp_eq_u32 {s('hasA')}, 0
 s_cbranch_scc1 L_nofa
+""")
+E(f"""
 s_cmp_eq_u32 {s('ua')}, 0
 s_cbranch_scc1 L_ua0
 """)
@@ -1919,6 +1958,8 @@ E(f"""
 v_or_b32 {v('wb0')}, {v('wb0')}, {v('uns0')}
 v_or_b32 {v('wb1')}, {v('wb1')}, {v('uns1')}
 {'' if ZB else f"s_mov_b64 {sp('haveB')}, 0"}
+""")
+G(f"""
 s_cmp_eq_u32 {s('hasB')}, 0
 s_cbranch_scc1 L_nofb0
 """)
@@ -1944,7 +1985,7 @@ L_ub0:
 if ZB:
     # not neighbours of B: the particle it stands for, and the moving particle n, which reaches B through the side pair
     excl(v('wb0'), v('wb1'), s('locB'))
-    E(f"""
+    G(f"""
     s_cmp_eq_u32 {s('hasA')}, 0
     s_cbranch_scc1 L_fb1
     """)
@@ -2013,9 +2054,11 @@ DdN = vp('M', 1)          # z8t: v[38:39] = displacement of move i+1 per row, lo
 def side_sources():
     """the side pair's sources on the side lanes: particle n = p0[tl] (ma, zb: where the move left it, read after the
     decision; z8t: its CURRENT position, read before the decision, and the proposal Q on the second lane)"""
-    E(f"""
+    GW(f"""
     s_cmp_eq_u32 {s_hasAw()}, 0
     s_cbranch_scc1 L_nosrc
+    """)
+    E(f"""
     s_mul_i32 {st(0)}, {s('tl')}, 24
     {f"v_add_u32 {v('T')}, {st(0)}, v1" if W4 else f"v_mov_b32 {v('T')}, {st(0)}"}
     {f"s_lshl_b64 {stp(2)}, 1, {s('sideL')}" if ZB else ""}
@@ -2042,6 +2085,8 @@ if TT:
     v_mov_b32 v{V['M'] + 1}, 0
     s_cmp_ge_u32 {WAVE}, {KS}
     s_cbranch_scc1 L_evalB
+    """)
+    G(f"""
     s_cmp_eq_u32 {s('hasA')}, 0
     s_cbranch_scc1 L_xchg
     """)
@@ -2058,6 +2103,8 @@ if TT:
     E(f"""
     s_branch L_xchg
     L_evalB:
+    """)
+    G(f"""
     s_cmp_eq_u32 {s('hasB')}, 0
     s_cbranch_scc1 L_xchg
     """)
@@ -2073,12 +2120,14 @@ if TT:
     if TTP == "red":
         E("s_setprio 0")
     mark(11)
-    E(f"""
-    L_xchg:
-    // displacement of move i+1 per row (rows 1..3 -> components 0, 8, 16 of displ[3 (i+1) ..]): asked for now, it
-    // travels during the exchange and the Metropolis step (DdV itself is still this move's)
+    E("L_xchg:")
+    # displacement of move i+1 per row (rows 1..3 -> components 0, 8, 16 of displ[3 (i+1) ..]): asked for now, it
+    # travels during the exchange and the Metropolis step (DdV itself is still this move's)
+    G(f"""
     s_cmp_eq_u32 {s('hasB')}, 0
     s_cbranch_scc1 L_nodd
+    """)
+    E(f"""
     s_add_u32 {st(1)}, {s('i')}, 1
     s_mul_i32 {st(1)}, {st(1)}, 24
     v_add_u32 {v('S6')}, {st(1)}, {KPROW}
@@ -2095,12 +2144,13 @@ if TT:
     v_mov_b32 v14, 0
     v_mov_b32 v15, 0
     """)
+    TG = " @G" if PEEL else ""
     xchg2(FnV, FnV, FbV, f"""
     ds_read_b64 v[16:17], v22 offset:{LDS_P0}
-    s_cmp_lg_u32 {s('hasA')}, 0
-    s_cselect_b64 exec, -1, 0
+    s_cmp_lg_u32 {s('hasA')}, 0{TG}
+    s_cselect_b64 exec, -1, 0{TG}
     ds_read_b64 v[14:15], v23 offset:{LDS_SIDE}
-    s_mov_b64 exec, -1
+    s_mov_b64 exec, -1{TG}
     """)
     # this move's dX = Fm A/T + displ (D2; harmless without a move to decide), then the displacement of move i+1 (asked
     # for before the exchange) takes DdV's place NOW, before the accepted move's stores: vmcnt counts loads and stores in
@@ -2167,20 +2217,20 @@ if TT:
     else:
         for q in Pl + Ml:
             E(q)
-    E(f"""
-    s_mov_b32 {s('accf')}, 0
+    E(f"s_mov_b32 {s('accf')}, 0")
+    G(f"""
     s_cmp_eq_u32 {s('hasA')}, 0
     s_cbranch_scc1 L_noA
-    v_cmp_lt_f64 vcc, {sp('lu')}, {vp('D',2)}
     """)
+    E(f"v_cmp_lt_f64 vcc, {sp('lu')}, {vp('D',2)}")
     mark(7)
     E(f"""
     s_bitcmp1_b32 vcc_hi, 31
     s_cbranch_scc0 L_reject
     """)
 else:
-    E(f"s_cmp_eq_u32 {s('hasA')}, 0")
-    E("s_cbranch_scc1 L_noA")
+    G(f"s_cmp_eq_u32 {s('hasA')}, 0")
+    G("s_cbranch_scc1 L_noA")
     probe("A", QP, True, (s('Q', 4), s('Q', 5)), V['wa0'], V['wa1'], XA_, CA_, sp('haveA'), False,
           ("" if (ZBC or Z8C) else "s_waitcnt vmcnt(4)") if ZB else "s_nop 0")
     reduce4(FnV)
@@ -2370,8 +2420,8 @@ L_noA:
 mark(8)
 
 # ---------------------------------------------------------------------------------------------- probe B
-E(f"s_cmp_eq_u32 {s('hasB')}, 0")
-E("s_cbranch_scc1 L_noB")
+G(f"s_cmp_eq_u32 {s('hasB')}, 0")
+G("s_cbranch_scc1 L_noB")
 if TT:
     # probe B was evaluated before the decision (team B) and the proposal of particle n+1 formed for both outcomes (above):
     # the half of every row that worked for the outcome that did NOT happen takes the other half's Fm (it is the next move's
@@ -2506,17 +2556,30 @@ E("L_noB:")
 mark(10)
 if ZB:
     E(f"s_mov_b32 {s('locA')}, {s('locB')}")
-E(f"""
-s_add_u32 {s('i')}, {s('i')}, 1
+E(f"s_add_u32 {s('i')}, {s('i')}, 1")
+G(f"""
 s_mov_b32 {s('hasA')}, 1
 {f"s_and_b32 {st(0)}, {WAVE}, {KS - 1}" if TT else ""}
 {f"s_cmp_eq_u32 {st(0) if TT else WAVE}, 0" if W4 else ""}
 {f"s_cselect_b32 {s('hasAw')}, 1, 0" if W4 else ""}
+""")
+E(f"""
 s_add_u32 {st(0)}, {s('i')}, 1
 s_cmp_lt_i32 {st(0)}, {s('len')}
-s_cselect_b32 {s('hasB')}, 1, 0
+""")
+G(f"s_cselect_b32 {s('hasB')}, 1, 0")
+# the next pass has a proposal to decide (hasA) and a next particle (hasB): the steady copy runs it
+E("s_cbranch_scc1 L_S_move" if PEEL else "")
+SO(f"""
+s_mov_b32 {s('hasB')}, 0
+s_branch L_G_move
+""")
+G(f"""
 s_cmp_lt_i32 {s('i')}, {s('len')}
 s_cbranch_scc1 L_move
+""")
+MOVE_END = len(out)
+E(f"""
 L_run_next:
 s_add_u32 {s('run')}, {s('run')}, 1
 s_cmp_lt_u32 {s('run')}, 2
@@ -2633,7 +2696,19 @@ s_mov_b64 exec, -1
 s_waitcnt vmcnt(0) lgkmcnt(0)
 """)
 
-if COLD_AT is not None:
+if PEEL:
+    # two copies of the move: [cold pieces + move] generic (all lines but the @S ones), and steady (all but the @G ones,
+    # the labels it defines renamed L_x -> L_S_x); the steady copy ends in unconditional branches and lies first
+    def variant(lines, drop, keep):
+        return [l[:-3] if l.endswith(keep) else l for l in lines if not l.endswith(drop)]
+    chunk = out[MOVE_AT:MOVE_END]
+    gen = variant(cold, " @S", " @G") + variant(chunk, " @S", " @G")
+    ste = variant(cold, " @G", " @S") + variant(chunk, " @G", " @S")
+    defined = {l[2:-1] for l in ste if re.fullmatch(r"L_\w+:", l)} - {"jb"}
+    ste = [re.sub(r"\bL_(\w+)", lambda m: ("L_S_" + m.group(1)) if m.group(1) in defined else m.group(0), l) for l in ste]
+    assert not any(l.endswith((" @G", " @S")) for l in out[:MOVE_AT] + out[MOVE_END:])
+    out[MOVE_AT:MOVE_END] = ste + gen
+elif COLD_AT is not None:
     out[COLD_AT:COLD_AT] = cold
 with open(sys.argv[1] if len(sys.argv) > 1 else "smcx_sweep_ma_body.inc", "w") as f:
     f.write("// generated by gen_sweep_ma.py -- do not edit\n")

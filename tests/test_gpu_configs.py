@@ -150,7 +150,7 @@ def test_config3_N4096_x4096_headline_launch_against_oracle(S, O):
     s = sys_of(O, p)
     refs = oracle_chains(O, s, [12345 + r for r in pick], R0, 0, nsw, 10)
     assert np.all(rel(ob["E_last"], Erec) < 1e-9)        # every replica: incremental energy = recomputed energy
-    assert len(np.unique(ob["accepted"])) > nrep // 4
+    assert len(np.unique(ob["E_last"])) > nrep // 2      # distinct seeds, distinct chains
     for k, (r, ref) in enumerate(zip(pick, refs)):
         assert int(ob["accepted"][r]) == ref["accepted"], r
         assert rel(ob["E_last"][r], ref["Efinal"]) < 1e-9, r
