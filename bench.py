@@ -52,6 +52,19 @@ def issue_roofline(kname, sweep_ms_per_sweep, nrep, N, clock_ghz, start=None):
     if kc["workload"]["replicas"] != nrep or kc["workload"]["N"] != N or \
             (start is not None and kc["workload"].get("start") != start):
         return None                                                  # counters are of another workload / start state
+    # ... or of another BUILD of the kernel: the counts carry the source identity of the library they were taken from
+    # (sha256 of the generated body / the source files, smcx_kernel_source_id); a kernel edited since has another one
+    try:
+        import smcx_loader
+        built = smcx_loader.load().kernel_source_id(kname)
+    except Exception:
+        built = None
+    if not built or kc.get("source_id") != built:
+        return {"bound": "valu_issue", "achieved": None, "peak": N_SIMD * clock_ghz, "unit": "G SIMD-cycles/s of VALU issue",
+                "frac": None, "clock_ghz": clock_ghz,
+                "note": "the committed PMC instruction counts (profiles/kernel_counters.json, source_id %s) are of another "
+                        "build of %s than the loaded library (source_id %s): re-profile with tools/profile_configs.sh"
+                        % (kc.get("source_id"), kname, built)}
     m = kc["per_wave_move"]
     f64 = m.get("SQ_INSTS_VALU_ADD_F64", 0) + m.get("SQ_INSTS_VALU_MUL_F64", 0) + m.get("SQ_INSTS_VALU_FMA_F64", 0)
     tr = m.get("SQ_INSTS_VALU_TRANS_F64", 0)
@@ -111,7 +124,7 @@ with K.Engine(p) as eng:
     f.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
     assert f(eng._h, cnt) == 0
 print(json.dumps({"name": name, "inside": int(cnt[0]), "cand": int(cnt[1]), "miss": int(cnt[2]), "groups": int(cnt[3]),
-                  "passes": int(cnt[4])}))
+                  "passes": int(cnt[4]), "more_rounds": int(cnt[5]), "fold": int(cnt[6])}))
 """
 
 
@@ -141,6 +154,10 @@ def executed_work(kname, N, lattice, slots, waves, device, nrep=64, sweeps=2):
             "fraction_of_all_pairs_screened": d["groups"] * 256.0 / moves / (2.0 * (N - 1)),
             "candidate_bits_per_probe": d["cand"] / (2.0 * moves), "pairs_inside_cutoff_per_probe": d["inside"] / (2.0 * moves),
             "pairs_inside_cutoff_missed": d["miss"],
+            # rounds of the fp64 body beyond the first, per probe (a lane held two candidates of one probe)
+            "further_rounds_per_probe": d.get("more_rounds", 0) / (2.0 * moves),
+            # design statistic: probes in which some lanes l and l + 32 both held a candidate (per probe evaluated)
+            "probes_with_candidates_32_lanes_apart": d.get("fold", 0) / (2.0 * moves),
             "source": "libsmcx_check.so (diagnostic build of the same sources, SMCX_CHECK_MB=2), %d replicas x %d sweeps "
                       "of the same start, after the timed region" % (nrep, sweeps)}
 
@@ -360,9 +377,16 @@ def main():
     gather_ms = (time.perf_counter() - tg) * 1e3
     summ = D.summarise(obs, N, a.steps)
 
-    tmax = torch.tensor([dt], dtype=torch.float64,
-                        device=("cuda:%d" % local_rank) if backend == "nccl" else "cpu")
+    tdev = ("cuda:%d" % local_rank) if backend == "nccl" else "cpu"
+    tmax = torch.tensor([dt], dtype=torch.float64, device=tdev)
+    per_rank = None
     if world > 1:
+        # every rank's own numbers, for the record (a straggler or a slow gather must be visible in SCALE_r*.json): its wall
+        # time over the K steps, the device time of its sweep kernels and of its whole run, its side of the gather
+        mine = torch.tensor([dt * 1e3 / a.steps, sweep_ms / a.steps, run_ms / a.steps, gather_ms], dtype=torch.float64, device=tdev)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = np.array([t.cpu().numpy() for t in allr])
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
 
@@ -402,6 +426,16 @@ def main():
             "observables": {"mean_acceptance": summ["mean_acceptance"], "mean_energy": summ["mean_of_meanE"],
                             "replicas_gathered": int(len(obs["accepted"]))},
         }
+        if per_rank is not None:
+            def stats(col):
+                v = per_rank[:, col]
+                return {"min": float(v.min()), "median": float(np.median(v)), "max": float(v.max()),
+                        "ranks": [float(x) for x in v]}
+            out["per_rank"] = {"ms_per_step": stats(0), "sweep_kernel_ms_per_step": stats(1), "device_ms_per_step": stats(2),
+                               "gather_ms": stats(3),
+                               "note": "ms_per_step = each rank's own wall time over the K steps between the two barriers (the "
+                                       "headline uses the MAX); gather_ms = its side of the one all-gather of observables"}
+        out["gather_ms"] = gather_ms
         rl = issue_roofline(kname, sweep_ms / a.steps, nrep, N, clock_ghz, start="fcc(%d,%d)" % tuple(lattice))
         base = {"kernel": kname, "launches": launches, "avg_launch_ms": sweep_ms / max(launches, 1),
                 # what `rocprofv3 --stats` averages over: the warm-up launches as well

@@ -224,6 +224,12 @@ int smcx_geometry(const smcx_handle *h, int *slots, int *waves_per_replica, int 
  * candidates: sweep_kernel_mi with one wavefront per replica, sweep_kernel_mx with several); name,
  * if not NULL, receives the kernel's name (at most len bytes) */
 int smcx_kernel_form(const smcx_handle *h, int *form, char *name, int len);
+/* source identity of a sweep kernel of THIS library (host only, no GPU needed): 16 hex digits, the sha256 of the generated
+ * body (hand-scheduled kernels) or of the source files (compiled ones) it was built from.  kernel = a name as
+ * smcx_kernel_form returns it.  Measurement plumbing: profiles/kernel_counters.json records the id of the library whose
+ * instruction counts it holds, and bench.py reports no roofline fraction from counts of another build.
+ * SMCX_ERR_PARAM for a name this library does not know. */
+int smcx_kernel_source_id(const char *kernel, char *id, int len);
 /* the numbers of the screened kernel's conservative cutoff test for a box (host only, no GPU needed):
  * thr = cutoff^2 + margin (fp32), u2 = (L/65536)^2, to_fixed = 65536/L, zsafe = |z| up to which the
  * margin holds; lds_z selects the variant with z as fp16.  tests/test_cabi_host.py checks on the CPU,

@@ -61,7 +61,7 @@ EXPORTS = [
     "smcx_rng_seed", "smcx_one_particle_moves",
     "smcx_cluster_counts", "smcx_cluster_update", "smcx_cluster_analysis", "smcx_kernel_form", "smcx_screen_bound",
     "smcx_screen_bound_int", "smcx_screen_bound_byte", "smcx_last_clock", "smcx_debug_wave_spread",
-    "smcx_debug_clk_rows",
+    "smcx_debug_clk_rows", "smcx_kernel_source_id",
 ]
 HOST_EXPORTS = ["smcx_host_sMC", "smcx_host_sMC_multi", "smcx_host_multi_error", "smcx_host_sim_free", "smcx_host_fcc_init",
                 "smcx_host_initialize_box", "smcx_host_initialize_walls", "smcx_host_box_for_N", "smcx_host_write_csv",
@@ -135,6 +135,15 @@ def default_params(N, nrep, **kw):
     for k, v in kw.items():
         setattr(p, k, v)
     return p
+
+
+def kernel_source_id(kernel):
+    """source identity (16 hex digits) of a sweep kernel of the loaded library (smcx_kernel_source_id); None if unknown"""
+    buf = C.create_string_buffer(32)
+    f = _lib().smcx_kernel_source_id
+    f.argtypes = [C.c_char_p, C.c_char_p, C.c_int]
+    f.restype = C.c_int
+    return buf.value.decode() if f(kernel.encode(), buf, 32) == OK else None
 
 
 def device_count():

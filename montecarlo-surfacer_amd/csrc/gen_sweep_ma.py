@@ -65,11 +65,19 @@ import sys
 out = []
 
 
+MUTE = [False]     # while set, nothing is emitted (the sections a variant replaces are skipped without re-indenting them)
+
+
+REDIR = [None]     # while set to a list, E() appends there (whole sections emitted among the cold pieces)
+
+
 def E(txt="", tag=""):
+    if MUTE[0]:
+        return
     for ln in txt.strip("\n").split("\n"):
         ln = ln.strip()
         if ln and not ln.startswith("//"):
-            out.append(ln + tag)
+            (out if REDIR[0] is None else REDIR[0]).append(ln + tag)
 
 
 def GW(txt):
@@ -130,6 +138,14 @@ NG = NS // 4                                              # 4-slot groups
 # first pass of a run, which only evaluates the first particle) and hasB (a next particle: not in the last pass), and a
 # STEADY copy for every other pass without those eight test-and-branch pairs (16 scalar instructions of ~180 per move).
 PEEL = ZB and os.environ.get("SMCX_GEN_NOPEEL") != "1"
+# "MG": both probes of a move in ONE pass of the fp64 body (z8 with one wavefront per replica).  After the two screens every
+# lane with a candidate hands its lowest one over to a WORKING lane through a list in LDS: lanes 0..31 work for probe A (the
+# proposal of particle n), lanes 32..63 for probe B (the current position of particle n+1) -- first the plane / wall sites
+# (and, in B's half, the pair (n, n+1) for BOTH outcomes of the move on two lanes, kept out of the sums as in the two-team
+# kernels), then the candidates in the order of their owner lanes.  One body, ONE reduction (4 accumulators x 2 halves -> 8
+# sums in 8-lane groups: e | fy in row 0, fx | fz in row 1 of each half), Metropolis and proposal in that "group layout".
+# Per move ~130 instructions fewer than two probes one after the other (of ~540).
+MG = Z8 and not W4 and os.environ.get("SMCX_GEN_MERGE") == "1"
 # z8t with 16 cells per lane ("LP"): the fp64 positions of all cells (24 KB, what candidates are fetched from) and the
 # wall table live in LDS at offset 0, shared by the two wavefronts of the replica; every other LDS area moves up
 PF2 = TT and NS >= 32     # z8t with many cells: the first TWO candidates of a lane are fetched together (dense states: the
@@ -146,6 +162,7 @@ LDS_SIDE = LDS_X + 2 * WPR * 512                          # z8t: [2 buffers][old
 if W4:
     LDS_CNT = LDS_X + 2 * WPR * 512 + (128 if TT else 0)  # z8wc: 8 counter words per wave behind the exchange area
 LDS_TM = LDS_SIDE + 128                                   # z8t stamps variant: per wave {t0, cycles before the barrier, cycles at it}
+LDS_LIST, LDS_SIDEM = 2048, 2304                          # mg: hand-over list [64] words; side results [old, new][e, fx, fy, fz]
 LANE, KARG, REP, WAVE = "%0", "%1", "%2", "%3"
 # z8t: the slab of a wave is wave mod K (team B = waves K .. 2K-1), formed with s_and_b32 in a scratch register where
 # it is needed (the inline-asm statement has no SGPR operand to spare); otherwise slab = wave
@@ -199,6 +216,12 @@ if W4:
 
 if Z8 and not W4:
     S.update(RZ=S['azz'])     # the reach of a group's z range in z units: azz is not used by the one-word screen
+if MG:
+    # wlp = (plane lanes of half A, of half B) = (hasA & walls, hasB & walls): bit 0 of either word -- the planes work on
+    # lanes 0 and 32; stB = first candidate lane of half B (behind its plane and the two side lanes); sidesHi = the side
+    # lanes' bits in the high word; nearA / nearB: the probe is within the cutoff of a wall (its sites join in: cold path);
+    # a0s, b0s: the plane's coefficients; hA, hB: scratch pairs; accf: this move was accepted
+    S.update(hA=78, a0s=80, b0s=82, hB=84, znear=86, wlp=48, stB=57, sidesHi=58, nearA=60, nearB=62, accf=64)
 if TT:
     # team B's waves never use probe A's masks: haveA's low word holds the lane of the side pair evaluated with the
     # PROPOSAL (sideL: with n's current position); its high word carries the accept flag from the Metropolis step to
@@ -222,6 +245,7 @@ ONE_HI = "0x3ff00000"
 K_R, K_DISPL, K_UNI, K_OFFS, K_OBS, K_REC, K_WTAB, K_CLK = 0x0, 0x8, 0x10, 0x18, 0x20, 0x28, 0x30, 0x38
 K_CONST16, K_CONST8, K_INTS, K_M2 = 0x40, 0x80, 0xa0, 0xb0
 K_RZ, K_RS, K_LOC, K_SW0, K_DBG, K_PRIO = 0xb4, 0xb8, 0xc0, 0xc8, 0xd0, 0xd8   # zb
+K_ZNEAR = 0xe0                                                                 # mg: |z| from which a wall's sites are in reach
 
 # ---------------------------------------------------------------------------------------------- prologue
 E(f"""
@@ -387,8 +411,42 @@ if not ZB:
     s_mov_b32 {s('sideM')}, 0x40000000
     s_mov_b32 {s('sideM',1)}, 0
     """)
+# per-lane constant of the row layout: 8 (row - 1) for rows 1..3 (components x, y, z), 0 for row 0 -- where a register is
+# free for it (z8 with one wavefront: v1, which holds the z words' address in the other forms; two teams: KPROW)
+KROW = "v1" if (Z8 and not W4 and not MG) else None
+KC, KL4, KSD = "v1", "v10", "v11"    # mg: per-lane constants of the group layout (below)
+if MG:
+    # group layout: in either half, row 0 = [e | fy], row 1 = [fx | fz] in 8-lane groups.  KC = byte offset of the lane's
+    # component in a position / displacement triple (x 0, y 8, z 16; the e group idles along with x); KSD = 8 x index of its
+    # sum in a side result (e, fx, fy, fz); KL4 = 4 lane.  The plane's coefficients and the near-wall bound in SGPRs.
+    E(f"""
+    s_load_dwordx2 {sp('znear')}, {KARG}, {K_ZNEAR}
+    s_mov_b64 {sp('a0s')}, 0
+    s_mov_b64 {sp('b0s')}, 0
+    s_cmp_lt_i32 {s('M2')}, 0
+    s_cbranch_scc1 L_nopl
+    s_lshl_b32 {st(0)}, {s('M2')}, 5
+    s_add_u32 {st(0)}, {st(0)}, 16
+    s_load_dwordx4 s[{S['a0s']}:{S['a0s'] + 3}], {sp('wtab')}, {st(0)}
+    L_nopl:
+    v_bfe_u32 v14, {LANE}, 3, 1
+    v_bfe_u32 v15, {LANE}, 4, 1
+    v_lshlrev_b32 v16, 3, v14
+    v_lshlrev_b32 {KC}, v15, v16
+    v_lshl_add_u32 v16, v14, 1, v15
+    v_lshlrev_b32 {KSD}, 3, v16
+    v_lshlrev_b32 {KL4}, 2, {LANE}
+    s_waitcnt lgkmcnt(0)
+    """)
+if KROW:
+    E(f"""
+    v_lshrrev_b32 {KROW}, 4, {LANE}
+    v_add_u32 {KROW}, -1, {KROW}
+    v_max_i32 {KROW}, 0, {KROW}
+    v_lshlrev_b32 {KROW}, 3, {KROW}
+    """)
 E(f"""
-{"" if W4 else f"v_lshlrev_b32 {v('zaddr')}, 2, {LANE}"}
+{"" if (W4 or KROW) else f"v_lshlrev_b32 {v('zaddr')}, 2, {LANE}"}
 v_mov_b32 {v('uns0')}, 0
 v_mov_b32 {v('uns1')}, 0
 s_mov_b32 {s('rot')}, 0
@@ -656,11 +714,19 @@ def compact_row(xyd, zld, locv):
     v_lshl_or_b32 v28, v29, 16, v28
     v_lshl_or_b32 {zld}, {locv}, 17, v28
     """)
+    if MG:   # bit 29: within the cutoff of a wall (or beyond it)
+        E(f"""
+        v_cmp_nlt_f64 vcc, |v[20:21]|, {sp('znear')}
+        v_cndmask_b32 v29, 0, 1, vcc
+        v_lshl_or_b32 {zld}, v29, 29, {zld}
+        """)
 
 
 def fill_p0(tag):
     """p0[lane] = fp64 position of particle rot*64 + lane (this lane's slot-0 particle), p0[64] = particle
-    rot*64 + 64 (lane 0's slot-1 particle); zb: also their compact copies and cells (rxy, rzl; nxy, nzl)"""
+    rot*64 + 64 (lane 0's slot-1 particle); zb: also the compact copies and cells of the NEXT particles: lane l of rxy, rzl <-
+    particle rot*64 + l + 1 (probe B of the move of particle rot*64 + l is one v_readlane at lane tl, also when the order
+    crosses into the next row), and where a run starts (tag r1) nxy, nzl <- those of the run's first particle"""
     E(f"""
     s_lshl_b32 {st(0)}, {s('rot')}, 6
     v_or_b32 v14, {st(0)}, {LANE}
@@ -682,14 +748,11 @@ def fill_p0(tag):
     s_and_saveexec_b64 {stp(2)}, vcc
     global_load_dwordx4 v[16:19], v15, {sp('Rg')}{NT}
     global_load_dwordx2 v[20:21], v15, {sp('Rg')} offset:16{NT}
-    {f"global_load_ushort v24, v23, {stp(4)}" if ZB else ""}
     s_waitcnt vmcnt(0)
     ds_write_b64 v22, v[16:17] offset:{LDS_P0}
     ds_write_b64 v22, v[18:19] offset:{LDS_P0 + 8}
     ds_write_b64 v22, v[20:21] offset:{LDS_P0 + 16}
     """)
-    if ZB:
-        compact_row(v('rxy'), v('rzl'), "v24")
     E(f"""
     s_mov_b64 exec, 1
     s_add_u32 {st(0)}, {st(0)}, 64
@@ -697,30 +760,53 @@ def fill_p0(tag):
     s_cbranch_scc0 L_p0done_{tag}
     s_mul_i32 {st(1)}, {st(0)}, 24
     v_mov_b32 v15, {st(1)}
-    {f"s_lshl_b32 {st(1)}, {st(0)}, 1" if ZB else ""}
-    {f"v_mov_b32 v23, {st(1)}" if ZB else ""}
     s_nop 1
     global_load_dwordx4 v[16:19], v15, {sp('Rg')}{NT}
     global_load_dwordx2 v[20:21], v15, {sp('Rg')} offset:16{NT}
-    {f"global_load_ushort v24, v23, {stp(4)}" if ZB else ""}
-    {f"v_add_u32 v22, {LDS_P0 + 64 * 24}, v1" if W4 else f"v_mov_b32 v22, {LDS_P0 + 64 * 24}"}
+    {f"v_add_u32 v25, {LDS_P0 + 64 * 24}, v1" if W4 else f"v_mov_b32 v25, {LDS_P0 + 64 * 24}"}
     s_waitcnt vmcnt(0)
-    ds_write_b64 v22, v[16:17]
-    ds_write_b64 v22, v[18:19] offset:8
-    ds_write_b64 v22, v[20:21] offset:16
-    """)
-    if ZB:
-        compact_row("v30", "v31", "v24")
-        E(f"""
-        s_nop 0
-        v_readfirstlane_b32 {s('nxy')}, v30
-        v_readfirstlane_b32 {s('nzl')}, v31
-        """)
-    E(f"""
+    ds_write_b64 v25, v[16:17]
+    ds_write_b64 v25, v[18:19] offset:8
+    ds_write_b64 v25, v[20:21] offset:16
     L_p0done_{tag}:
     s_mov_b64 exec, -1
     s_waitcnt lgkmcnt(0)
     """)
+    if ZB:
+        # the row registers: lane l <- particle rot*64 + l + 1 (fp64 position = p0[l + 1], just written; cell from loc[])
+        E(f"""
+        v_add_u32 v14, 1, v14
+        v_cmp_gt_u32 vcc, {s('N')}, v14
+        s_and_saveexec_b64 {stp(2)}, vcc
+        global_load_ushort v24, v23, {stp(4)} offset:2
+        ds_read_b64 v[16:17], v22 offset:{LDS_P0 + 24}
+        ds_read_b64 v[18:19], v22 offset:{LDS_P0 + 32}
+        ds_read_b64 v[20:21], v22 offset:{LDS_P0 + 40}
+        s_waitcnt vmcnt(0) lgkmcnt(0)
+        """)
+        compact_row(v('rxy'), v('rzl'), "v24")
+        if tag == "r1":   # a run starts: its first particle is probe B of the pass that has no proposal to decide
+            E(f"""
+            s_mov_b64 exec, 1
+            s_and_b32 {st(0)}, {s('first')}, 63
+            s_mul_i32 {st(0)}, {st(0)}, 24
+            {f"v_add_u32 v25, {st(0)}, v1" if W4 else f"v_mov_b32 v25, {st(0)}"}
+            s_lshl_b32 {st(1)}, {s('first')}, 1
+            v_mov_b32 v23, {st(1)}
+            s_nop 0
+            global_load_ushort v24, v23, {stp(4)}
+            ds_read_b64 v[16:17], v25 offset:{LDS_P0}
+            ds_read_b64 v[18:19], v25 offset:{LDS_P0 + 8}
+            ds_read_b64 v[20:21], v25 offset:{LDS_P0 + 16}
+            s_waitcnt vmcnt(0) lgkmcnt(0)
+            """)
+            compact_row("v30", "v31", "v24")
+            E(f"""
+            s_nop 0
+            v_readfirstlane_b32 {s('nxy')}, v30
+            v_readfirstlane_b32 {s('nzl')}, v31
+            """)
+        E("s_mov_b64 exec, -1")
     if PRIO:
         # The SIMD's arbiter favours the oldest of its four wavefronts: left alone, one replica runs at nearly the
         # lone-wave rate and finishes after 7 ms while the youngest needs 13 and runs the last third of its sweep
@@ -974,6 +1060,15 @@ v_mov_b32 {v('FmV',1)}, 0
 v_mov_b32 {v('DdV')}, 0
 v_mov_b32 {v('DdV',1)}, 0
 """)
+if MG:   # the first pass of a run has no proposal: no plane for half A, no side pair
+    E(f"""
+    s_mov_b32 {s('nearA')}, 0
+    s_mov_b32 {s('wlp')}, 0
+    s_cmp_ge_i32 {s('M2')}, 0
+    s_cselect_b32 {s('wlp',1)}, 1, 0
+    s_mov_b32 {s('stB')}, {s('wlp',1)}
+    s_mov_b32 {s('sidesHi')}, 0
+    """)
 # rarely executed pieces of the move (zb) are gathered here, jumped over when a run starts
 COLD_AT = None
 if ZB:
@@ -994,6 +1089,8 @@ cold = []
 
 
 def COLD(txt):
+    if MUTE[0]:
+        return
     for ln in txt.strip("\n").split("\n"):
         ln = ln.strip()
         if ln and not ln.startswith("//"):
@@ -1043,19 +1140,24 @@ else:
   s_cmp_eq_u32 {s('hasB')}, 0
   s_cbranch_scc1 L_nob0
   """)
-  E(f"""
-  s_add_u32 {s('lb')}, {s('tl')}, 1
-  s_cmp_eq_u32 {s('tl')}, 63
-  s_cselect_b32 {s('lb')}, 0, {s('lb')}
-  s_cselect_b32 {s('cross')}, 1, 0
+  # the first pass of a run (no proposal yet) takes the run's first particle from nxy, nzl
+  G(f"""
+  s_cmp_eq_u32 {s('hasA')}, 0
+  s_cbranch_scc1 L_bfirst
+  """)
+  COLD(f"""
+  L_bfirst:
   s_mov_b32 {s('bxys')}, {s('nxy')}
   s_mov_b32 {st(1)}, {s('nzl')}
-  s_cbranch_scc1 L_bjoin
-  v_readlane_b32 {s('bxys')}, {v('rxy')}, {s('lb')}
-  v_readlane_b32 {st(1)}, {v('rzl')}, {s('lb')}
+  s_branch L_bjoin
+  """)
+  E(f"""
+  v_readlane_b32 {s('bxys')}, {v('rxy')}, {s('tl')}
+  v_readlane_b32 {st(1)}, {v('rzl')}, {s('tl')}
   L_bjoin:
   s_bfe_u32 {s('ub')}, {st(1)}, 0x10010
-  s_lshr_b32 {s('locB')}, {st(1)}, 17
+  {f"s_bfe_u32 {s('nearB')}, {st(1)}, 0x1001d" if MG else ""}
+  {f"s_bfe_u32 {s('locB')}, {st(1)}, 0xc0011" if MG else f"s_lshr_b32 {s('locB')}, {st(1)}, 17"}
   {"" if Z8 else f"s_and_b32 {st(1)}, {st(1)}, 0xffff"}
   {"" if Z8 else f"s_mul_i32 {s('bzz')}, {st(1)}, 0x10001"}
   L_nob1:
@@ -1064,8 +1166,7 @@ else:
   L_nob0:
   {"" if Z8 else f"s_mov_b32 {s('bzz')}, 0"}
   s_mov_b32 {s('ub')}, 0
-  s_mov_b32 {s('cross')}, 0
-  s_mov_b32 {s('lb')}, 0
+  {f"s_mov_b32 {s('nearB')}, 0" if MG else ""}
   s_mov_b32 {s('bxys')}, 0
   s_mov_b32 {s('locB')}, 0
   s_branch L_nob1
@@ -1286,8 +1387,7 @@ def z8c_check(tag, P_sgpr, w0, w1, locs, guard):
             E(f"v_mov_b32 v{20 + j}, {s('Q', j)}")
     else:
         E(f"""
-        s_cmp_eq_u32 {s('cross')}, 1
-        s_cselect_b32 {st(0)}, 64, {s('lb')}
+        s_add_u32 {st(0)}, {s('tl')}, 1
         s_mul_i32 {st(0)}, {st(0)}, 24
         {f"v_add_u32 v36, {st(0)}, v1" if W4 else f"v_mov_b32 v36, {st(0)}"}
         ds_read_b64 v[20:21], v36 offset:{LDS_P0}
@@ -1380,14 +1480,13 @@ def excl(w0, w1, loc):
         s_cmp_lg_u32 {st(1)}, {st(2) if TT else WAVE}
         s_cbranch_scc1 L_excl{NEXCL[0]}
         """)
+    # lane loc & 63 clears bit (slot) of its flag words: d = (mask & 0) | (~mask & w)
     E(f"""
     {f"s_bfe_u32 {st(1)}, {loc}, {SLOTF}" if W4 else f"s_lshr_b32 {st(1)}, {loc}, 6"}
-    s_lshl_b64 {stp(2)}, 1, {loc}
-    s_lshl_b64 {stp(4)}, 1, {st(1)}
-    s_not_b64 {stp(4)}, {stp(4)}
-    s_mov_b64 exec, {stp(2)}
-    v_and_b32 {w0}, {st(4)}, {w0}
-    v_and_b32 {w1}, {st(5)}, {w1}
+    s_lshl_b64 exec, 1, {loc}
+    s_bfm_b64 {stp(4)}, 1, {st(1)}
+    v_bfi_b32 {w0}, {st(4)}, 0, {w0}
+    v_bfi_b32 {w1}, {st(5)}, 0, {w1}
     s_mov_b64 exec, -1
     """)
     if W4:
@@ -1737,6 +1836,14 @@ def probe(tag, P, pz_sgpr, pz, w0, w1, X, C, have, side, wait, wl=None, pl=None)
     {"s_cbranch_vccz L_done_" + tag if ZB else "s_cmp_lg_u64 vcc, 0"}
     {"" if ZB else "s_cbranch_scc0 L_done_" + tag}
     """)
+    if Z8C:   # executed work: rounds beyond the first of a probe (a lane held two candidates)
+        cnt_addr("v46")
+        E(f"""
+        v_mov_b32 v44, 1
+        s_mov_b64 exec, 1
+        ds_add_u32 v46, v44 offset:{LDS_CNT + 20}
+        s_mov_b64 exec, -1
+        """)
     coeff_one(C)
     pick_fetch(w0, w1, X, "0", stp(6))
     E("s_waitcnt lgkmcnt(0)" if LP else "s_waitcnt vmcnt(0)")
@@ -1762,8 +1869,20 @@ def assign_specials(tag, w0, w1, X, C, wl, pl, with_side, have):
     all-flagged words of an unsafe probe are cut to the real cells where they are made."""
     wlo, whi = (int(x) for x in wl[2:-1].split(":"))
     need = st(6) if with_side else st(3)
+    E(f"v_cmp_ne_u64 {have}, 0, v[{w0}:{w1}]")
+    if Z8C:   # statistics for a design question: would folding the lanes l and l + 32 onto one make a candidate wait?
+        hlo, hhi = (int(x) for x in have[2:-1].split(":"))
+        cnt_addr("v16")
+        E(f"""
+        s_and_b32 {st(0)}, s{hlo}, s{hhi}
+        s_cmp_lg_u32 {st(0)}, 0
+        s_cselect_b32 {st(0)}, 1, 0
+        v_mov_b32 v14, {st(0)}
+        s_mov_b64 exec, 1
+        ds_add_u32 v16, v14 offset:{LDS_CNT + 24}
+        s_mov_b64 exec, -1
+        """)
     E(f"""
-    v_cmp_ne_u64 {have}, 0, v[{w0}:{w1}]
     s_add_u32 {st(3)}, {s_M2w()}, 1
     s_not_b64 {stp(0)}, {have}
     s_bcnt1_i32_b64 {st(2)}, {stp(0)}
@@ -1866,9 +1985,9 @@ def assign_specials(tag, w0, w1, X, C, wl, pl, with_side, have):
     """)
 
 
-def all_real_cells(w0, w1):
-    """zb, unsafe probe: every REAL cell of this lane is a candidate (cell = slot * 64 + lane < N)"""
-    E(f"""
+def all_real_cells(w0, w1, back):
+    """zb, unsafe probe (cold piece, returns to `back`): every REAL cell of this lane is a candidate (cell = slot * 64 + lane < N)"""
+    COLD(f"""
     v_sub_u32 v14, {s_Nw()}, {LANE}
     v_add_u32 v14, 63, v14
     v_ashrrev_i32 v14, 6, v14
@@ -1880,6 +1999,7 @@ def all_real_cells(w0, w1):
     v_cmp_lt_u32 vcc, 63, v14
     v_cndmask_b32 {w0}, v16, -1, vcc
     v_cndmask_b32 {w1}, v17, -1, vcc
+    s_branch {back}
     """)
 
 
@@ -1907,14 +2027,22 @@ v_or_b32 {v('wa1')}, {v('wa1')}, {v('uns1')}
 """)
 G(f"""
 s_cmp_eq_u32 {s('hasA')}, 0
-s_cbranch_scc1 L_nofa
+s_cbranch_scc1 {"L_nofaC" if MG else "L_nofa"}
 """)
+if MG:
+    COLD(f"""
+    L_nofaC:
+    v_mov_b32 {v('wa0')}, 0
+    v_mov_b32 {v('wa1')}, 0
+    s_branch L_nofa
+    """)
 E(f"""
-s_cmp_eq_u32 {s('ua')}, 0
-s_cbranch_scc1 L_ua0
+s_cmp_{"lg" if ZB else "eq"}_u32 {s('ua')}, 0
+s_cbranch_scc1 {"L_uaC" if ZB else "L_ua0"}
 """)
 if ZB:
-    all_real_cells(v('wa0'), v('wa1'))
+    COLD("L_uaC:")
+    all_real_cells(v('wa0'), v('wa1'), "L_ua0")
 else:
     E(f"v_mov_b32 {v('wa0')}, {'-1' if NS >= 32 else '0xffff'}")
     E(f"v_mov_b32 {v('wa1')}, {'-1' if NS == 64 else '0'}")
@@ -1933,7 +2061,9 @@ else:
     """)
 if Z8C:
     z8c_check("A", True, v('wa0'), v('wa1'), [(s('locA'), "1")], s('hasA'))
-if ZB:
+if MG:
+    pass
+elif ZB:
     assign_specials("A", V['wa0'], V['wa1'], XA_, CA_, sp('wallM'), sp('planeM'), False, sp('haveA'))
 else:
     pick_fetch(V['wa0'], V['wa1'], XA_, sp('wallM'), sp('haveA'))
@@ -1961,8 +2091,15 @@ v_or_b32 {v('wb1')}, {v('wb1')}, {v('uns1')}
 """)
 G(f"""
 s_cmp_eq_u32 {s('hasB')}, 0
-s_cbranch_scc1 L_nofb0
+s_cbranch_scc1 {"L_nofbC" if MG else "L_nofb0"}
 """)
+if MG:
+    COLD(f"""
+    L_nofbC:
+    v_mov_b32 {v('wb0')}, 0
+    v_mov_b32 {v('wb1')}, 0
+    s_branch L_nofb
+    """)
 if not Z8:
     E(f"""
     // log-uniform of move i+1 (scalar load: only now that no screen pass is running on the LDS counter)
@@ -1971,11 +2108,12 @@ if not Z8:
     s_load_dwordx2 {sp('nlu')}, {sp('uK')}, {st(0)}
     """)
 E(f"""
-s_cmp_eq_u32 {s('ub')}, 0
-s_cbranch_scc1 L_ub0
+s_cmp_{"lg" if ZB else "eq"}_u32 {s('ub')}, 0
+s_cbranch_scc1 {"L_ubC" if ZB else "L_ub0"}
 """)
 if ZB:
-    all_real_cells(v('wb0'), v('wb1'))
+    COLD("L_ubC:")
+    all_real_cells(v('wb0'), v('wb1'), "L_ub0")
 else:
     E(f"v_mov_b32 {v('wb0')}, {'-1' if NS >= 32 else '0xffff'}")
     E(f"v_mov_b32 {v('wb1')}, {'-1' if NS == 64 else '0'}")
@@ -2024,11 +2162,14 @@ else:
     """)
 if Z8C:
     z8c_check("B", False, v('wb0'), v('wb1'), [(s('locB'), "1"), (s('locA'), s('hasA'))], s('hasB'))
-if ZB:
+if MG:
+    pass
+elif ZB:
     assign_specials("B", V['wb0'], V['wb1'], XB_, CB_, sp('wallB'), sp('planeB'), True, sp('haveB'))
 else:
     pick_fetch(V['wb0'], V['wb1'], XB_, stp(0), sp('haveB'))
     wall_fetch(XB_, CB_)
+MUTE[0] = MG
 E(f"""
 // probe B's fp64 position from the LDS cache: row = cross ? 64 : tl + 1 (= tl + 1 either way)
 s_add_u32 {st(0)}, {s('tl')}, 1
@@ -2042,6 +2183,391 @@ L_nofb0:
 s_waitcnt vmcnt(0)
 L_nofb:
 """)
+MUTE[0] = False
+if MG:
+    E("L_nofb:")
+# ---------------------------------------------------------------------------------------------- mg: both probes in one pass
+PV = ["v[14:15]", "v[16:17]", "v[18:19]"]      # mg: the probe of this lane's half (A: the proposal Q, B: particle n+1)
+MGW = "v[20:21]"                               # mg: probe B's sums (without the side pair), in both halves
+DdNm = "v[12:13]"                              # mg: displacement of move i+1 in group layout, asked for during the pass
+
+
+def mg_handover(w0, w1, h, start, off, n):
+    """every lane with a candidate in (w0, w1) hands its lowest one over: working lane = start + its rank among those lanes
+    (of this probe's half; only below 32), through list[off / 4 + lane]; h (s pair) <- the lanes that did, n (s) <- how many"""
+    hlo, hhi = (int(x) for x in h[2:-1].split(":"))
+    E(f"""
+    v_cmp_ne_u64 {h}, 0, v[{w0}:{w1}]
+    v_ffbl_b32 v46, v{w0}
+    v_ffbl_b32 v47, v{w1}
+    v_mov_b32 v45, {start}
+    v_mbcnt_lo_u32_b32 v45, s{hlo}, v45
+    v_mbcnt_hi_u32_b32 v45, s{hhi}, v45
+    v_or_b32 v47, 32, v47
+    v_cmp_gt_u32 vcc, 32, v45
+    v_min_u32 v46, v46, v47
+    v_lshl_add_u64 v[48:49], v[{w0}:{w1}], 0, -1
+    s_and_b64 {h}, {h}, vcc
+    v_lshl_or_b32 v46, v46, 6, {LANE}
+    s_bcnt1_i32_b64 {n}, {h}
+    v_lshlrev_b32 v45, 2, v45
+    s_mov_b64 exec, {h}
+    v_and_b32 v{w0}, v{w0}, v48
+    v_and_b32 v{w1}, v{w1}, v49
+    ds_write_b32 v45, v46 offset:{LDS_LIST + off}
+    s_mov_b64 exec, -1
+    """)
+
+
+def mg_probes():
+    """the probes of the two halves: lanes 0..31 <- Q (the proposal, s), lanes 32..63 <- p0[tl + 1] (particle n+1)"""
+    E(f"""
+    s_add_u32 {st(7)}, {s('tl')}, 1
+    s_mul_i32 {st(7)}, {st(7)}, 24
+    v_mov_b32 v44, {st(7)}
+    v_mov_b64 {PV[0]}, {sp('Q',0)}
+    v_mov_b64 {PV[1]}, {sp('Q',1)}
+    v_mov_b64 {PV[2]}, {sp('Q',2)}
+    s_mov_b32 exec_lo, 0
+    ds_read_b64 {PV[0]}, v44 offset:{LDS_P0}
+    ds_read_b64 {PV[1]}, v44 offset:{LDS_P0 + 8}
+    ds_read_b64 {PV[2]}, v44 offset:{LDS_P0 + 16}
+    s_mov_b32 exec_lo, -1
+    """)
+
+
+def mg_wall_dz(tag):
+    """wdz = signed distance of the lane's probe to its nearer wall, the reference's clamp at / beyond a wall per lane
+    (SMC.c:736-739)"""
+    E(f"""
+    v_add_f64 {vp('T')}, {PV[2]}, {sp('halfLz')}
+    v_cmp_ge_f64 vcc, |{PV[2]}|, {sp('halfLz')}
+    v_mul_f64 {vp('S6')}, {vp('T')}, {sp('invLz')}
+    v_rndne_f64 {vp('S6')}, {vp('S6')}
+    v_fma_f64 {vp('wdz')}, -{vp('S6')}, {sp('Lz')}, {vp('T')}
+    s_cbranch_vccnz L_wdzC_{tag}
+    L_wdz_{tag}:
+    """)
+    tgt = cold if REDIR[0] is None else REDIR[0]
+    for ln in f"""
+    L_wdzC_{tag}:
+    s_mov_b64 {stp(0)}, vcc
+    v_cmp_ge_f64 vcc, 0, {vp('T')}
+    v_mov_b32 {v('T')}, 0xbf1a36e2
+    v_mov_b32 {v('T',1)}, 0x3f1a36e2
+    s_mov_b64 exec, {stp(0)}
+    v_mov_b32 {v('wdz')}, 0xeb1c432d
+    v_cndmask_b32 {v('wdz',1)}, {v('T')}, {v('T',1)}, vcc
+    s_mov_b64 exec, -1
+    s_branch L_wdz_{tag}
+    """.strip().split("\n"):
+        tgt.append(ln.strip())
+
+
+def mg_side_sources(lane_old):
+    """the side pair's sources: lane `lane_old` (s) of half B <- particle n's CURRENT position p0[tl], the next lane <- the
+    proposal Q; both evaluate against probe B (particle n+1)"""
+    E(f"""
+    s_mul_i32 {st(7)}, {s('tl')}, 24
+    v_mov_b32 v47, {st(7)}
+    s_lshl_b64 exec, 1, {lane_old}
+    ds_read_b64 v[{XA_}:{XA_+1}], v47 offset:{LDS_P0}
+    ds_read_b64 v[{XA_+2}:{XA_+3}], v47 offset:{LDS_P0 + 8}
+    ds_read_b64 v[{XA_+4}:{XA_+5}], v47 offset:{LDS_P0 + 16}
+    s_add_u32 {st(7)}, {lane_old}, 1
+    s_lshl_b64 exec, 1, {st(7)}
+    v_mov_b64 v[{XA_}:{XA_+1}], {sp('Q',0)}
+    v_mov_b64 v[{XA_+2}:{XA_+3}], {sp('Q',1)}
+    v_mov_b64 v[{XA_+4}:{XA_+5}], {sp('Q',2)}
+    s_mov_b64 exec, -1
+    """)
+
+
+def mg_side_capture(sides, lane_old):
+    """after round 0: the accumulators of the two side lanes (each holds that one item) go to the side area --
+    [old, new][e, fx, fy, fz] -- and are zeroed: the reduction carries probe B WITHOUT the pair (n, n+1)"""
+    a = [vp('acc', j) for j in range(4)]
+    E(f"""
+    s_mov_b64 exec, {sides}
+    v_cmp_ne_u32 vcc, {lane_old}, {LANE}
+    v_mov_b32 v44, 0
+    s_nop 1
+    v_cndmask_b32 v44, 0, 32, vcc
+    ds_write_b64 v44, {a[0]} offset:{LDS_SIDEM}
+    ds_write_b64 v44, {a[1]} offset:{LDS_SIDEM + 8}
+    ds_write_b64 v44, {a[2]} offset:{LDS_SIDEM + 16}
+    ds_write_b64 v44, {a[3]} offset:{LDS_SIDEM + 24}
+    v_mov_b64 {a[0]}, 0
+    v_mov_b64 {a[1]}, 0
+    v_mov_b64 {a[2]}, 0
+    v_mov_b64 {a[3]}, 0
+    s_mov_b64 exec, -1
+    """)
+
+
+def mg_round0(near):
+    """round 0 of the merged pass: hand-over of the first candidates, the planes (near: with the wall sites of a probe that
+    is within the cutoff of a wall) and the side pair, one fp64 body.  The far form is the hot path: planes on lanes 0 and
+    32 (the words of wlp), side pair on the two lanes behind half B's plane; the near form lies among the cold pieces."""
+    tag = "mn" if near else "mf"
+    if near:
+        # wall lanes of either half: the sites and the plane (M2 + 1, the plane last) or the plane alone
+        E(f"""
+        L_mgN:
+        s_add_u32 {st(0)}, {s('M2')}, 1
+        s_cmp_lg_u32 {s('nearA')}, 0
+        s_cselect_b32 {st(2)}, {st(0)}, {s('wlp')}
+        s_cmp_lg_u32 {s('nearB')}, 0
+        s_cselect_b32 {st(3)}, {st(0)}, {s('wlp',1)}
+        s_bcnt1_i32_b32 {st(4)}, {s('sidesHi')}
+        s_add_u32 {st(4)}, {st(4)}, {st(3)}
+        """)
+        startA, startB = st(2), st(4)
+    else:
+        startA, startB = s('wlp'), s('stB')
+    mg_handover(V['wa0'], V['wa1'], sp('hA'), startA, 0, st(5))
+    mg_handover(V['wb0'], V['wb1'], sp('hB'), startB, 128, st(6))
+    mg_probes()
+    # this lane's item; the candidates' lanes (st(0): half A's word, st(1): half B's)
+    E(f"""
+    ds_read_b32 v44, {KL4} offset:{LDS_LIST}
+    s_bfm_b64 {stp(0)}, {st(5)}, {startA}
+    s_bfm_b64 {stp(6)}, {st(6)}, {startB}
+    s_mov_b32 {st(1)}, {st(6)}
+    """)
+    if near:
+        # wl = the wall lanes, pl = the planes (last wall lane of a half), the side lanes behind half B's wall lanes
+        E(f"""
+        s_bfm_b32 {s('hA')}, {st(2)}, 0
+        s_bfm_b32 {s('hA',1)}, {st(3)}, 0
+        s_sub_u32 {st(7)}, {st(2)}, 1
+        s_max_i32 {st(7)}, {st(7)}, 0
+        s_lshl_b32 {s('hB')}, {s('wlp')}, {st(7)}
+        s_sub_u32 {st(7)}, {st(3)}, 1
+        s_max_i32 {st(7)}, {st(7)}, 0
+        s_lshl_b32 {s('hB',1)}, {s('wlp',1)}, {st(7)}
+        s_cmp_lg_u32 {s('sidesHi')}, 0
+        s_cselect_b32 {st(5)}, 3, 0
+        s_lshl_b32 {st(5)}, {st(5)}, {st(3)}
+        s_mov_b32 {st(4)}, 0
+        s_add_u32 {st(3)}, {st(3)}, 32
+        """)
+        wl, pl, sides, lane_old = sp('hA'), sp('hB'), stp(4), st(3)
+    else:
+        E(f"""
+        s_mov_b32 {st(4)}, 0
+        s_mov_b32 {st(5)}, {s('sidesHi')}
+        s_add_u32 {st(3)}, {s('wlp',1)}, 32
+        """)
+        wl, pl, sides, lane_old = sp('wlp'), sp('wlp'), stp(4), st(3)
+    # the side pair (a pass that has a proposal AND a next particle)
+    (E if near else G)(f"""
+    s_cmp_eq_u32 {s('sidesHi')}, 0
+    s_cbranch_scc1 L_nss_{tag}
+    """)
+    mg_side_sources(lane_old)
+    E(f"L_nss_{tag}:")
+    E(f"""
+    s_waitcnt lgkmcnt(0)
+    v_mul_u32_u24 v45, 24, v44
+    {"v_mov_b32 v45, 0" if FAKE else ""}
+    s_mov_b64 exec, {stp(0)}
+    global_load_dwordx4 v[{XA_}:{XA_+3}], v45, {SRC}
+    global_load_dwordx2 v[{XA_+4}:{XA_+5}], v45, {SRC} offset:16
+    s_mov_b64 exec, -1
+    """)
+    if near:   # table rows of the wall lanes of a near probe: row = lane within its half
+        E(f"""
+        s_cmp_lg_u32 {s('nearA')}, 0
+        s_cselect_b32 {st(6)}, {s('hA')}, 0
+        s_cmp_lg_u32 {s('nearB')}, 0
+        s_cselect_b32 {st(7)}, {s('hA',1)}, 0
+        v_and_b32 v46, 31, {LANE}
+        v_lshlrev_b32 v46, 5, v46
+        """)
+    # displacement of move i+1 in group layout: it travels during the pass and the Metropolis step
+    (E if near else G)(f"""
+    s_cmp_eq_u32 {s('hasB')}, 0
+    s_cbranch_scc1 L_ndd_{tag}
+    """)
+    E(f"""
+    s_add_u32 {st(2)}, {s('i')}, 1
+    s_mul_i32 {st(2)}, {st(2)}, 24
+    v_add_u32 v45, {st(2)}, {KC}
+    global_load_dwordx2 {DdNm}, v45, {sp('dK')}{NT}
+    L_ndd_{tag}:
+    """)
+    # coefficients: 1 for the candidates, (a0, b0) for a plane, the table's for wall sites
+    coeff_one(CA_)
+    if near:
+        E(f"""
+        s_mov_b64 exec, {stp(6)}
+        global_load_dwordx4 v[{XA_}:{XA_+3}], v46, {sp('wtab')}
+        global_load_dwordx4 v[{CA_}:{CA_+3}], v46, {sp('wtab')} offset:16
+        s_andn2_b64 exec, {pl}, {stp(6)}
+        v_mov_b64 v[{CA_}:{CA_+1}], {sp('a0s')}
+        v_mov_b64 v[{CA_+2}:{CA_+3}], {sp('b0s')}
+        s_mov_b64 exec, -1
+        """)
+    else:
+        E(f"""
+        s_mov_b64 exec, {pl}
+        v_mov_b64 v[{CA_}:{CA_+1}], {sp('a0s')}
+        v_mov_b64 v[{CA_+2}:{CA_+3}], {sp('b0s')}
+        s_mov_b64 exec, -1
+        """)
+    for j in range(4):
+        E(f"v_mov_b64 {vp('acc', j)}, 0")
+    # everything that has an item: candidates, wall lanes, side lanes
+    E(f"""
+    s_or_b64 {stp(6)}, {stp(0)}, {wl}
+    s_or_b64 {stp(6)}, {stp(6)}, {sides}
+    """)
+    mg_wall_dz(tag)
+    if near:
+        E("s_waitcnt vmcnt(0)")
+    else:   # the candidates' positions; the displacement asked for behind them may still travel
+        G("s_waitcnt vmcnt(0)")
+        SO("s_waitcnt vmcnt(1)")
+    body(tag, PV, XA_, CA_, stp(6), True, wl, pl)
+    (E if near else G)(f"""
+    s_cmp_eq_u32 {s('sidesHi')}, 0
+    s_cbranch_scc1 L_nsc_{tag}
+    """)
+    mg_side_capture(sides, lane_old)
+    E(f"L_nsc_{tag}:")
+    if near:
+        E("s_branch L_mgR0")
+
+
+def mg_more():
+    """further rounds (cold): the candidates still in the flag words, 32 per half and round"""
+    E(f"""
+    L_mgMore:
+    """)
+    if Z8C:   # executed work: rounds beyond the first of a pass
+        cnt_addr("v46")
+        E(f"""
+        v_mov_b32 v44, 1
+        s_mov_b64 exec, 1
+        ds_add_u32 v46, v44 offset:{LDS_CNT + 20}
+        s_mov_b64 exec, -1
+        """)
+    mg_handover(V['wa0'], V['wa1'], sp('hA'), "0", 0, st(5))
+    mg_handover(V['wb0'], V['wb1'], sp('hB'), "0", 128, st(6))
+    E(f"""
+    ds_read_b32 v44, {KL4} offset:{LDS_LIST}
+    s_bfm_b64 {stp(0)}, {st(5)}, 0
+    s_bfm_b64 {stp(6)}, {st(6)}, 0
+    s_mov_b32 {st(1)}, {st(6)}
+    s_waitcnt lgkmcnt(0)
+    v_mul_u32_u24 v45, 24, v44
+    s_mov_b64 exec, {stp(0)}
+    global_load_dwordx4 v[{XA_}:{XA_+3}], v45, {SRC}
+    global_load_dwordx2 v[{XA_+4}:{XA_+5}], v45, {SRC} offset:16
+    s_mov_b64 exec, -1
+    """)
+    coeff_one(CA_)
+    E("s_waitcnt vmcnt(0)")
+    body("mm", PV, XA_, CA_, stp(0), False)
+    E("s_branch L_mgR0")
+
+
+def mg_reduce():
+    """the four accumulators of the two halves -> 8 sums in group layout (v[50:51]): row 0 of a half = [e | fy], row 1 =
+    [fx | fz]; then v[50:51] = probe A's sums in both halves (Fn), MGW = probe B's in both halves"""
+    a = [V['acc'] + 2 * j for j in range(4)]
+    E(f"""
+    s_nop 1
+    v_permlane16_swap_b32 v{a[0]}, v{a[1]}
+    v_permlane16_swap_b32 v{a[0]+1}, v{a[1]+1}
+    v_permlane16_swap_b32 v{a[2]}, v{a[3]}
+    v_permlane16_swap_b32 v{a[2]+1}, v{a[3]+1}
+    s_nop 0
+    v_add_f64 v[{a[0]}:{a[0]+1}], v[{a[0]}:{a[0]+1}], v[{a[1]}:{a[1]+1}]
+    v_add_f64 v[{a[2]}:{a[2]+1}], v[{a[2]}:{a[2]+1}], v[{a[3]}:{a[3]+1}]
+    s_nop 1
+    v_mov_b32_dpp v44, v{a[0]} row_ror:8 row_mask:0xf bank_mask:0xf bound_ctrl:1
+    v_mov_b32_dpp v45, v{a[0]+1} row_ror:8 row_mask:0xf bank_mask:0xf bound_ctrl:1
+    v_mov_b32_dpp v46, v{a[2]} row_ror:8 row_mask:0xf bank_mask:0xf bound_ctrl:1
+    v_mov_b32_dpp v47, v{a[2]+1} row_ror:8 row_mask:0xf bank_mask:0xf bound_ctrl:1
+    v_add_f64 v[{a[0]}:{a[0]+1}], v[{a[0]}:{a[0]+1}], v[44:45]
+    v_add_f64 v[{a[2]}:{a[2]+1}], v[{a[2]}:{a[2]+1}], v[46:47]
+    s_nop 1
+    v_mov_b32_dpp v{a[0]}, v{a[2]} quad_perm:[0,1,2,3] row_mask:0xf bank_mask:0xc
+    v_mov_b32_dpp v{a[0]+1}, v{a[2]+1} quad_perm:[0,1,2,3] row_mask:0xf bank_mask:0xc
+    """)
+    dst = f"v[{a[0]}:{a[0]+1}]"
+    for ctrl in ("row_half_mirror", "quad_perm:[2,3,0,1]", "quad_perm:[1,0,3,2]"):
+        E(f"""
+        s_nop 1
+        v_mov_b32_dpp v44, v{a[0]} {ctrl} row_mask:0xf bank_mask:0xf bound_ctrl:1
+        v_mov_b32_dpp v45, v{a[0]+1} {ctrl} row_mask:0xf bank_mask:0xf bound_ctrl:1
+        v_add_f64 {dst}, {dst}, v[44:45]
+        """)
+    E(f"""
+    v_mov_b32 v20, v{a[0]}
+    v_mov_b32 v21, v{a[0]+1}
+    s_nop 1
+    v_permlane32_swap_b32 v{a[0]}, v20
+    v_permlane32_swap_b32 v{a[0]+1}, v21
+    """)
+    return dst
+
+
+if MG:
+    E(f"""
+    s_or_b32 {st(0)}, {s('nearA')}, {s('nearB')}
+    s_cbranch_scc1 L_mgN
+    """)
+    mg_round0(False)
+    REDIR[0] = cold
+    mg_round0(True)
+    REDIR[0] = None
+    E(f"""
+    L_mgR0:
+    v_or3_b32 v44, {v('wa0')}, {v('wa1')}, {v('wb0')}
+    v_or_b32 v44, v44, {v('wb1')}
+    v_cmp_ne_u32 vcc, 0, v44
+    s_cbranch_vccnz L_mgMore
+    """)
+    REDIR[0] = cold
+    mg_more()
+    REDIR[0] = None
+    FnG = mg_reduce()
+    # ---- Metropolis step in group layout (SMC.c:326-335); FmV, DdV: this move's Fm and displacement per group
+    E(f"s_mov_b32 {s('accf')}, 0")
+    G(f"""
+    s_cmp_eq_u32 {s('hasA')}, 0
+    s_cbranch_scc1 L_noA
+    """)
+    E(f"""
+    v_add_f64 {vp('D',0)}, {FnG}, -{vp('FmV')}
+    v_add_f64 {vp('D',1)}, {FnG}, {vp('FmV')}
+    v_fma_f64 {vp('D',2)}, {vp('FmV')}, {sp('AoT')}, {vp('DdV')}
+    v_mul_f64 {vp('D',2)}, {vp('D',2)}, 0.5
+    v_fma_f64 {vp('D',2)}, {vp('D',0)}, {sp('Ao4T')}, {vp('D',2)}
+    v_mul_f64 {vp('D',2)}, {vp('D',2)}, {vp('D',1)}
+    s_mov_b64 exec, 0xff
+    v_mul_f64 {vp('D',2)}, {vp('D',0)}, 4.0
+    s_mov_b64 exec, -1
+    s_nop 0
+    v_mov_b32_dpp {v('T')}, {v('D',4)} row_ror:8 row_mask:0xf bank_mask:0xf bound_ctrl:1
+    v_mov_b32_dpp {v('T',1)}, {v('D',5)} row_ror:8 row_mask:0xf bank_mask:0xf bound_ctrl:1
+    v_add_f64 {vp('D',2)}, {vp('D',2)}, {vp('T')}
+    v_mov_b32 {v('T')}, 0
+    v_mov_b32 {v('T',1)}, 0
+    s_nop 0
+    v_mov_b32_dpp {v('T')}, {v('D',4)} row_bcast:15 row_mask:0xa bank_mask:0xf
+    v_mov_b32_dpp {v('T',1)}, {v('D',5)} row_bcast:15 row_mask:0xa bank_mask:0xf
+    v_add_f64 {vp('D',2)}, {vp('D',2)}, {vp('T')}
+    v_mul_f64 {vp('D',2)}, {vp('D',2)}, -{sp('invT')}
+    v_cmp_lt_f64 vcc, {sp('lu')}, {vp('D',2)}
+    s_nop 0
+    s_bitcmp1_b32 vcc_lo, 31
+    s_cbranch_scc0 L_reject
+    """)
+MUTE[0] = MG
 
 # ---------------------------------------------------------------------------------------------- probe A + Metropolis
 QP = [sp('Q', 0), sp('Q', 1), sp('Q', 2)]
@@ -2296,9 +2822,10 @@ else:
     s_cmp_lg_u64 vcc, 0
     s_cbranch_scc0 L_reject
     """)
+MUTE[0] = False
 E(f"""
-// accepted: E += Un - Um = 4 (eA - eB) (row 0 of g), particle n takes the proposal
-{f"s_mov_b32 {s('accf')}, 1" if TT else ""}
+// accepted: E += Un - Um = 4 (eA - eB) (row 0 of g; mg: the e group, lane 0 either way), particle n takes the proposal
+{f"s_mov_b32 {s('accf')}, 1" if (TT or MG) else ""}
 v_readlane_b32 {st(0)}, {v('D',0)}, 0
 v_readlane_b32 {st(1)}, {v('D',1)}, 0
 s_add_u32 {s('jacc')}, {s('jacc')}, 1
@@ -2422,6 +2949,63 @@ mark(8)
 # ---------------------------------------------------------------------------------------------- probe B
 G(f"s_cmp_eq_u32 {s('hasB')}, 0")
 G("s_cbranch_scc1 L_noB")
+if MG:
+    # ---- Fm of particle n+1 = probe B's sums + the side result that applies; then its proposal, in group layout
+    E(f"""
+    s_add_u32 {st(1)}, {s('i')}, 1
+    s_lshl_b32 {st(0)}, {st(1)}, 3
+    s_load_dwordx2 {sp('lu')}, {sp('uK')}, {st(0)}
+    s_add_u32 {st(2)}, {s('tl')}, 1
+    s_mul_i32 {st(2)}, {st(2)}, 24
+    v_add_u32 v25, {st(2)}, {KC}
+    ds_read_b64 {vp('D',0)}, v25 offset:{LDS_P0}
+    v_mov_b32 {v('FmV')}, v20
+    v_mov_b32 {v('FmV',1)}, v21
+    """)
+    G(f"""
+    s_cmp_eq_u32 {s('sidesHi')}, 0
+    s_cbranch_scc1 L_nsr
+    """)
+    E(f"""
+    v_lshl_add_u32 v24, {s('accf')}, 5, {KSD}
+    ds_read_b64 v[22:23], v24 offset:{LDS_SIDEM}
+    s_waitcnt lgkmcnt(0)
+    v_add_f64 {vp('FmV')}, {MGW}, v[22:23]
+    L_nsr:
+    s_waitcnt vmcnt(0) lgkmcnt(0)
+    v_mov_b32 {v('DdV')}, v12
+    v_mov_b32 {v('DdV',1)}, v13
+    v_fma_f64 {vp('D',1)}, {vp('FmV')}, {sp('AoT')}, {DdNm}
+    v_add_f64 {vp('D',0)}, {vp('D',0)}, {vp('D',1)}
+    // wrap x and y (lanes 16..23, 8..15 of a half), fixed point with 256/L ; z (lanes 24..31): fixed point, safe range, near a wall
+    s_bfm_b64 exec, 16, 8
+    v_mul_f64 {vp('D',1)}, {vp('D',0)}, {sp('invL')}
+    v_rndne_f64 {vp('D',1)}, {vp('D',1)}
+    v_fma_f64 {vp('D',0)}, -{vp('D',1)}, {sp('L')}, {vp('D',0)}
+    v_mul_f64 {vp('D',1)}, {vp('D',0)}, {sp('toFix')}
+    s_bfm_b64 exec, 8, 24
+    v_mul_f64 {vp('D',1)}, {vp('D',0)}, {sp('zFix')}
+    v_cmp_nlt_f64 vcc, |{vp('D',0)}|, {sp('zsafe')}
+    v_cmp_nlt_f64 {stp(4)}, |{vp('D',0)}|, {sp('znear')}
+    s_mov_b64 exec, -1
+    v_rndne_f64 {vp('D',1)}, {vp('D',1)}
+    v_mov_b32 {v('T')}, 0x7fff
+    v_mov_b32 {v('T',1)}, 0xffff8001
+    v_cvt_i32_f64 {v('D',4)}, {vp('D',1)}
+    s_bfe_u32 {s('ua')}, vcc_lo, 0x10018
+    s_bfe_u32 {s('nearA')}, {st(4)}, 0x10018
+    v_med3_i32 {v('D',5)}, {v('D',4)}, {v('T')}, {v('T',1)}
+    v_readlane_b32 {s('Q',0)}, {v('D',0)}, 16
+    v_readlane_b32 {s('Q',1)}, {v('D',1)}, 16
+    v_readlane_b32 {s('Q',2)}, {v('D',0)}, 8
+    v_readlane_b32 {s('Q',3)}, {v('D',1)}, 8
+    v_readlane_b32 {s('Q',4)}, {v('D',0)}, 24
+    v_readlane_b32 {s('Q',5)}, {v('D',1)}, 24
+    v_readlane_b32 {st(0)}, {v('D',4)}, 16
+    v_readlane_b32 {st(1)}, {v('D',4)}, 8
+    v_readlane_b32 {st(2)}, {v('D',5)}, 24
+    """)
+MUTE[0] = MG
 if TT:
     # probe B was evaluated before the decision (team B) and the proposal of particle n+1 formed for both outcomes (above):
     # the half of every row that worked for the outcome that did NOT happen takes the other half's Fm (it is the next move's
@@ -2458,17 +3042,20 @@ if TT:
     # (no wait for lu here: every later wait on this counter is lgkmcnt(0), the first at the latest before the exchange)
     mark(9)
 else:
+    if not KROW:
+        E(f"""
+        // per-row component offset: rows 1..3 -> 0, 8, 16 (row 0 idles along with component 0)
+        v_lshrrev_b32 {v('T')}, 4, {LANE}
+        v_add_u32 {v('T')}, -1, {v('T')}
+        v_max_i32 {v('T')}, 0, {v('T')}
+        v_lshlrev_b32 {v('T')}, 3, {v('T')}
+        """)
     E(f"""
-    // per-row component offset: rows 1..3 -> 0, 8, 16 (row 0 idles along with component 0)
-    v_lshrrev_b32 {v('T')}, 4, {LANE}
-    v_add_u32 {v('T')}, -1, {v('T')}
-    v_max_i32 {v('T')}, 0, {v('T')}
-    v_lshlrev_b32 {v('T')}, 3, {v('T')}
     s_add_u32 {st(1)}, {s('i')}, 1
     {f"s_lshl_b32 {st(0)}, {st(1)}, 3" if Z8 else ""}
     {f"s_load_dwordx2 {sp('lu')}, {sp('uK')}, {st(0)}" if Z8 else ""}
     s_mul_i32 {st(1)}, {st(1)}, 24
-    v_add_u32 {v('S6')}, {st(1)}, {v('T')}
+    v_add_u32 {v('S6')}, {st(1)}, {KROW or v('T')}
     """)
     side_sources()
     E(f"""
@@ -2484,13 +3071,13 @@ else:
 (E if not TT else (lambda t: None))(f"""
 // ---- proposal of particle n+1 in row layout (SMC.c:307-316): q = p + (Fm A/T + displ)   (z8t: before the decision, above)
 // rows 1..3 read component row-1 of p0[rowB] and of displ[3 (i+1) ..]; row 0 idles along with component 0
-v_lshrrev_b32 {v('T')}, 4, {LANE}
-v_add_u32 {v('T')}, -1, {v('T')}
-v_max_i32 {v('T')}, 0, {v('T')}
-v_lshlrev_b32 {v('T')}, 3, {v('T')}
+{"" if KROW else f"v_lshrrev_b32 {v('T')}, 4, {LANE}"}
+{"" if KROW else f"v_add_u32 {v('T')}, -1, {v('T')}"}
+{"" if KROW else f"v_max_i32 {v('T')}, 0, {v('T')}"}
+{"" if KROW else f"v_lshlrev_b32 {v('T')}, 3, {v('T')}"}
 s_add_u32 {st(0)}, {s('tl')}, 1
 s_mul_i32 {st(0)}, {st(0)}, 24
-{f"v_add3_u32 {v('T',1)}, {st(0)}, {v('T')}, v1" if W4 else f"v_add_u32 {v('T',1)}, {st(0)}, {v('T')}"}
+{f"v_add3_u32 {v('T',1)}, {st(0)}, {v('T')}, v1" if W4 else f"v_add_u32 {v('T',1)}, {st(0)}, {KROW or v('T')}"}
 ds_read_b64 {vp('D',0)}, {v('T',1)} offset:{LDS_P0}
 {"s_waitcnt lgkmcnt(0)" if TT else "s_waitcnt vmcnt(0) lgkmcnt(0)"}
 {'' if Z8 else f"s_mov_b64 {sp('lu')}, {sp('nlu')}"}
@@ -2527,6 +3114,7 @@ v_readlane_b32 {st(0)}, {v('D',4)}, 16
 v_readlane_b32 {st(1)}, {v('D',4)}, 32
 v_readlane_b32 {st(2)}, {v('D',5)}, 48
 """)
+MUTE[0] = False
 if Z8:
     E(f"""
     s_and_b32 {st(0)}, {st(0)}, 0xff
@@ -2546,7 +3134,7 @@ else:
 E(f"""
 {f"s_mov_b32 {s('axys')}, {st(0)}" if ZB else f"v_mov_b32 {v('axy')}, {st(0)}"}
 """)
-E(f"s_cmp_eq_u32 {s('cross')}, 1")
+E(f"s_cmp_eq_u32 {s('tl')}, 63" if ZB else f"s_cmp_eq_u32 {s('cross')}, 1")
 E("s_cbranch_scc0 L_nocross")
 rotate("r2")
 E(f"s_mov_b32 {s('tl')}, -1")
@@ -2568,10 +3156,24 @@ s_add_u32 {st(0)}, {s('i')}, 1
 s_cmp_lt_i32 {st(0)}, {s('len')}
 """)
 G(f"s_cselect_b32 {s('hasB')}, 1, 0")
+if MG:   # what the next pass has: plane of half A (a proposal and walls), of half B (a next particle and walls), the side pair
+    G(f"""
+    s_cmp_ge_i32 {s('M2')}, 0
+    s_cselect_b32 {s('wlp')}, 1, 0
+    s_and_b32 {s('wlp',1)}, {s('wlp')}, {s('hasB')}
+    s_lshl_b32 {st(1)}, {s('hasB')}, 1
+    s_add_u32 {s('stB')}, {s('wlp',1)}, {st(1)}
+    s_mul_i32 {st(1)}, {s('hasB')}, 3
+    s_lshl_b32 {s('sidesHi')}, {st(1)}, {s('wlp',1)}
+    s_cmp_lt_i32 {st(0)}, {s('len')}
+    """)
 # the next pass has a proposal to decide (hasA) and a next particle (hasB): the steady copy runs it
 E("s_cbranch_scc1 L_S_move" if PEEL else "")
 SO(f"""
 s_mov_b32 {s('hasB')}, 0
+{f"s_mov_b32 {s('wlp',1)}, 0" if MG else ""}
+{f"s_mov_b32 {s('stB')}, 0" if MG else ""}
+{f"s_mov_b32 {s('sidesHi')}, 0" if MG else ""}
 s_branch L_G_move
 """)
 G(f"""
@@ -2626,6 +3228,8 @@ if Z8C:
     ds_read_b32 v24, v25 offset:{LDS_CNT + 8}
     ds_read_b32 v34, v25 offset:{LDS_CNT + 12}
     ds_read_b32 v35, v25 offset:{LDS_CNT + 16}
+    ds_read_b32 v40, v25 offset:{LDS_CNT + 20}
+    ds_read_b32 v42, v25 offset:{LDS_CNT + 24}
     s_load_dwordx2 {stp(2)}, {KARG}, {K_DBG}
     v_mov_b32 v30, 0
     v_mov_b32 v27, 0
@@ -2645,6 +3249,10 @@ if Z8C:
     v_mov_b32 v38, v35
     v_mov_b32 v39, 0
     global_atomic_add_x2 v30, v[38:39], {stp(2)} offset:32
+    v_mov_b32 v41, 0
+    v_mov_b32 v43, 0
+    global_atomic_add_x2 v30, v[40:41], {stp(2)} offset:40
+    global_atomic_add_x2 v30, v[42:43], {stp(2)} offset:48
     s_mov_b64 exec, -1
     s_waitcnt vmcnt(0)
     """)

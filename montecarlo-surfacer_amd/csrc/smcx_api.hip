@@ -501,6 +501,18 @@ extern "C" int smcx_kernel_form(const smcx_handle *hh, int *form, char *name, in
     return SMCX_OK;
 }
 
+#include "smcx_kernel_ids.h"
+extern "C" int smcx_kernel_source_id(const char *kernel, char *id, int len)
+{
+    if (!kernel || !id || len < 17) return SMCX_ERR_PARAM;
+    for (const auto &e : smcx_kernel_ids)
+        if (e.prefix ? std::strncmp(kernel, e.kernel, std::strlen(e.kernel)) == 0 : std::strcmp(kernel, e.kernel) == 0) {
+            std::snprintf(id, (size_t)len, "%s", e.id);
+            return SMCX_OK;
+        }
+    return SMCX_ERR_PARAM;
+}
+
 extern "C" int smcx_upload(smcx_handle *hh, const double *R0, int r0_per_replica, const double *W,
                            const uint32_t *seeds)
 {
@@ -889,12 +901,12 @@ extern "C" int smcx_debug_check_counts(smcx_handle *hh, uint64_t *out /*[3]*/)
 }
 // the same plus the executed work of the z-ordered byte-screen kernels (SMCX_CHECK_MB=2): out[3] = 4-slot groups
 // screened (256 cells per wavefront each), out[4] = screen passes (one per probe and wavefront)
-extern "C" int smcx_debug_work_counts(smcx_handle *hh, uint64_t *out /*[5]*/)
+extern "C" int smcx_debug_work_counts(smcx_handle *hh, uint64_t *out /*[8]*/)
 {
     if (!hh || !out) return SMCX_ERR_PARAM;
     Handle &h = hh->h;
     HIPCHK(&h, hipSetDevice(h.p.device));
-    HIPCHK(&h, hipMemcpy(out, h.c.dbg, 5 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    HIPCHK(&h, hipMemcpy(out, h.c.dbg, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost));
     return SMCX_OK;
 }
 #endif

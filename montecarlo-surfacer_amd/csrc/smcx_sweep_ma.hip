@@ -29,8 +29,19 @@ struct MaArgs {
     int sw0, pad0;                                            // 0xc8  mb: first sweep of this launch within the chunk
     unsigned long long *dbg;                                  // 0xd0  diagnostic build: the screen's counters
     unsigned *prio;                                           // 0xd8  mb/mc: progress table of the SIMDs' wavefronts [16384]
+    double znear;                                             // 0xe0  mg: |z| from which a wall's sites can be inside the cutoff
 };
-static_assert(sizeof(MaArgs) == 0xe0, "offsets are hard-wired in gen_sweep_ma.py");
+static_assert(sizeof(MaArgs) == 0xe8, "offsets are hard-wired in gen_sweep_ma.py");
+
+// |z| below which no wall SITE can be within the cutoff of a probe and the clamp of SMC.c:736-739 cannot apply: the wall is
+// Lz/2 - |z| away and a site at least that far; a relative margin covers the roundings of the kernel's own wall distance.
+// Probes beyond it take the path that evaluates the sites (always right; this bound only has to be conservative).
+static double wall_sites_reach(double halfLz, double cutoff2, int M2)
+{
+    if (M2 < 0) return 1e300;                                 // no walls: nothing to reach
+    const double rc = std::sqrt(cutoff2);
+    return halfLz - rc - 1e-6 * (halfLz + rc);
+}
 
 // LDS (dynamic, at launch; the body addresses it by fixed offsets): unsigned zw[S/2][64] (int16 z, slot pairs x
 // lanes) at 0, double p0[65][3] (fp64 positions of the slot-0 particles + lane 0's slot-1 particle) behind it
@@ -268,11 +279,9 @@ constexpr unsigned mcw_lds_bytes(int wpr) { return (unsigned)wpr * 2048u + 2u * 
 #else
 constexpr unsigned mcw_lds_bytes(int wpr) { return (unsigned)wpr * 2048u + 2u * (unsigned)wpr * 512u; }
 #endif
-#ifdef SMCX_CHECK
-constexpr unsigned mc_lds_bytes() { return 65u * 24u + 8u + 512u; }
-#else
-constexpr unsigned mc_lds_bytes() { return 65u * 24u; }
-#endif
+// sweep_kernel_mc16/32/64: the row cache (65 x 24 B; the diagnostic build's counters behind it), then at 2048 the hand-over
+// list of the merged pass (64 words) and at 2304 the side pair's results (64 B): gen_sweep_ma.py LDS_LIST, LDS_SIDEM
+constexpr unsigned mc_lds_bytes() { return 2304u + 64u; }
 
 // Order of the cells for sweep_kernel_mb.  Cell = slot * 64 + lane; a group = 4 slots = 256 cells.
 //  1. the particles of a replica sorted by z (bitonic sort of (float z, particle) keys in LDS): group g holds
@@ -460,6 +469,7 @@ hipError_t launch_sweeps_mt(const SweepArgs &s, const DevCtx &c, const KernelPla
     mc_bound_values(c.L, c.cutoff2, &a.toFix, &a.zsafe, &a.negC, &a.RZ);
     a.zFix = a.toFix;
     a.Rs = c.Rs; a.loc = c.loc; a.pad0 = 0; a.dbg = nullptr; a.prio = c.prio;
+    a.znear = wall_sites_reach(c.halfLz, c.cutoff2, a.M2);
 #ifdef SMCX_CHECK
     a.dbg = s.dbg;
 #endif
@@ -501,6 +511,7 @@ hipError_t launch_sweeps_mcw(const SweepArgs &s, const DevCtx &c, int WPR, int n
     mc_bound_values(c.L, c.cutoff2, &a.toFix, &a.zsafe, &a.negC, &a.RZ);
     a.zFix = a.toFix;
     a.Rs = c.Rs; a.loc = c.loc; a.pad0 = 0; a.dbg = nullptr; a.prio = c.prio;
+    a.znear = wall_sites_reach(c.halfLz, c.cutoff2, a.M2);
 #ifdef SMCX_CHECK
     a.dbg = s.dbg;
 #endif
@@ -577,6 +588,7 @@ hipError_t launch_sweeps_ma(const SweepArgs &s, const DevCtx &c, const KernelPla
     a.N = s.N; a.chunk = s.chunk; a.nsweeps = nsweeps; a.negC = negC;
     a.M2 = (c.flags & 0x1u) ? c.M2 : -1;
     a.RZ = 0; a.Rs = nullptr; a.loc = nullptr; a.sw0 = 0; a.pad0 = 0; a.dbg = nullptr; a.prio = c.prio;
+    a.znear = wall_sites_reach(c.halfLz, c.cutoff2, a.M2);
 #ifdef SMCX_CHECK
     a.dbg = s.dbg;
 #endif

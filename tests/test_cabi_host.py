@@ -29,6 +29,34 @@ def test_library_exports_every_declared_symbol(S):
     assert sorted(S.EXPORTS) == names  # the Python binding covers the whole ABI
 
 
+def test_roofline_refuses_instruction_counts_of_another_build(S, tmp_path, monkeypatch):
+    """bench.py's roofline fraction comes from committed PMC instruction counts; they carry the source identity of the library
+    they were taken from (smcx_kernel_source_id: sha256 of the generated body / the source files) and are used only for the
+    same build of the kernel -- a kernel edited without a re-profile yields frac: null with a note, not a stale number."""
+    import importlib
+    import json
+    kn = "smcx::sweep_kernel_mc64"
+    sid = S.kernel_source_id(kn)
+    assert sid and re.fullmatch(r"[0-9a-f]{16}", sid)
+    assert S.kernel_source_id("smcx::sweep_kernel_mt16x2") not in (None, sid)
+    assert S.kernel_source_id("smcx::sweep_kernel_mi<64, 4, 4>") and S.kernel_source_id("smcx::sweep_kernel_lead<16, 4, 3, 2>")
+    assert S.kernel_source_id("smcx::no_such_kernel") is None
+    bench = importlib.import_module("bench")
+    (tmp_path / "profiles").mkdir()
+    entry = {"workload": {"N": 4096, "replicas": 4096, "sweeps_in_launch": 1, "start": "fcc(8,16)"}, "source_id": sid,
+             "per_wave_move": {"SQ_INSTS_VALU": 300.0, "SQ_INSTS_VALU_ADD_F64": 30.0, "SQ_INSTS_VALU_MUL_F64": 30.0,
+                               "SQ_INSTS_VALU_FMA_F64": 30.0, "SQ_INSTS_VALU_TRANS_F64": 2.0, "SQ_INSTS_SALU": 100.0}}
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    for ident, ok in ((sid, True), ("0123456789abcdef", False), (None, False)):
+        entry["source_id"] = ident
+        json.dump({kn: entry}, open(tmp_path / "profiles" / "kernel_counters.json", "w"))
+        r = bench.issue_roofline(kn, 10.0, 4096, 4096, 2.35, start="fcc(8,16)")
+        if ok:
+            assert 0.1 < r["frac"] < 1.0 and r["valu_wave_instr_per_move"] == 300.0
+        else:
+            assert r["frac"] is None and "another build" in r["note"]
+
+
 def test_host_library_exports_every_declared_symbol(S):
     """libsmcx_host.so (plain C above the ABI, incl. the RCCL multi-GPU driver) against include/smcx_host.h"""
     hdr = open(os.path.join(ROOT, "include", "smcx_host.h")).read()

@@ -315,7 +315,8 @@ def test_benchmark_kernel_ensemble_statistics_beyond_chaos_horizon(S, O, tmp_pat
 
 
 def _load_check_build():
-    path = os.path.join(ROOT, "montecarlo-surfacer_amd", "libsmcx_check.so")
+    # (SMCX_CHECK_LIB: the diagnostic build of a VARIANT library, for A/B sessions)
+    path = os.environ.get("SMCX_CHECK_LIB") or os.path.join(ROOT, "montecarlo-surfacer_amd", "libsmcx_check.so")
     if not os.path.exists(path):
         pytest.fail("libsmcx_check.so is not built (make -C montecarlo-surfacer_amd/csrc CHECK=1; build() does it)")
     old = os.environ.get("SMCX_LIB")
@@ -555,3 +556,9 @@ def test_bench_launches_its_own_ranks():
     assert out["n_gpus"] == 2 and out["scaling"] == "weak"
     assert out["observables"]["replicas_gathered"] == 128 and out["config"]["replicas_total"] == 128
     assert out["value"] > 0 and out["roofline"]["bound"] == "valu_issue" and out["roofline"]["clock_ghz"] > 1.0
+    # multi-rank observability: every rank's own step time (the headline is the MAX), device times and gather time
+    pr = out["per_rank"]
+    for k in ("ms_per_step", "sweep_kernel_ms_per_step", "device_ms_per_step", "gather_ms"):
+        assert len(pr[k]["ranks"]) == 2 and pr[k]["min"] <= pr[k]["median"] <= pr[k]["max"] and pr[k]["min"] > 0, k
+    assert abs(pr["ms_per_step"]["max"] - out["ms_per_step"]) < 1e-6 * out["ms_per_step"] + 1e-9
+    assert out["gather_ms"] > 0

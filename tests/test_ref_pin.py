@@ -119,3 +119,35 @@ def test_timing_build_of_the_reference_equals_the_oracle_on_one_sweep():
     ch = O.chain(s, 12345, O.fcc(8, 16), O.W_FIXTURE, 1.1, 1.1, 0, 1, 10)
     assert int(acc) == int(ch["jj"][0])
     assert abs(float(E1) - ch["E"][1]) < 1e-9 * max(1.0, abs(ch["E"][1]))
+
+
+@pytest.mark.skipif(not _have_ref, reason="oracle/_ref not built")
+def test_fft_acf_restatement_against_the_references_own_simple_acf():
+    """Row 8f.3 has NO reference pin: fft_acf (SMC.c:1055-1093) needs FFTW, which the image lacks, and no stand-in is written.
+    The reference's OTHER autocorrelation, simple_acf (SMC.c:1096-1122: plain sums, compiled into oracle/_ref from the
+    reference's own text), gives an independent cross-check of the restatement where the two definitions are expected to agree:
+    fft_acf transforms the HALF spectrum back with a transform of HALF the length (SMC.c:1063, 1083), so its entry i is the
+    circular autocorrelation at lag 2 i (exactly: (n c[2i] - P_nyq) / (n c[0] - P_nyq) for even n), while simple_acf[k] is the
+    linear one at lag k over the first n - k_max - 1 products.  For a stationary series with n >> k_max they agree to
+    O(k_max / n): fft_acf[i] ~ simple_acf[2 i].  Where they do NOT agree: odd entries of simple_acf have no counterpart, the
+    circular wrap and the truncation differ by O(k_max / n), and short series (the GPU test's 33..40 samples) differ at O(1).
+    This checks the lag structure and normalisation of the restatement against reference CODE; it is not a bit-level pin."""
+    import numpy as np
+    import oracle_lib as O
+    r = ref_lib.RefSMC(108)
+    rs = np.random.RandomState(11)
+    n, K = 40000, 24
+    for rho in (0.9, 0.6):
+        e = rs.standard_normal(n)
+        H = np.empty(n)
+        H[0] = e[0]
+        for i in range(1, n):
+            H[i] = rho * H[i - 1] + e[i]
+        H -= 150.0
+        a = O.fft_acf(H, K)
+        b = r.simple_acf(H, 2 * K)
+        assert a[0] == 1.0 and b[0] == 1.0
+        assert np.abs(a - b[0:2 * K:2]).max() < 0.02, np.abs(a - b[0:2 * K:2]).max()
+        # the series really decays over these lags, so a wrong lag map (entry i against lag i) could not pass
+        assert np.abs(a[1:8] - b[1:8]).max() > 0.1
+        assert abs(a[3] - rho ** 6) < 0.05

@@ -43,6 +43,15 @@ for name, e in res.items():
         e["hbm_bytes_per_sweep"] = {"fetch_x2_plus_write": (2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024 / sweeps,
                                     "fetch_x1_plus_write": (c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024 / sweeps}
     e["launch_ms"] = sorted(set(round(v / 1e6, 3) for v in e.pop("launch_ns").values()))
+# the identity of the library these counts were taken from (bench.py uses them only for the same build of the kernel)
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+try:
+    import smcx_loader
+    _S = smcx_loader.load()
+    for name, e in res.items():
+        e["source_id"] = _S.kernel_source_id(name)
+except Exception as ex:   # counts without an identity are never used for a fraction
+    print("pmc_to_json: no source ids (%r)" % (ex,))
 json.dump(res, open(out, "w"), indent=1, sort_keys=True)
 for name, e in res.items():
     print(name, "VGPR", e["vgpr"], "SGPR", e["sgpr"], "scratch", e["scratch_bytes"], "LDS", e["lds_bytes"], "launch ms", e["launch_ms"])
