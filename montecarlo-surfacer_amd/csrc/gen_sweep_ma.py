@@ -145,7 +145,7 @@ PEEL = ZB and os.environ.get("SMCX_GEN_NOPEEL") != "1"
 # kernels), then the candidates in the order of their owner lanes.  One body, ONE reduction (4 accumulators x 2 halves -> 8
 # sums in 8-lane groups: e | fy in row 0, fx | fz in row 1 of each half), Metropolis and proposal in that "group layout".
 # Per move ~130 instructions fewer than two probes one after the other (of ~540).
-MG = Z8 and not W4 and os.environ.get("SMCX_GEN_MERGE") == "1"
+MG = Z8 and not W4 and os.environ.get("SMCX_GEN_NOMERGE") != "1"      # (switch for the A/B: SMCX_GEN_NOMERGE=1)
 # z8t with 16 cells per lane ("LP"): the fp64 positions of all cells (24 KB, what candidates are fetched from) and the
 # wall table live in LDS at offset 0, shared by the two wavefronts of the replica; every other LDS area moves up
 PF2 = TT and NS >= 32     # z8t with many cells: the first TWO candidates of a lane are fetched together (dense states: the
@@ -446,7 +446,7 @@ if KROW:
     v_lshlrev_b32 {KROW}, 3, {KROW}
     """)
 E(f"""
-{"" if (W4 or KROW) else f"v_lshlrev_b32 {v('zaddr')}, 2, {LANE}"}
+{"" if (W4 or KROW or MG) else f"v_lshlrev_b32 {v('zaddr')}, 2, {LANE}"}
 v_mov_b32 {v('uns0')}, 0
 v_mov_b32 {v('uns1')}, 0
 s_mov_b32 {s('rot')}, 0
@@ -2245,12 +2245,8 @@ def mg_wall_dz(tag):
     v_mul_f64 {vp('S6')}, {vp('T')}, {sp('invLz')}
     v_rndne_f64 {vp('S6')}, {vp('S6')}
     v_fma_f64 {vp('wdz')}, -{vp('S6')}, {sp('Lz')}, {vp('T')}
-    s_cbranch_vccnz L_wdzC_{tag}
-    L_wdz_{tag}:
     """)
-    tgt = cold if REDIR[0] is None else REDIR[0]
-    for ln in f"""
-    L_wdzC_{tag}:
+    clamp = f"""
     s_mov_b64 {stp(0)}, vcc
     v_cmp_ge_f64 vcc, 0, {vp('T')}
     v_mov_b32 {v('T')}, 0xbf1a36e2
@@ -2259,9 +2255,17 @@ def mg_wall_dz(tag):
     v_mov_b32 {v('wdz')}, 0xeb1c432d
     v_cndmask_b32 {v('wdz',1)}, {v('T')}, {v('T',1)}, vcc
     s_mov_b64 exec, -1
-    s_branch L_wdz_{tag}
-    """.strip().split("\n"):
-        tgt.append(ln.strip())
+    """
+    if REDIR[0] is None:      # hot path: the clamp lies among the cold pieces
+        E(f"s_cbranch_vccnz L_wdzC_{tag}")
+        E(f"L_wdz_{tag}:")
+        COLD(f"L_wdzC_{tag}:")
+        COLD(clamp)
+        COLD(f"s_branch L_wdz_{tag}")
+    else:                     # already among the cold pieces: in line, jumped over
+        E(f"s_cbranch_vccz L_wdz_{tag}")
+        E(clamp)
+        E(f"L_wdz_{tag}:")
 
 
 def mg_side_sources(lane_old):
