@@ -224,6 +224,13 @@ int smcx_geometry(const smcx_handle *h, int *slots, int *waves_per_replica, int 
  * candidates: sweep_kernel_mi with one wavefront per replica, sweep_kernel_mx with several); name,
  * if not NULL, receives the kernel's name (at most len bytes) */
 int smcx_kernel_form(const smcx_handle *h, int *form, char *name, int len);
+/* how many replicas the device runs at once with this handle's sweep kernel (workgroups resident per CU x CUs; 0 if unknown
+ * for this kernel form).  One launch runs one sweep of every replica and a sweep is sequential inside a replica, so the time
+ * per sweep is a step function of nrep / granule: 4097 replicas of N = 4096 cost one full round plus a round of ONE replica
+ * on an empty chip (profiles/r04_replica_cliff.txt).  note (optional, len bytes) receives a one-paragraph advisory when nrep
+ * is not a multiple of the granule, "" otherwise.  The reference has no counterpart: its MPI ranks are independent processes
+ * (SMC.c:40, 66-95); this is the sizing rule of the batched replacement. */
+int smcx_replica_granule(smcx_handle *h, int *granule, char *note, int len);
 /* source identity of a sweep kernel of THIS library (host only, no GPU needed): 16 hex digits, the sha256 of the generated
  * body (hand-scheduled kernels) or of the source files (compiled ones) it was built from.  kernel = a name as
  * smcx_kernel_form returns it.  Measurement plumbing: profiles/kernel_counters.json records the id of the library whose

@@ -61,7 +61,7 @@ EXPORTS = [
     "smcx_rng_seed", "smcx_one_particle_moves",
     "smcx_cluster_counts", "smcx_cluster_update", "smcx_cluster_analysis", "smcx_kernel_form", "smcx_screen_bound",
     "smcx_screen_bound_int", "smcx_screen_bound_byte", "smcx_last_clock", "smcx_debug_wave_spread",
-    "smcx_debug_clk_rows", "smcx_kernel_source_id",
+    "smcx_debug_clk_rows", "smcx_kernel_source_id", "smcx_replica_granule",
 ]
 HOST_EXPORTS = ["smcx_host_sMC", "smcx_host_sMC_multi", "smcx_host_multi_error", "smcx_host_sim_free", "smcx_host_fcc_init",
                 "smcx_host_initialize_box", "smcx_host_initialize_walls", "smcx_host_box_for_N", "smcx_host_write_csv",
@@ -382,6 +382,15 @@ class Engine:
     def export_observables_device(self, dev_ptr, nbytes):
         self._chk(_lib().smcx_export_observables_device(self._h, C.c_void_p(dev_ptr), nbytes),
                   "smcx_export_observables_device")
+
+    def replica_granule(self):
+        """(replicas the device runs at once with this kernel, advisory text or "")"""
+        g = C.c_int(0)
+        buf = C.create_string_buffer(640)
+        f = _lib().smcx_replica_granule
+        f.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.c_char_p, C.c_int]
+        self._chk(f(self._h, C.byref(g), buf, 640), "smcx_replica_granule")
+        return g.value, buf.value.decode()
 
     def last_run_ms(self):
         ms = C.c_double()

@@ -886,6 +886,15 @@ def fill_p0(tag):
         s_setprio 2
         L_pre_{tag}:
         """)
+    fill_p0_end()
+
+
+def fill_p0_end():
+    if MG:   # the row fill used the registers of the merged pass's vector constants
+        E(f"""
+        v_mov_b32 v22, {s('wlp')}
+        v_mov_b32 v23, {s('stB')}
+        """)
 
 
 def rotate(tag):
@@ -1068,6 +1077,8 @@ if MG:   # the first pass of a run has no proposal: no plane for half A, no side
     s_cselect_b32 {s('wlp',1)}, 1, 0
     s_mov_b32 {s('stB')}, {s('wlp',1)}
     s_mov_b32 {s('sidesHi')}, 0
+    v_mov_b32 v22, 0
+    v_mov_b32 v23, {s('stB')}
     """)
 # rarely executed pieces of the move (zb) are gathered here, jumped over when a run starts
 COLD_AT = None
@@ -1465,6 +1476,7 @@ def z8c_check(tag, P_sgpr, w0, w1, locs, guard):
     s_waitcnt lgkmcnt(0)
     L_ck_end_{tag}:
     """)
+    fill_p0_end()     # (mg: the check used the registers of the vector constants)
 
 
 NEXCL = [0]
@@ -2188,6 +2200,7 @@ if MG:
     E("L_nofb:")
 # ---------------------------------------------------------------------------------------------- mg: both probes in one pass
 PV = ["v[14:15]", "v[16:17]", "v[18:19]"]      # mg: the probe of this lane's half (A: the proposal Q, B: particle n+1)
+KSTA, KSTB = "v22", "v23"                      # mg: wlp's low word and stB as vector constants (start values of the ranks)
 MGW = "v[20:21]"                               # mg: probe B's sums (without the side pair), in both halves
 DdNm = "v[12:13]"                              # mg: displacement of move i+1 in group layout, asked for during the pass
 
@@ -2200,10 +2213,10 @@ def mg_handover(w0, w1, h, start, off, n):
     v_cmp_ne_u64 {h}, 0, v[{w0}:{w1}]
     v_ffbl_b32 v46, v{w0}
     v_ffbl_b32 v47, v{w1}
-    v_mov_b32 v45, {start}
-    v_mbcnt_lo_u32_b32 v45, s{hlo}, v45
+    {"v_or_b32 v47, 32, v47" if start.startswith("v") else f"v_mov_b32 v45, {start}"}
+    v_mbcnt_lo_u32_b32 v45, s{hlo}, {start if start.startswith("v") else "v45"}
     v_mbcnt_hi_u32_b32 v45, s{hhi}, v45
-    v_or_b32 v47, 32, v47
+    {"" if start.startswith("v") else "v_or_b32 v47, 32, v47"}
     v_cmp_gt_u32 vcc, 32, v45
     v_min_u32 v46, v46, v47
     v_lshl_add_u64 v[48:49], v[{w0}:{w1}], 0, -1
@@ -2217,6 +2230,38 @@ def mg_handover(w0, w1, h, start, off, n):
     ds_write_b32 v45, v46 offset:{LDS_LIST + off}
     s_mov_b64 exec, -1
     """)
+
+
+def mg_handover2(tagc, w0, w1, h, start, off, n):
+    """the lanes that STILL hold a candidate after the hand-over (two of one probe in one lane: ~15 % of the probes) hand
+    that one over as well, to the working lanes behind the first batch, so that it is evaluated in the same pass instead
+    of a round of its own; what remains after that (a third candidate, a full half) sets bit 1 of nearB = "more rounds".
+    Cold piece; start (s), n (s): first working lane and count of the first batch, n is updated"""
+    def emit(txt):
+        (COLD if REDIR[0] is None else E)(txt)
+    E(f"""
+    v_cmp_ne_u64 vcc, 0, v[{w0}:{w1}]
+    s_cbranch_vccnz L_ho2{tagc}
+    L_ho2r{tagc}:
+    """)
+    save, REDIR[0] = REDIR[0], (cold if REDIR[0] is None else REDIR[0])
+    if save is not None:      # already among the cold pieces: in line, jumped over
+        E(f"s_branch L_ho2x{tagc}")
+    E(f"""
+    L_ho2{tagc}:
+    s_add_u32 {st(7)}, {start}, {n}
+    """)
+    mg_handover(w0, w1, h, st(7), off, st(7))
+    E(f"""
+    s_add_u32 {n}, {n}, {st(7)}
+    v_cmp_ne_u64 vcc, 0, v[{w0}:{w1}]
+    s_cbranch_vccz L_ho2r{tagc}
+    s_bitset1_b32 {s('nearB')}, 1
+    s_branch L_ho2r{tagc}
+    """)
+    if save is not None:
+        E(f"L_ho2x{tagc}:")
+    REDIR[0] = save
 
 
 def mg_probes():
@@ -2327,10 +2372,13 @@ def mg_round0(near):
         s_add_u32 {st(4)}, {st(4)}, {st(3)}
         """)
         startA, startB = st(2), st(4)
+        mg_handover(V['wa0'], V['wa1'], sp('hA'), startA, 0, st(5))
     else:
         startA, startB = s('wlp'), s('stB')
-    mg_handover(V['wa0'], V['wa1'], sp('hA'), startA, 0, st(5))
-    mg_handover(V['wb0'], V['wb1'], sp('hB'), startB, 128, st(6))
+        mg_handover(V['wa0'], V['wa1'], sp('hA'), KSTA, 0, st(5))
+    mg_handover2("A" + tag, V['wa0'], V['wa1'], sp('hA'), startA, 0, st(5))
+    mg_handover(V['wb0'], V['wb1'], sp('hB'), startB if near else KSTB, 128, st(6))
+    mg_handover2("B" + tag, V['wb0'], V['wb1'], sp('hB'), startB, 128, st(6))
     mg_probes()
     # this lane's item; the candidates' lanes (st(0): half A's word, st(1): half B's)
     E(f"""
@@ -2382,9 +2430,9 @@ def mg_round0(near):
     """)
     if near:   # table rows of the wall lanes of a near probe: row = lane within its half
         E(f"""
-        s_cmp_lg_u32 {s('nearA')}, 0
+        s_bitcmp1_b32 {s('nearA')}, 0
         s_cselect_b32 {st(6)}, {s('hA')}, 0
-        s_cmp_lg_u32 {s('nearB')}, 0
+        s_bitcmp1_b32 {s('nearB')}, 0
         s_cselect_b32 {st(7)}, {s('hA',1)}, 0
         v_and_b32 v46, 31, {LANE}
         v_lshlrev_b32 v46, 5, v46
@@ -2460,6 +2508,13 @@ def mg_more():
     mg_handover(V['wa0'], V['wa1'], sp('hA'), "0", 0, st(5))
     mg_handover(V['wb0'], V['wb1'], sp('hB'), "0", 128, st(6))
     E(f"""
+    s_bitset0_b32 {s('nearB')}, 1
+    v_or3_b32 v44, {v('wa0')}, {v('wa1')}, {v('wb0')}
+    v_or_b32 v44, v44, {v('wb1')}
+    v_cmp_ne_u32 vcc, 0, v44
+    s_cbranch_vccz L_mgM1
+    s_bitset1_b32 {s('nearB')}, 1
+    L_mgM1:
     ds_read_b32 v44, {KL4} offset:{LDS_LIST}
     s_bfm_b64 {stp(0)}, {st(5)}, 0
     s_bfm_b64 {stp(6)}, {st(6)}, 0
@@ -2530,10 +2585,8 @@ if MG:
     REDIR[0] = None
     E(f"""
     L_mgR0:
-    v_or3_b32 v44, {v('wa0')}, {v('wa1')}, {v('wb0')}
-    v_or_b32 v44, v44, {v('wb1')}
-    v_cmp_ne_u32 vcc, 0, v44
-    s_cbranch_vccnz L_mgMore
+    s_bitcmp1_b32 {s('nearB')}, 1
+    s_cbranch_scc1 L_mgMore
     """)
     REDIR[0] = cold
     mg_more()
@@ -2961,8 +3014,8 @@ if MG:
     s_load_dwordx2 {sp('lu')}, {sp('uK')}, {st(0)}
     s_add_u32 {st(2)}, {s('tl')}, 1
     s_mul_i32 {st(2)}, {st(2)}, 24
-    v_add_u32 v25, {st(2)}, {KC}
-    ds_read_b64 {vp('D',0)}, v25 offset:{LDS_P0}
+    v_add_u32 v49, {st(2)}, {KC}
+    ds_read_b64 {vp('D',0)}, v49 offset:{LDS_P0}
     v_mov_b32 {v('FmV')}, v20
     v_mov_b32 {v('FmV',1)}, v21
     """)
@@ -2971,10 +3024,10 @@ if MG:
     s_cbranch_scc1 L_nsr
     """)
     E(f"""
-    v_lshl_add_u32 v24, {s('accf')}, 5, {KSD}
-    ds_read_b64 v[22:23], v24 offset:{LDS_SIDEM}
+    v_lshl_add_u32 v48, {s('accf')}, 5, {KSD}
+    ds_read_b64 v[46:47], v48 offset:{LDS_SIDEM}
     s_waitcnt lgkmcnt(0)
-    v_add_f64 {vp('FmV')}, {MGW}, v[22:23]
+    v_add_f64 {vp('FmV')}, {MGW}, v[46:47]
     L_nsr:
     s_waitcnt vmcnt(0) lgkmcnt(0)
     v_mov_b32 {v('DdV')}, v12
@@ -3169,6 +3222,8 @@ if MG:   # what the next pass has: plane of half A (a proposal and walls), of ha
     s_add_u32 {s('stB')}, {s('wlp',1)}, {st(1)}
     s_mul_i32 {st(1)}, {s('hasB')}, 3
     s_lshl_b32 {s('sidesHi')}, {st(1)}, {s('wlp',1)}
+    v_mov_b32 v22, {s('wlp')}
+    v_mov_b32 v23, {s('stB')}
     s_cmp_lt_i32 {st(0)}, {s('len')}
     """)
 # the next pass has a proposal to decide (hasA) and a next particle (hasB): the steady copy runs it
@@ -3178,6 +3233,7 @@ s_mov_b32 {s('hasB')}, 0
 {f"s_mov_b32 {s('wlp',1)}, 0" if MG else ""}
 {f"s_mov_b32 {s('stB')}, 0" if MG else ""}
 {f"s_mov_b32 {s('sidesHi')}, 0" if MG else ""}
+{"v_mov_b32 v23, 0" if MG else ""}
 s_branch L_G_move
 """)
 G(f"""

@@ -196,10 +196,10 @@ static int validate(const smcx_params *p)
 
 // particles per lane (S) and wavefronts per replica (WPR): the smallest capacity 64*WPR*S
 // that holds N from a table of the geometries measured fastest on MI355X.
-// The measurement switches of the sweep kernels.  They are smcx_params fields (tune_kernel, tune_resort); the SMCX_*
-// environment variables of rounds 1-2 still exist for tools/ and A/B sessions, but only under
-// SMCX_ALLOW_ENV_TUNING=1: without it a set variable makes smcx_create fail instead of silently changing the kernel
-// a caller gets.
+// The measurement switches of the sweep kernels are smcx_params fields (tune_kernel, tune_resort, tune_slots, tune_waves).
+// The SMCX_* environment variables of rounds 1-2 exist only in VARIANT builds of this library (make VARIANT=x: -DSMCX_VARIANT,
+// libsmcx_x.so, loaded by name for an A/B session) and there only under SMCX_ALLOW_ENV_TUNING=1.  The product library and the
+// diagnostic build never read them: a set variable makes smcx_create fail instead of silently changing the kernel a caller gets.
 static const char *const k_tune_env[] = {"SMCX_MX", "SMCX_MI", "SMCX_MA", "SMCX_MB", "SMCX_MC", "SMCX_MCW", "SMCX_MZ",
                                          "SMCX_RESORT", "SMCX_ZSORT_TPB", "SMCX_LEAD", "SMCX_NO_LEAD"};
 
@@ -209,17 +209,22 @@ static int make_tune(const smcx_params *p, Tune *t)
     t->kernel = p->tune_kernel;
     t->resort = p->tune_resort > 0 ? p->tune_resort : 1;
     if (const char *e = getenv("SMCX_CHECK_MB")) t->check_mb = atoi(e); // read by the diagnostic build only (ma_cap)
+    bool allowed = false;
+#ifdef SMCX_VARIANT
     const char *allow = getenv("SMCX_ALLOW_ENV_TUNING");
-    if (!(allow && allow[0] == '1')) {
+    allowed = allow && allow[0] == '1';
+#endif
+    if (!allowed) {
         for (const char *name : k_tune_env)
             if (getenv(name)) {
                 g_last_error = std::string("environment variable ") + name +
-                               " is set but SMCX_ALLOW_ENV_TUNING=1 is not: refusing to let a stale measurement "
-                               "switch pick the kernel (use smcx_params.tune_kernel / tune_resort)";
+                               " is set: this library does not read measurement switches from the environment (use "
+                               "smcx_params.tune_kernel / tune_resort; only VARIANT builds honour SMCX_ALLOW_ENV_TUNING=1)";
                 return SMCX_ERR_PARAM;
             }
         return SMCX_OK;
     }
+#ifdef SMCX_VARIANT
     auto off = [](const char *n) { const char *e = getenv(n); return e && e[0] == '0'; };
     if (t->kernel == 0) {
         if (const char *e = getenv("SMCX_MX")) t->kernel = (e[0] == '0') ? 1 : 2;
@@ -237,6 +242,7 @@ static int make_tune(const smcx_params *p, Tune *t)
     if (const char *e = getenv("SMCX_MZ")) t->mz = (e[0] != '0');
     if (const char *e = getenv("SMCX_RESORT")) { const int v = atoi(e); if (v > 0) t->resort = v; }
     if (const char *e = getenv("SMCX_ZSORT_TPB")) { const int v = atoi(e); if (v == 128 || v == 256 || v == 512 || v == 1024) t->zsort_tpb = v; }
+#endif
     return SMCX_OK;
 }
 
@@ -498,6 +504,27 @@ extern "C" int smcx_kernel_form(const smcx_handle *hh, int *form, char *name, in
     const Handle &h = hh->h;
     if (form) *form = h.plan.form == FORM_FP64 ? 1 : 2;
     if (name && len > 0) std::snprintf(name, (size_t)len, "%s", h.plan.name);
+    return SMCX_OK;
+}
+
+extern "C" int smcx_replica_granule(smcx_handle *hh, int *granule, char *note, int len)
+{
+    if (!hh || !granule) return SMCX_ERR_PARAM;
+    Handle &h = hh->h;
+    HIPCHK(&h, hipSetDevice(h.p.device));
+    const int g = ma_resident_replicas(h.plan, h.p.device);
+    *granule = g;
+    if (note && len > 0) {
+        note[0] = 0;
+        if (g > 0 && h.p.nrep % g != 0) {
+            const int rounds = (h.p.nrep + g - 1) / g, last = h.p.nrep - (rounds - 1) * g;
+            std::snprintf(note, (size_t)len,
+                          "%d replicas with %s: the device runs %d of them at once and a sweep is sequential inside a replica, so a "
+                          "sweep takes %d rounds, the last with %d replica(s) on a nearly empty chip (a lone wavefront still needs "
+                          "about half the time of a full round).  Use a multiple of %d replicas per GPU: %d cost the same time.",
+                          h.p.nrep, h.plan.name, g, rounds, last, g, rounds * g);
+        }
+    }
     return SMCX_OK;
 }
 

@@ -105,6 +105,7 @@ hipError_t launch_sweeps_mt(const SweepArgs &s, const DevCtx &c, const KernelPla
 hipError_t launch_sweeps_mcw(const SweepArgs &s, const DevCtx &c, int WPR, int nsweeps, double A, hipStream_t st,
                              SweepTimer *tm);
 void mc_bound_values(double L, double cutoff2, double *toFix, double *zsafe, int *negT, int *RZ);
+int ma_resident_replicas(const KernelPlan &pl, int device); // replicas the device runs at once with this kernel (0: unknown)
 hipError_t launch_sweeps_ma(const SweepArgs &s, const DevCtx &c, const KernelPlan &pl, const double *wtab, int nsweeps,
                             double A, double toFix, double zFix, double zsafe, int negC, hipStream_t st, SweepTimer *tm);
 

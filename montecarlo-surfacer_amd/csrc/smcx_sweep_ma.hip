@@ -642,4 +642,33 @@ hipError_t launch_sweeps_ma(const SweepArgs &s, const DevCtx &c, const KernelPla
     return rc;
 }
 
+// how many replicas the device runs AT ONCE with this plan's kernel (workgroups resident per CU x CUs; 0 = not one of the
+// z-ordered hand-scheduled kernels).  A sweep is sequential inside a replica and one launch runs one sweep of all replicas, so
+// the time of a sweep is a step function of nrep / this number: smcx_replica_granule reports it.
+int ma_resident_replicas(const KernelPlan &pl, int device)
+{
+    const void *f = nullptr;
+    int threads = 64;
+    unsigned lds = 0;
+    if (pl.form == FORM_MC && pl.WPR == 1) {
+        f = pl.S == 64 ? (const void *)sweep_kernel_mc64 : pl.S == 32 ? (const void *)sweep_kernel_mc32 : (const void *)sweep_kernel_mc16;
+        lds = mc_lds_bytes();
+    } else if (pl.form == FORM_MB) {
+        f = (const void *)sweep_kernel_mb64; lds = mb_lds_bytes(64);
+    } else if (pl.form == FORM_MC) {
+        threads = 64 * pl.WPR; lds = mcw_lds_bytes(pl.WPR);
+        f = (pl.WPR == 4 && pl.S == 32) ? (const void *)sweep_kernel_mc32x4 : pl.WPR == 4 ? (const void *)sweep_kernel_mc64x4
+                                                                                         : (const void *)sweep_kernel_mc32x8;
+    } else if (pl.form == FORM_MT) {
+        threads = 64 * pl.WPR;
+        lds = pl.S == 16 ? mt_lds_bytes(2) + 16u * 64u * 24u + 1024u : mt_lds_bytes(pl.WPR);
+        f = pl.S == 16 ? (const void *)sweep_kernel_mt16x2 : pl.S == 32 ? (const void *)sweep_kernel_mt32x16 : (const void *)sweep_kernel_mt64x8;
+    }
+    if (!f) return 0;
+    int per_cu = 0, cus = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, f, threads, lds) != hipSuccess) return 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) return 0;
+    return per_cu * cus;
+}
+
 } // namespace smcx

@@ -2,7 +2,7 @@
 """Soak of the diagnostic build (libsmcx_check.so, SMCX_CHECK_MB=2): long, thermalising trajectories through every family of
 z-ordered sweep kernels; beside EVERY screen pass the fp64 cutoff test of EVERY cell runs on the device and counts the pairs
 inside the cutoff whose candidate bit the pass did not set.  Prints one line per case; exits 1 if any count is not zero.
-   SMCX_ALLOW_ENV_TUNING=1 python tools/soak_check.py            (through gpurun, a few minutes)
+   python tools/soak_check.py            (through gpurun, a few minutes)
 The parity suite runs the same check for 2-4 sweeps from the lattice starts (tests/test_gpu_configs.py); this runs it for
 tens of sweeps with thermalisation at 2A first, where the film has melted and the z order is rebuilt from moved particles."""
 import ctypes as C
@@ -14,7 +14,6 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 os.environ["SMCX_LIB"] = os.path.join(ROOT, "montecarlo-surfacer_amd", "libsmcx_check.so")
-os.environ["SMCX_ALLOW_ENV_TUNING"] = "1"
 os.environ["SMCX_CHECK_MB"] = "2"
 spec = importlib.util.spec_from_file_location("smcx_chk", os.path.join(ROOT, "montecarlo-surfacer_amd", "__init__.py"))
 K = importlib.util.module_from_spec(spec); spec.loader.exec_module(K)
