@@ -92,7 +92,7 @@ typedef struct smcx_params {
     int32_t lca_time;       /* LCA_TIME: cluster analysis every lca_time-th gather (SMC.h:48) */
     int32_t tune_kernel;    /* SMCX_KERNEL_*: 0 = auto; 1 = fp64 sweep kernels; 2 = screened (compact-copy) sweep
                                kernels, best form; 3..7 = the best screened form not above that rung */
-    int32_t tune_resort;    /* 0/1 = sort the cells by z before every sweep (z-ordered kernels); k = every k sweeps */
+    int32_t tune_resort;    /* sweeps per z sort of the one-wavefront z-ordered kernels: 0 = default (2), 1 = before every sweep, k */
     double lca_cutoff;      /* LCA_cutoff (SMC.h:50) */
 } smcx_params;
 

@@ -119,7 +119,10 @@ NT = " nt" if os.environ.get("SMCX_GEN_NT") == "1" else ""   # experiment: strea
 STAMPS = os.environ.get("SMCX_GEN_TT_STAMPS") == "1"        # z8t diagnostic: where a move's time goes (before / at the barrier)
 FAKE = os.environ.get("SMCX_GEN_FAKEFETCH") == "1"          # TIMING experiment only (wrong results): every candidate fetch reads cell 0
 PRIO_SHIFT = int(os.environ.get("SMCX_GEN_PRIO_SHIFT", "14"))   # ... every 2^14 ticks of the 100 MHz clock (164 us)
-Z8C = MODE in ("z8c", "z8wc", "z8tc")
+Z8C = MODE in ("z8c", "z8wc", "z8tc", "z8lc")
+# "z8l" / "z8lc": z8 with 16 cells per lane and the fp64 positions of ALL cells (24 KB) in LDS -- the few-replica form of
+# N <= 1024 (sweep_kernel_ml16): with one wavefront per SIMD nothing hides the round trip of a candidate fetch to L2
+ZL = MODE in ("z8l", "z8lc")
 # "z8w": z8 for FOUR wavefronts per replica (8192 < N <= 16384): wave w owns the cells 4096 w .. 4096 w + 4095 of the
 # z order (its own 16 groups and ranges) and runs the whole move loop itself -- same scalar state, own copy of the row
 # cache -- except that the wall sites, plane and side pair live on wave 0, a cell is written by its owner only, and
@@ -131,7 +134,7 @@ assert WPR in (1, 2, 4, 8, 16)                            # (NS = 32 with 4: 409
 KS = WPR // 2 if TT else WPR                              # slabs of the z order = wavefronts that share out the cells
 WSH = (NS * 64).bit_length() - 1                          # cell >> WSH = the wave that owns it
 SLOTF = ((NS.bit_length() - 1) << 16) | 6                 # s_bfe field of the slot inside a cell index
-Z8 = Z8C or W4 or MODE == "z8"
+Z8 = Z8C or W4 or MODE in ("z8", "z8l")
 ZB = ZBC or Z8 or MODE == "zb"
 NG = NS // 4                                              # 4-slot groups
 # The move loop is emitted twice for the z-ordered kernels: a GENERIC copy that tests hasA (a proposal to decide: not in the
@@ -150,7 +153,8 @@ MG = Z8 and not W4 and os.environ.get("SMCX_GEN_NOMERGE") != "1"      # (switch 
 # wall table live in LDS at offset 0, shared by the two wavefronts of the replica; every other LDS area moves up
 PF2 = TT and NS >= 32     # z8t with many cells: the first TWO candidates of a lane are fetched together (dense states: the
                           # second round's memory round trip was the longest stretch of the slowest wavefront's move)
-LP = TT and NS == 16
+LP = (TT and NS == 16) or ZL
+assert not ZL or NS == 16
 LDS_RS, LDS_WT = 0, NS * 64 * 24
 LDS_BASE = LDS_WT + 1024 if LP else 0
 LDS_P0 = LDS_BASE if Z8 else (NS // 2) * 256              # after the int16 z words
@@ -162,7 +166,7 @@ LDS_SIDE = LDS_X + 2 * WPR * 512                          # z8t: [2 buffers][old
 if W4:
     LDS_CNT = LDS_X + 2 * WPR * 512 + (128 if TT else 0)  # z8wc: 8 counter words per wave behind the exchange area
 LDS_TM = LDS_SIDE + 128                                   # z8t stamps variant: per wave {t0, cycles before the barrier, cycles at it}
-LDS_LIST, LDS_SIDEM = 2048, 2304                          # mg: hand-over list [64] words; side results [old, new][e, fx, fy, fz]
+LDS_LIST, LDS_SIDEM = LDS_BASE + 2048, LDS_BASE + 2304    # mg: hand-over list [64] words; side results [old, new][e, fx, fy, fz]
 LANE, KARG, REP, WAVE = "%0", "%1", "%2", "%3"
 # z8t: the slab of a wave is wave mod K (team B = waves K .. 2K-1), formed with s_and_b32 in a scratch register where
 # it is needed (the inline-asm statement has no SGPR operand to spare); otherwise slab = wave
@@ -2419,13 +2423,23 @@ def mg_round0(near):
     """)
     mg_side_sources(lane_old)
     E(f"L_nss_{tag}:")
+    if not near:   # what does not depend on the LDS reads in flight (list item, probe B, side sources) goes in front of the wait
+        coeff_one(CA_)
+        E(f"""
+        s_mov_b64 exec, {pl}
+        v_mov_b64 v[{CA_}:{CA_+1}], {sp('a0s')}
+        v_mov_b64 v[{CA_+2}:{CA_+3}], {sp('b0s')}
+        s_mov_b64 exec, -1
+        """)
+        for j in range(4):
+            E(f"v_mov_b64 {vp('acc', j)}, 0")
     E(f"""
     s_waitcnt lgkmcnt(0)
     v_mul_u32_u24 v45, 24, v44
     {"v_mov_b32 v45, 0" if FAKE else ""}
     s_mov_b64 exec, {stp(0)}
-    global_load_dwordx4 v[{XA_}:{XA_+3}], v45, {SRC}
-    global_load_dwordx2 v[{XA_+4}:{XA_+5}], v45, {SRC} offset:16
+    {f"ds_read2_b64 v[{XA_}:{XA_+3}], v45 offset1:1" if LP else f"global_load_dwordx4 v[{XA_}:{XA_+3}], v45, {SRC}"}
+    {f"ds_read_b64 v[{XA_+4}:{XA_+5}], v45 offset:16" if LP else f"global_load_dwordx2 v[{XA_+4}:{XA_+5}], v45, {SRC} offset:16"}
     s_mov_b64 exec, -1
     """)
     if near:   # table rows of the wall lanes of a near probe: row = lane within its half
@@ -2450,8 +2464,8 @@ def mg_round0(near):
     L_ndd_{tag}:
     """)
     # coefficients: 1 for the candidates, (a0, b0) for a plane, the table's for wall sites
-    coeff_one(CA_)
     if near:
+        coeff_one(CA_)
         E(f"""
         s_mov_b64 exec, {stp(6)}
         global_load_dwordx4 v[{XA_}:{XA_+3}], v46, {sp('wtab')}
@@ -2461,15 +2475,8 @@ def mg_round0(near):
         v_mov_b64 v[{CA_+2}:{CA_+3}], {sp('b0s')}
         s_mov_b64 exec, -1
         """)
-    else:
-        E(f"""
-        s_mov_b64 exec, {pl}
-        v_mov_b64 v[{CA_}:{CA_+1}], {sp('a0s')}
-        v_mov_b64 v[{CA_+2}:{CA_+3}], {sp('b0s')}
-        s_mov_b64 exec, -1
-        """)
-    for j in range(4):
-        E(f"v_mov_b64 {vp('acc', j)}, 0")
+        for j in range(4):
+            E(f"v_mov_b64 {vp('acc', j)}, 0")
     # everything that has an item: candidates, wall lanes, side lanes
     E(f"""
     s_or_b64 {stp(6)}, {stp(0)}, {wl}
@@ -2477,7 +2484,9 @@ def mg_round0(near):
     """)
     mg_wall_dz(tag)
     if near:
-        E("s_waitcnt vmcnt(0)")
+        E("s_waitcnt vmcnt(0) lgkmcnt(0)")
+    elif LP:
+        E("s_waitcnt lgkmcnt(0)")
     else:   # the candidates' positions; the displacement asked for behind them may still travel
         G("s_waitcnt vmcnt(0)")
         SO("s_waitcnt vmcnt(1)")
@@ -2522,12 +2531,12 @@ def mg_more():
     s_waitcnt lgkmcnt(0)
     v_mul_u32_u24 v45, 24, v44
     s_mov_b64 exec, {stp(0)}
-    global_load_dwordx4 v[{XA_}:{XA_+3}], v45, {SRC}
-    global_load_dwordx2 v[{XA_+4}:{XA_+5}], v45, {SRC} offset:16
+    {f"ds_read2_b64 v[{XA_}:{XA_+3}], v45 offset1:1" if LP else f"global_load_dwordx4 v[{XA_}:{XA_+3}], v45, {SRC}"}
+    {f"ds_read_b64 v[{XA_+4}:{XA_+5}], v45 offset:16" if LP else f"global_load_dwordx2 v[{XA_+4}:{XA_+5}], v45, {SRC} offset:16"}
     s_mov_b64 exec, -1
     """)
     coeff_one(CA_)
-    E("s_waitcnt vmcnt(0)")
+    E("s_waitcnt vmcnt(0) lgkmcnt(0)")
     body("mm", PV, XA_, CA_, stp(0), False)
     E("s_branch L_mgR0")
 
@@ -2575,7 +2584,17 @@ def mg_reduce():
 
 
 if MG:
+    # log-uniform of move i+1 (scalar load into nxy:nzl, whose run-start values the first pass has consumed by now): it
+    # travels during the whole pass; lu itself is still this move's until the decision
+    G(f"""
+    s_cmp_eq_u32 {s('hasB')}, 0
+    s_cbranch_scc1 L_nolu
+    """)
     E(f"""
+    s_add_u32 {st(1)}, {s('i')}, 1
+    s_lshl_b32 {st(0)}, {st(1)}, 3
+    s_load_dwordx2 {sp('nxy')}, {sp('uK')}, {st(0)}
+    L_nolu:
     s_or_b32 {st(0)}, {s('nearA')}, {s('nearB')}
     s_cbranch_scc1 L_mgN
     """)
@@ -3009,9 +3028,7 @@ G("s_cbranch_scc1 L_noB")
 if MG:
     # ---- Fm of particle n+1 = probe B's sums + the side result that applies; then its proposal, in group layout
     E(f"""
-    s_add_u32 {st(1)}, {s('i')}, 1
-    s_lshl_b32 {st(0)}, {st(1)}, 3
-    s_load_dwordx2 {sp('lu')}, {sp('uK')}, {st(0)}
+    s_mov_b64 {sp('lu')}, {sp('nxy')}
     s_add_u32 {st(2)}, {s('tl')}, 1
     s_mul_i32 {st(2)}, {st(2)}, 24
     v_add_u32 v49, {st(2)}, {KC}

@@ -207,7 +207,9 @@ static int make_tune(const smcx_params *p, Tune *t)
 {
     *t = Tune();
     t->kernel = p->tune_kernel;
-    t->resort = p->tune_resort > 0 ? p->tune_resort : 1;
+    // sweeps per z sort of the one-wavefront z-ordered kernels: 2 by default (the sort saved outweighs the wider group
+    // ranges of the second sweep: 9.75 against 9.90 ms per step at config 3, profiles/r04_config2_forms.txt; 1 in round 3)
+    t->resort = p->tune_resort > 0 ? p->tune_resort : 2;
     if (const char *e = getenv("SMCX_CHECK_MB")) t->check_mb = atoi(e); // read by the diagnostic build only (ma_cap)
     bool allowed = false;
 #ifdef SMCX_VARIANT
@@ -300,7 +302,10 @@ static int choose_geometry(const smcx_params *p, const Tune &t, int *S, int *WPR
         // the replicas the one-probe-after-the-other forms win: 50 against 57 ms, 1.89 against 2.24)
         if (p->tune_kernel == 0 || p->tune_kernel == SMCX_KERNEL_SCREENED) {
             if (p->N > 8192 && (long)p->nrep * 8 <= 2048 && plan_for(p, 64, 8, t, &pl) && pl.form == FORM_MT) { s = 64; w = 8; one_wave = true; }
-            if (p->N <= 1024 && p->nrep <= 1024 && plan_for(p, 16, 2, t, &pl) && pl.form == FORM_MT) { s = 16; w = 2; one_wave = true; }
+            // (N <= 1024 with at most 1024 replicas ran the two-team form 16 x 2 in round 3; round 4's one-wavefront kernel
+            // with both probes in one pass and the cells' positions in LDS, sweep_kernel_ml16, is faster: 1.27 against 1.31 ms
+            // per sweep at 1024 replicas, 1.26 against 1.36 at 512 -- profiles/r04_config2_forms.txt; 16 x 2 stays available
+            // through tune_kernel = SMCX_KERNEL_MT or tune_slots / tune_waves)
         }
         while (!one_wave && (long)p->nrep * w < 2048 && s > 16 && w < 8 && geometry_supported(s / 2, w * 2)) { s /= 2; w *= 2; }
     } else {
@@ -384,6 +389,13 @@ extern "C" int smcx_create(const smcx_params *p, smcx_handle **out)
     rc = choose_geometry(p, tune, &h.S, &h.WPR);
     if (rc == SMCX_OK && !plan_for(p, h.S, h.WPR, tune, &h.plan)) rc = SMCX_ERR_UNSUPPORTED;
     if (rc != SMCX_OK) { delete hh; return rc; }
+    // few replicas of N <= 1024 through the one-wavefront kernel (at most one wavefront per SIMD): the form that keeps the
+    // fp64 positions of all cells in LDS, sweep_kernel_ml16 -- nothing else would hide a candidate fetch's trip to L2
+    if (h.plan.form == FORM_MC && h.plan.S == 16 && h.plan.WPR == 1 && p->nrep <= 1024 &&
+        (p->tune_kernel == 0 || p->tune_kernel == SMCX_KERNEL_SCREENED)) {
+        h.plan.lpos = true;
+        h.plan.name = ma_kernel_name(FORM_MC, 16, -1);
+    }
 
     // sweeps of random numbers kept on the device at once: bounded by ~6 GB
     const double per_sweep = (double)p->nrep * (32.0 * p->N + 8);

@@ -66,6 +66,7 @@ struct KernelPlan {
     int form = FORM_NONE, S = 0, WPR = 0;
     int zs = 0;          // z unit shift of the integer screen (FORM_MI and above)
     bool lead = false, mz = false;
+    bool lpos = false;   // sweep_kernel_ml16: mc16 with the cells' fp64 positions in LDS (few replicas of N <= 1024)
     Tune tune;
     const char *name = ""; // the launched instantiation as rocprofv3 prints it
     bool zordered() const { return form >= FORM_MB; } // needs Rs, loc and the z sort

@@ -162,6 +162,23 @@ __global__ void __launch_bounds__(64, 6) sweep_kernel_mc16(MaArgs a)
         :
         : "memory", "vcc", "scc", "m0", SMCX_MA_SGPRS, SMCX_MA_V79);
 }
+// sweep_kernel_mc16 with the fp64 positions of all 1024 cells in LDS (gen_sweep_ma.py ... z8l): the few-replica form of
+// N <= 1024 -- with one wavefront per SIMD nothing hides a candidate fetch's round trip to L2, so the candidates come from LDS
+__global__ void __launch_bounds__(64, 2) sweep_kernel_ml16(MaArgs a)
+{
+    unsigned lane = threadIdx.x;
+    unsigned long long kp = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
+    unsigned rep = blockIdx.x;
+    asm volatile(
+#ifdef SMCX_CHECK
+#include "smcx_sweep_mlc_body16.inc"
+#else
+#include "smcx_sweep_ml_body16.inc"
+#endif
+        : "+v"(lane), "+s"(kp), "+s"(rep)
+        :
+        : "memory", "vcc", "scc", "m0", SMCX_MA_SGPRS, SMCX_MA_V79);
+}
 // four wavefronts per replica (8192 < N <= 16384; gen_sweep_ma.py ... z8w): wave w owns the cells 4096 w .. of the
 // z order; LDS = four copies of the row cache (2048 B apart) + the exchange area of the reductions (2 x 2048 B)
 __global__ void __launch_bounds__(256, 1) sweep_kernel_mc64x4(MaArgs a)
@@ -282,6 +299,8 @@ constexpr unsigned mcw_lds_bytes(int wpr) { return (unsigned)wpr * 2048u + 2u * 
 // sweep_kernel_mc16/32/64: the row cache (65 x 24 B; the diagnostic build's counters behind it), then at 2048 the hand-over
 // list of the merged pass (64 words) and at 2304 the side pair's results (64 B): gen_sweep_ma.py LDS_LIST, LDS_SIDEM
 constexpr unsigned mc_lds_bytes() { return 2304u + 64u; }
+// sweep_kernel_ml16: the positions of the 1024 cells (24 KB) and the wall table's room (1 KB) in front of that
+constexpr unsigned ml_lds_bytes() { return 16u * 64u * 24u + 1024u + mc_lds_bytes(); }
 
 // Order of the cells for sweep_kernel_mb.  Cell = slot * 64 + lane; a group = 4 slots = 256 cells.
 //  1. the particles of a replica sorted by z (bitonic sort of (float z, particle) keys in LDS): group g holds
@@ -569,6 +588,7 @@ const char *ma_kernel_name(int form, int S, int WPR)
     if (form == FORM_MC && WPR == 4 && S == 32) return "smcx::sweep_kernel_mc32x4";
     if (form == FORM_MC && WPR == 4) return "smcx::sweep_kernel_mc64x4";
     if (form == FORM_MC && WPR == 8) return "smcx::sweep_kernel_mc32x8";
+    if (form == FORM_MC && WPR == -1) return "smcx::sweep_kernel_ml16";   // (asked for with WPR = -1: positions in LDS)
     if (form == FORM_MC) return S == 64 ? "smcx::sweep_kernel_mc64" : S == 32 ? "smcx::sweep_kernel_mc32" : "smcx::sweep_kernel_mc16";
     if (form == FORM_MB) return "smcx::sweep_kernel_mb64";
     return S == 64 ? "smcx::sweep_kernel_ma64" : S == 32 ? "smcx::sweep_kernel_ma32" : "smcx::sweep_kernel_ma16";
@@ -624,7 +644,10 @@ hipError_t launch_sweeps_ma(const SweepArgs &s, const DevCtx &c, const KernelPla
             else if (mc && S == 32)
                 hipLaunchKernelGGL(sweep_kernel_mc32, dim3(c.nrep), dim3(64), mc_lds_bytes(), st, a);
             else if (mc)
-                hipLaunchKernelGGL(sweep_kernel_mc16, dim3(c.nrep), dim3(64), mc_lds_bytes(), st, a);
+                if (pl.lpos)
+                    hipLaunchKernelGGL(sweep_kernel_ml16, dim3(c.nrep), dim3(64), ml_lds_bytes(), st, a);
+                else
+                    hipLaunchKernelGGL(sweep_kernel_mc16, dim3(c.nrep), dim3(64), mc_lds_bytes(), st, a);
             else
                 hipLaunchKernelGGL(sweep_kernel_mb64, dim3(c.nrep), dim3(64), mb_lds_bytes(64), st, a);
             rc = hipGetLastError();
@@ -653,6 +676,7 @@ int ma_resident_replicas(const KernelPlan &pl, int device)
     if (pl.form == FORM_MC && pl.WPR == 1) {
         f = pl.S == 64 ? (const void *)sweep_kernel_mc64 : pl.S == 32 ? (const void *)sweep_kernel_mc32 : (const void *)sweep_kernel_mc16;
         lds = mc_lds_bytes();
+        if (pl.lpos) { f = (const void *)sweep_kernel_ml16; lds = ml_lds_bytes(); }
     } else if (pl.form == FORM_MB) {
         f = (const void *)sweep_kernel_mb64; lds = mb_lds_bytes(64);
     } else if (pl.form == FORM_MC) {

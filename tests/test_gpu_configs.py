@@ -272,7 +272,8 @@ def test_hand_scheduled_kernel_matches_compiled_kernel(S, O, tmp_path, N, lat, n
     # the z-ordered forms (cells in z order, only the groups in reach screened): the default for this box, one word
     # per cell (int8 x, y + int16 z) screened by v_dot4_i32_i8; and with 64 particles per lane also int16 x,y in
     # registers + int16 z in LDS
-    assert str(out["mc"]["name"]) == "smcx::sweep_kernel_mc%d" % slots
+    # (few replicas of N <= 1024: the form of mc16 with the cells' positions in LDS)
+    assert str(out["mc"]["name"]) == ("smcx::sweep_kernel_ml16" if slots == 16 and nrep <= 1024 else "smcx::sweep_kernel_mc%d" % slots)
     if slots == 64:
         assert str(out["mb"]["name"]) == "smcx::sweep_kernel_mb64"
     for tag in out:
@@ -288,7 +289,7 @@ def test_several_sweeps_per_launch_between_sorts(S, O, tmp_path):
     """tune_resort = 3: the z sort runs every third sweep and the sweep kernel loops over the sweeps of a launch itself
     (group ranges widened by three sweeps of moves, energy carried in a register, per-sweep records): same chains
     as with a sort before every sweep, to rounding (the cells differ, so the sums associate differently)."""
-    out = {tag: _run_form(S, 4096, (8, 16), 64, 7, 64, resort=resort) for tag, resort in (("every", 0), ("third", 3))}
+    out = {tag: _run_form(S, 4096, (8, 16), 64, 7, 64, resort=resort) for tag, resort in (("every", 1), ("third", 3))}
     assert str(out["third"]["name"]) == "smcx::sweep_kernel_mc64"
     k = 4
     assert np.array_equal(out["every"]["jj"][:, :k], out["third"]["jj"][:, :k]) and out["every"]["jj"].sum() > 0
@@ -417,7 +418,8 @@ def test_ranged_screen_sets_every_bit_of_the_full_screen(tmp_path, N, lat, nrep,
 @pytest.mark.parametrize("N,lat,nrep,nsw,gl,slots,waves,kernel", [
     (4096, (8, 16), 64, 4, 2, 64, 1, "mc64"), (4000, (10, 10), 32, 3, 1, 64, 1, "mc64"), (2100, (5, 21), 32, 3, 3, 64, 1, "mc64"),
     (4096, (16, 4), 16, 2, 1, 64, 1, "mc64"),
-    (1024, (8, 4), 64, 4, 2, 16, 1, "mc16"), (1000, (5, 10), 32, 3, 1, 16, 1, "mc16"),          # config 2's kernel
+    (1024, (8, 4), 64, 4, 2, 16, 1, "ml16"), (1000, (5, 10), 1100, 2, 1, 16, 1, "mc16"),        # N <= 1024: few replicas (positions
+                                                                                                # in LDS) / many
     (2048, (8, 8), 32, 3, 1, 32, 1, "mc32"),
     (16384, (16, 16), 4, 2, 1, 64, 4, "mc64x4"), (16384, (16, 16), 4, 2, 1, 32, 8, "mc32x8"),   # config 5's kernels
     (9000, (15, 10), 4, 2, 2, 64, 4, "mc64x4"), (10000, (10, 25), 4, 2, 1, 32, 8, "mc32x8"),    # ragged, tall

@@ -733,7 +733,7 @@ def test_wall_grids_other_than_3x3_against_oracle(S, O, M, N, lat, slots, waves)
     nsw, nrep = 2, 2
     p = S.default_params(N, nrep, M=M, flags=S.FLAGS_REFERENCE | S.FLAG_SERIES, tune_slots=slots, tune_waves=waves)
     with S.Engine(p) as eng:
-        want = {(16, 2): "mt16x2", (64, 8): "mt64x8", (32, 4): "mc32x4"}.get((slots, waves), "mc%d" % slots)
+        want = {(16, 2): "mt16x2", (64, 8): "mt64x8", (32, 4): "mc32x4", (16, 1): "ml16"}.get((slots, waves), "mc%d" % slots)
         assert eng.kernel_form[1] == "smcx::sweep_kernel_" + want, eng.kernel_form
         eng.upload(R0.ravel(), W)
         eng.run(0, nsw, 1)

@@ -65,12 +65,12 @@ def _state(O, case):
     if case == "resort_3":            # three sweeps per z sort: group ranges widened by two sweeps of accepted moves
         L, Lz = 33.0, 240.0
         return O.fcc(8, 16, L=L), L, Lz, None, "mc64", {"tune_resort": 3}
-    if case == "mc16_dense":          # N = 1024 dense film through sweep_kernel_mc16 (config 2's kernel)
-        L, Lz = 33.0, 240.0
+    if case in ("mc16_dense", "ml16_dense"):   # N = 1024 dense film through sweep_kernel_mc16 (asked for by name) and through
+        L, Lz = 33.0, 240.0                    # sweep_kernel_ml16, which the plan gives few replicas of N <= 1024 (positions in LDS)
         R = O.fcc(16, 1, L=L).reshape(-1, 3).copy()
         R[:, 2] = 0.9 * rs.standard_normal(len(R))                      # a rough monolayer: overlaps, rejections
         R += 0.05 * rs.standard_normal(R.shape)
-        return _wrap(R, L).ravel(), L, Lz, None, "mc16", {}
+        return _wrap(R, L).ravel(), L, Lz, None, case[:4], ({"tune_kernel": 7} if case == "mc16_dense" else {})
     if case == "mc32_two_slabs":      # N = 2000 ragged, two slabs, through sweep_kernel_mc32
         L, Lz = 33.0, 240.0
         R = O.fcc(8, 8, L=L).reshape(-1, 3)[:2000].copy()
@@ -96,8 +96,8 @@ def _tt_state(O, case):
     if case == "mt16x2_benchmark":
         return O.fcc(8, 4), 33.0, 240.0, None, "mt16x2", {}
     if case == "mt16x2_dense":
-        R0, L, Lz, mode, _, extra = _state(O, "mc16_dense")
-        return R0, L, Lz, mode, "mt16x2", extra
+        R0, L, Lz, mode, _, _ = _state(O, "ml16_dense")
+        return R0, L, Lz, mode, "mt16x2", {}
     if case == "mt16x2_ragged_no_walls":
         rs = np.random.RandomState(5)
         R = O.fcc(8, 4).reshape(-1, 3)[:900].copy()
@@ -122,7 +122,7 @@ TT_CASES = ["mt16x2_benchmark", "mt16x2_dense", "mt16x2_ragged_no_walls", "mt16x
             "mt32x16_benchmark", "mt32x16_two_slabs"]
 
 CASES = ["dense_film", "dense_film_at_wall", "thin_film", "two_slabs_ragged", "unsafe_z_mb64", "unsafe_z_ma64", "resort_3", "mc16_dense",
-         "mc32_two_slabs", "mc32x4_dense", "mc64x4_two_slabs"]
+         "ml16_dense", "mc32_two_slabs", "mc32x4_dense", "mc64x4_two_slabs"]
 
 
 @pytest.mark.parametrize("case", CASES + TT_CASES)
@@ -131,7 +131,7 @@ def test_rare_path_against_oracle(S, O, case):
     N = R0.size // 3
     nrep, eq, nsw = 2, 0, (3 if case == "resort_3" else 4 if N <= 1024 else 2 if N <= 2304 else 1)
     flags = S.FLAG_SERIES | (S.FLAG_E0_RESTART if mode == "nowalls" else S.FLAGS_REFERENCE)
-    geom = {"mc64": (64, 1), "mb64": (64, 1), "ma64": (64, 1), "mc32": (32, 1), "mc16": (16, 1), "mc32x4": (0, 0),
+    geom = {"mc64": (64, 1), "mb64": (64, 1), "ma64": (64, 1), "mc32": (32, 1), "mc16": (16, 1), "ml16": (16, 1), "mc32x4": (0, 0),
             "mc64x4": (64, 4), "mt16x2": (16, 2), "mt64x8": (64, 8), "mt32x16": (32, 16)}[kernel]
     p = S.default_params(N, nrep, L=L, Lz=Lz, flags=flags, tune_slots=geom[0], tune_waves=geom[1], **extra)
     with S.Engine(p) as eng:

@@ -28,8 +28,10 @@ for f in glob.glob(os.path.join(d, "*", "*", "*_counter_collection.csv")):
         e["launch_ns"][cnt] = ns
 for name, e in res.items():
     c = e["counters"]
-    if "kernel_mb" in name or "kernel_mc" in name or "kernel_mt" in name:      # one launch per z sort: tune_resort sweeps (default 1)
-        sweeps = int(os.environ.get("SMCX_RESORT", "1"))
+    if "kernel_mt" in name or ("kernel_mc" in name and "x" in name.split("kernel_")[1]):   # several wavefronts per replica:
+        sweeps = 1                                                                          # a z sort and a launch per sweep
+    elif "kernel_mb" in name or "kernel_mc" in name or "kernel_ml" in name:   # one launch per z sort: tune_resort sweeps (default 2)
+        sweeps = int(os.environ.get("SMCX_RESORT", "2"))
     moves = float(nrep) * sweeps * N * wpr              # wave-moves: every wavefront of a replica runs every move
     e["workload"] = {"N": N, "replicas": nrep, "sweeps_in_launch": sweeps, "wave_moves": moves, "waves_per_replica": wpr}
     if "SQ_ACTIVE_INST_VALU" in c and "SQ_BUSY_CYCLES" in c:
