@@ -148,7 +148,9 @@ PEEL = ZB and os.environ.get("SMCX_GEN_NOPEEL") != "1"
 # kernels), then the candidates in the order of their owner lanes.  One body, ONE reduction (4 accumulators x 2 halves -> 8
 # sums in 8-lane groups: e | fy in row 0, fx | fz in row 1 of each half), Metropolis and proposal in that "group layout".
 # Per move ~130 instructions fewer than two probes one after the other (of ~540).
-MG = Z8 and not W4 and os.environ.get("SMCX_GEN_NOMERGE") != "1"      # (switch for the A/B: SMCX_GEN_NOMERGE=1)
+MG = Z8 and not TT and os.environ.get("SMCX_GEN_NOMERGE") != "1"      # (switch for the A/B: SMCX_GEN_NOMERGE=1)
+# ... also with several wavefronts per replica (z8w): every wave merges the two probes over ITS cells; the 8 sums of the waves
+# are added in ONE exchange per move (two before); the wall sites, planes and the side pair work on the slab-0 wave
 # z8t with 16 cells per lane ("LP"): the fp64 positions of all cells (24 KB, what candidates are fetched from) and the
 # wall table live in LDS at offset 0, shared by the two wavefronts of the replica; every other LDS area moves up
 PF2 = TT and NS >= 32     # z8t with many cells: the first TWO candidates of a lane are fetched together (dense states: the
@@ -164,9 +166,12 @@ LDS_WAVE = 2048                                           # z8w: each wave's cop
 LDS_X = LDS_BASE + WPR * LDS_WAVE                         # z8w: exchange area [2 buffers][WPR waves][64 lanes] doubles
 LDS_SIDE = LDS_X + 2 * WPR * 512                          # z8t: [2 buffers][old, new][e, fx, fy, fz] of the side pair
 if W4:
-    LDS_CNT = LDS_X + 2 * WPR * 512 + (128 if TT else 0)  # z8wc: 8 counter words per wave behind the exchange area
+    LDS_CNT = LDS_X + 2 * WPR * 512 + 128                 # z8wc: 8 counter words per wave behind the exchange and side areas
 LDS_TM = LDS_SIDE + 128                                   # z8t stamps variant: per wave {t0, cycles before the barrier, cycles at it}
 LDS_LIST, LDS_SIDEM = LDS_BASE + 2048, LDS_BASE + 2304    # mg: hand-over list [64] words; side results [old, new][e, fx, fy, fz]
+if W4 and not TT:   # z8w: the list inside the wave's own block (behind its row cache; addressed through v1), the side results
+    LDS_LIST = 1600                                       # -- [2 buffers by the parity of the move] -- behind the exchange area
+    LDS_SIDEM = LDS_X + 2 * WPR * 512
 LANE, KARG, REP, WAVE = "%0", "%1", "%2", "%3"
 # z8t: the slab of a wave is wave mod K (team B = waves K .. 2K-1), formed with s_and_b32 in a scratch register where
 # it is needed (the inline-asm statement has no SGPR operand to spare); otherwise slab = wave
@@ -226,6 +231,8 @@ if MG:
     # lanes' bits in the high word; nearA / nearB: the probe is within the cutoff of a wall (its sites join in: cold path);
     # a0s, b0s: the plane's coefficients; hA, hB: scratch pairs; accf: this move was accepted
     S.update(hA=78, a0s=80, b0s=82, hB=84, znear=86, wlp=48, stB=57, sidesHi=58, nearA=60, nearB=62, accf=64)
+    if W4:   # the real cells of this wave move to azz (the merged pass needs no hasAw; M2w and hasAw are never written: the
+        S.update(Nw=S['azz'])   # state of the pass -- wlp, stB, sidesHi -- is per wave, empty off the slab-0 wave)
 if TT:
     # team B's waves never use probe A's masks: haveA's low word holds the lane of the side pair evaluated with the
     # PROPOSAL (sideL: with n's current position); its high word carries the accept flag from the Metropolis step to
@@ -326,8 +333,8 @@ else:
         s_add_u32 {s('Nw')}, {st(6)}, {st(5)}
         s_min_i32 {s('Nw')}, {s('Nw')}, {NS * 64}
         {f"s_and_b32 {st(0)}, {WAVE}, {KS - 1}" if TT else ""}
-        s_cmp_eq_u32 {st(0) if TT else WAVE}, 0
-        s_cselect_b32 {s('M2w')}, {s('M2')}, -1
+        {"" if MG else f"s_cmp_eq_u32 {st(0) if TT else WAVE}, 0"}
+        {"" if MG else f"s_cselect_b32 {s('M2w')}, {s('M2')}, -1"}
         s_mul_i32 {st(0)}, {WAVE}, {LDS_WAVE}
         v_mov_b32 v1, {st(0)}
         """)
@@ -418,7 +425,7 @@ if not ZB:
 # per-lane constant of the row layout: 8 (row - 1) for rows 1..3 (components x, y, z), 0 for row 0 -- where a register is
 # free for it (z8 with one wavefront: v1, which holds the z words' address in the other forms; two teams: KPROW)
 KROW = "v1" if (Z8 and not W4 and not MG) else None
-KC, KL4, KSD = "v1", "v10", "v11"    # mg: per-lane constants of the group layout (below)
+KC, KL4, KSD = ("v24" if W4 else "v1"), "v10", "v11"    # mg: per-lane constants of the group layout (below; z8w: v1 = the wave's LDS block)
 if MG:
     # group layout: in either half, row 0 = [e | fy], row 1 = [fx | fz] in 8-lane groups.  KC = byte offset of the lane's
     # component in a position / displacement triple (x 0, y 8, z 16; the e group idles along with x); KSD = 8 x index of its
@@ -439,7 +446,7 @@ if MG:
     v_lshlrev_b32 {KC}, v15, v16
     v_lshl_add_u32 v16, v14, 1, v15
     v_lshlrev_b32 {KSD}, 3, v16
-    v_lshlrev_b32 {KL4}, 2, {LANE}
+    {f"v_lshl_add_u32 {KL4}, {LANE}, 2, v1" if W4 else f"v_lshlrev_b32 {KL4}, 2, {LANE}"}
     s_waitcnt lgkmcnt(0)
     """)
 if KROW:
@@ -718,11 +725,11 @@ def compact_row(xyd, zld, locv):
     v_lshl_or_b32 v28, v29, 16, v28
     v_lshl_or_b32 {zld}, {locv}, 17, v28
     """)
-    if MG:   # bit 29: within the cutoff of a wall (or beyond it)
+    if MG:   # bit 31: within the cutoff of a wall (or beyond it)
         E(f"""
         v_cmp_nlt_f64 vcc, |v[20:21]|, {sp('znear')}
         v_cndmask_b32 v29, 0, 1, vcc
-        v_lshl_or_b32 {zld}, v29, 29, {zld}
+        v_lshl_or_b32 {zld}, v29, 31, {zld}
         """)
 
 
@@ -899,6 +906,13 @@ def fill_p0_end():
         v_mov_b32 v22, {s('wlp')}
         v_mov_b32 v23, {s('stB')}
         """)
+        if W4:
+            E(f"""
+            v_bfe_u32 v14, {LANE}, 3, 1
+            v_bfe_u32 v15, {LANE}, 4, 1
+            v_lshlrev_b32 v16, 3, v14
+            v_lshlrev_b32 {KC}, v15, v16
+            """)
 
 
 def rotate(tag):
@@ -1062,7 +1076,7 @@ else:
 E(f"""
 s_mov_b32 {s('i')}, -1
 s_mov_b32 {s('hasA')}, 0
-{f"s_mov_b32 {s('hasAw')}, 0" if W4 else ""}
+{f"s_mov_b32 {s('hasAw')}, 0" if (W4 and not MG) else ""}
 s_mov_b32 {s('hasB')}, 1
 {"" if Z8 else f"s_mov_b32 {s('azz')}, 0"}
 {"" if Z8 else f"s_mov_b32 {s('az16')}, 0"}
@@ -1079,6 +1093,8 @@ if MG:   # the first pass of a run has no proposal: no plane for half A, no side
     s_mov_b32 {s('wlp')}, 0
     s_cmp_ge_i32 {s('M2')}, 0
     s_cselect_b32 {s('wlp',1)}, 1, 0
+    {f"s_cmp_eq_u32 {WAVE}, 0" if W4 else ""}
+    {f"s_cselect_b32 {s('wlp',1)}, {s('wlp',1)}, 0" if W4 else ""}
     s_mov_b32 {s('stB')}, {s('wlp',1)}
     s_mov_b32 {s('sidesHi')}, 0
     v_mov_b32 v22, 0
@@ -1171,8 +1187,8 @@ else:
   v_readlane_b32 {st(1)}, {v('rzl')}, {s('tl')}
   L_bjoin:
   s_bfe_u32 {s('ub')}, {st(1)}, 0x10010
-  {f"s_bfe_u32 {s('nearB')}, {st(1)}, 0x1001d" if MG else ""}
-  {f"s_bfe_u32 {s('locB')}, {st(1)}, 0xc0011" if MG else f"s_lshr_b32 {s('locB')}, {st(1)}, 17"}
+  {f"s_lshr_b32 {s('nearB')}, {st(1)}, 31" if MG else ""}
+  {f"s_bfe_u32 {s('locB')}, {st(1)}, 0xe0011" if MG else f"s_lshr_b32 {s('locB')}, {st(1)}, 17"}
   {"" if Z8 else f"s_and_b32 {st(1)}, {st(1)}, 0xffff"}
   {"" if Z8 else f"s_mul_i32 {s('bzz')}, {st(1)}, 0x10001"}
   L_nob1:
@@ -2227,7 +2243,7 @@ def mg_handover(w0, w1, h, start, off, n):
     s_and_b64 {h}, {h}, vcc
     v_lshl_or_b32 v46, v46, 6, {LANE}
     s_bcnt1_i32_b64 {n}, {h}
-    v_lshlrev_b32 v45, 2, v45
+    {"v_lshl_add_u32 v45, v45, 2, v1" if W4 else "v_lshlrev_b32 v45, 2, v45"}
     s_mov_b64 exec, {h}
     v_and_b32 v{w0}, v{w0}, v48
     v_and_b32 v{w1}, v{w1}, v49
@@ -2273,7 +2289,7 @@ def mg_probes():
     E(f"""
     s_add_u32 {st(7)}, {s('tl')}, 1
     s_mul_i32 {st(7)}, {st(7)}, 24
-    v_mov_b32 v44, {st(7)}
+    {f"v_add_u32 v44, {st(7)}, v1" if W4 else f"v_mov_b32 v44, {st(7)}"}
     v_mov_b64 {PV[0]}, {sp('Q',0)}
     v_mov_b64 {PV[1]}, {sp('Q',1)}
     v_mov_b64 {PV[2]}, {sp('Q',2)}
@@ -2322,7 +2338,7 @@ def mg_side_sources(lane_old):
     proposal Q; both evaluate against probe B (particle n+1)"""
     E(f"""
     s_mul_i32 {st(7)}, {s('tl')}, 24
-    v_mov_b32 v47, {st(7)}
+    {f"v_add_u32 v47, {st(7)}, v1" if W4 else f"v_mov_b32 v47, {st(7)}"}
     s_lshl_b64 exec, 1, {lane_old}
     ds_read_b64 v[{XA_}:{XA_+1}], v47 offset:{LDS_P0}
     ds_read_b64 v[{XA_+2}:{XA_+3}], v47 offset:{LDS_P0 + 8}
@@ -2341,11 +2357,13 @@ def mg_side_capture(sides, lane_old):
     [old, new][e, fx, fy, fz] -- and are zeroed: the reduction carries probe B WITHOUT the pair (n, n+1)"""
     a = [vp('acc', j) for j in range(4)]
     E(f"""
+    {f"s_and_b32 {st(7)}, {s('i')}, 1" if W4 else ""}
+    {f"s_lshl_b32 {st(7)}, {st(7)}, 6" if W4 else ""}
     s_mov_b64 exec, {sides}
     v_cmp_ne_u32 vcc, {lane_old}, {LANE}
-    v_mov_b32 v44, 0
     s_nop 1
     v_cndmask_b32 v44, 0, 32, vcc
+    {f"v_add_u32 v44, {st(7)}, v44" if W4 else ""}
     ds_write_b64 v44, {a[0]} offset:{LDS_SIDEM}
     ds_write_b64 v44, {a[1]} offset:{LDS_SIDEM + 8}
     ds_write_b64 v44, {a[2]} offset:{LDS_SIDEM + 16}
@@ -2368,6 +2386,8 @@ def mg_round0(near):
         E(f"""
         L_mgN:
         s_add_u32 {st(0)}, {s('M2')}, 1
+        {f"s_cmp_eq_u32 {WAVE}, 0" if W4 else ""}
+        {f"s_cselect_b32 {st(0)}, {st(0)}, 0" if W4 else ""}
         s_cmp_lg_u32 {s('nearA')}, 0
         s_cselect_b32 {st(2)}, {st(0)}, {s('wlp')}
         s_cmp_lg_u32 {s('nearB')}, 0
@@ -2573,6 +2593,32 @@ def mg_reduce():
         v_mov_b32_dpp v45, v{a[0]+1} {ctrl} row_mask:0xf bank_mask:0xf bound_ctrl:1
         v_add_f64 {dst}, {dst}, v[44:45]
         """)
+    if W4:
+        # the ONE exchange of a move: every wave writes its 8 partial sums, s_barrier, every wave adds the waves' partials in
+        # wave order -- bit-identical totals on all waves, so all take the same Metropolis decision.  Two buffers alternate
+        # with the parity of the move counter: a wave already in the next move cannot overwrite what a slower one still reads.
+        E(f"""
+        s_and_b32 {st(1)}, {s('i')}, 1
+        s_mul_i32 {st(1)}, {st(1)}, {WPR * 512}
+        s_lshl_b32 {st(0)}, {WAVE}, 9
+        s_add_u32 {st(0)}, {st(0)}, {st(1)}
+        v_lshl_add_u32 v44, {LANE}, 3, {st(0)}
+        v_lshl_add_u32 v45, {LANE}, 3, {st(1)}
+        ds_write_b64 v44, {dst} offset:{LDS_X}
+        s_waitcnt lgkmcnt(0)
+        s_barrier
+        """)
+        for k in range(0, WPR, 4):           # four partial sums at a time in v36..v43
+            for j in range(4):
+                E(f"ds_read_b64 v[{36 + 2 * j}:{37 + 2 * j}], v45 offset:{LDS_X + 512 * (k + j)}")
+            E("s_waitcnt lgkmcnt(0)")
+            if k == 0:
+                E(f"v_add_f64 {dst}, v[36:37], v[38:39]")
+            else:
+                E(f"v_add_f64 {dst}, {dst}, v[36:37]")
+                E(f"v_add_f64 {dst}, {dst}, v[38:39]")
+            E(f"v_add_f64 {dst}, {dst}, v[40:41]")
+            E(f"v_add_f64 {dst}, {dst}, v[42:43]")
     E(f"""
     v_mov_b32 v20, v{a[0]}
     v_mov_b32 v21, v{a[0]+1}
@@ -3031,17 +3077,20 @@ if MG:
     s_mov_b64 {sp('lu')}, {sp('nxy')}
     s_add_u32 {st(2)}, {s('tl')}, 1
     s_mul_i32 {st(2)}, {st(2)}, 24
-    v_add_u32 v49, {st(2)}, {KC}
+    {f"v_add3_u32 v49, {st(2)}, {KC}, v1" if W4 else f"v_add_u32 v49, {st(2)}, {KC}"}
     ds_read_b64 {vp('D',0)}, v49 offset:{LDS_P0}
     v_mov_b32 {v('FmV')}, v20
     v_mov_b32 {v('FmV',1)}, v21
     """)
     G(f"""
-    s_cmp_eq_u32 {s('sidesHi')}, 0
+    s_cmp_eq_u32 {s('hasA') if W4 else s('sidesHi')}, 0
     s_cbranch_scc1 L_nsr
     """)
     E(f"""
-    v_lshl_add_u32 v48, {s('accf')}, 5, {KSD}
+    {f"s_and_b32 {st(0)}, {s('i')}, 1" if W4 else ""}
+    {f"s_lshl_b32 {st(0)}, {st(0)}, 1" if W4 else ""}
+    {f"s_add_u32 {st(0)}, {st(0)}, {s('accf')}" if W4 else ""}
+    v_lshl_add_u32 v48, {st(0) if W4 else s('accf')}, 5, {KSD}
     ds_read_b64 v[46:47], v48 offset:{LDS_SIDEM}
     s_waitcnt lgkmcnt(0)
     v_add_f64 {vp('FmV')}, {MGW}, v[46:47]
@@ -3222,8 +3271,8 @@ E(f"s_add_u32 {s('i')}, {s('i')}, 1")
 G(f"""
 s_mov_b32 {s('hasA')}, 1
 {f"s_and_b32 {st(0)}, {WAVE}, {KS - 1}" if TT else ""}
-{f"s_cmp_eq_u32 {st(0) if TT else WAVE}, 0" if W4 else ""}
-{f"s_cselect_b32 {s('hasAw')}, 1, 0" if W4 else ""}
+{f"s_cmp_eq_u32 {st(0) if TT else WAVE}, 0" if (W4 and not MG) else ""}
+{f"s_cselect_b32 {s('hasAw')}, 1, 0" if (W4 and not MG) else ""}
 """)
 E(f"""
 s_add_u32 {st(0)}, {s('i')}, 1
@@ -3234,10 +3283,14 @@ if MG:   # what the next pass has: plane of half A (a proposal and walls), of ha
     G(f"""
     s_cmp_ge_i32 {s('M2')}, 0
     s_cselect_b32 {s('wlp')}, 1, 0
-    s_and_b32 {s('wlp',1)}, {s('wlp')}, {s('hasB')}
-    s_lshl_b32 {st(1)}, {s('hasB')}, 1
+    s_mov_b32 {st(2)}, {s('hasB')}
+    {f"s_cmp_eq_u32 {WAVE}, 0" if W4 else ""}
+    {f"s_cselect_b32 {s('wlp')}, {s('wlp')}, 0" if W4 else ""}
+    {f"s_cselect_b32 {st(2)}, {st(2)}, 0" if W4 else ""}
+    s_and_b32 {s('wlp',1)}, {s('wlp')}, {st(2)}
+    s_lshl_b32 {st(1)}, {st(2)}, 1
     s_add_u32 {s('stB')}, {s('wlp',1)}, {st(1)}
-    s_mul_i32 {st(1)}, {s('hasB')}, 3
+    s_mul_i32 {st(1)}, {st(2)}, 3
     s_lshl_b32 {s('sidesHi')}, {st(1)}, {s('wlp',1)}
     v_mov_b32 v22, {s('wlp')}
     v_mov_b32 v23, {s('stB')}

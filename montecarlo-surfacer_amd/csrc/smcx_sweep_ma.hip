@@ -292,9 +292,9 @@ constexpr unsigned mt_lds_bytes(int wpr) { return (unsigned)wpr * 2048u + 2u * (
 constexpr unsigned mt_lds_bytes(int wpr) { return (unsigned)wpr * 2048u + 2u * (unsigned)wpr * 512u + 128u; }
 #endif
 #ifdef SMCX_CHECK
-constexpr unsigned mcw_lds_bytes(int wpr) { return (unsigned)wpr * 2048u + 2u * (unsigned)wpr * 512u + (unsigned)wpr * 32u; }
+constexpr unsigned mcw_lds_bytes(int wpr) { return (unsigned)wpr * 2048u + 2u * (unsigned)wpr * 512u + 128u + (unsigned)wpr * 32u; }
 #else
-constexpr unsigned mcw_lds_bytes(int wpr) { return (unsigned)wpr * 2048u + 2u * (unsigned)wpr * 512u; }
+constexpr unsigned mcw_lds_bytes(int wpr) { return (unsigned)wpr * 2048u + 2u * (unsigned)wpr * 512u + 128u; } // + the side pair's results (2 buffers)
 #endif
 // sweep_kernel_mc16/32/64: the row cache (65 x 24 B; the diagnostic build's counters behind it), then at 2048 the hand-over
 // list of the merged pass (64 words) and at 2304 the side pair's results (64 B): gen_sweep_ma.py LDS_LIST, LDS_SIDEM

@@ -189,7 +189,8 @@ def test_config2_N1024_x1024(S, O):
         Es, jj = eng.series(nsw)
         g, oob = eng.hist_info()
         Erec = eng.total_energy()
-    assert form == 2 and name == "smcx::sweep_kernel_mt16x2", name      # (round 3: two teams of one wavefront each)
+    # (round 3: two teams of one wavefront each, mt16x2; round 4: one wavefront, both probes in one pass, positions in LDS)
+    assert form == 2 and name == "smcx::sweep_kernel_ml16", name
     assert np.all(rel(ob["E_last"], Erec) < 1e-9)
     assert np.all(g == nsw) and np.all(oob == 0) and np.all(ob["zhist"].sum(axis=1) == nsw * 1024)
     pick = [0, 1, 127, 128, 511, 640, 1000, 1023]
