@@ -136,7 +136,14 @@ WSH = (NS * 64).bit_length() - 1                          # cell >> WSH = the wa
 SLOTF = ((NS.bit_length() - 1) << 16) | 6                 # s_bfe field of the slot inside a cell index
 Z8 = Z8C or W4 or MODE in ("z8", "z8l")
 ZB = ZBC or Z8 or MODE == "zb"
-NG = NS // 4                                              # 4-slot groups
+# slots per z group: 4 (256 cells).  Groups of 2 slots (128 cells; the code below is written for either) were built and
+# measured in round 4 (SMCX_GEN_GS=2 with zsort_kernel sorting into groups of 128): at the benchmark start a group of 128 is ONE
+# lattice layer, and the ranges widened by a sweep of moves put 6.4 of 32 such groups in reach where 3.4 of 16 are: 6 % fewer
+# cells screened at 13 % more per cell (an exit test per 2 slots) -- 8.90 against 8.97 ms per sweep, while the dense N = 16384
+# start lost (24.2 -> 27.0 ms: more lanes with two candidates).  Not adopted.
+GS = int(os.environ.get("SMCX_GEN_GS", "4")) if Z8 else 4
+GSH = GS.bit_length() - 1
+NG = NS // GS                                             # z groups of this lane's cells
 # The move loop is emitted twice for the z-ordered kernels: a GENERIC copy that tests hasA (a proposal to decide: not in the
 # first pass of a run, which only evaluates the first particle) and hasB (a next particle: not in the last pass), and a
 # STEADY copy for every other pass without those eight test-and-branch pairs (16 scalar instructions of ~180 per move).
@@ -576,7 +583,7 @@ if ZB:
         """)
 
 zb_range_update = "" if not ZB else f"""
-s_lshr_b32 {st(6)}, {st(0)}, 2
+s_lshr_b32 {st(6)}, {st(0)}, {GSH}
 s_lshl_b32 {st(6)}, {st(6)}, 3
 {f"v_add_u32 v26, {st(6)}, v1" if W4 else f"v_mov_b32 v26, {st(6)}"}
 s_mov_b64 exec, vcc
@@ -1329,21 +1336,24 @@ def zbc_check(pzz, w0, w1):
     """)
 
 
-def screen_group8(k0, p, w):
-    """z8: one probe against slots k0..k0+3: 12 instructions (the dot4 results are read four instructions later)"""
-    a = ["v%d" % (V['t'] + j) for j in range(4)]
-    X = [xy(k0 + 3), xy(k0 + 2), xy(k0 + 1), xy(k0)]
-    for j in range(4):
+def screen_group8(k0, p, w, fill=""):
+    """z8: one probe against slots k0..k0+GS-1, highest first: 3 instructions per slot; a v_dot4 result is read at least
+    three instructions later (`fill`: what the caller puts between the dot products and the flag shifts of a 2-slot group)"""
+    a = ["v%d" % (V['t'] + j) for j in range(GS)]
+    X = [xy(k0 + GS - 1 - j) for j in range(GS)]
+    for j in range(GS):
         E(f"v_sub_u32 {a[j]}, {p}, {X[j]}")
-    for j in range(4):
+    for j in range(GS):
         E(f"v_dot4_i32_i8 {a[j]}, {a[j]}, {a[j]}, {s('negC')}")
-    for j in range(4):
+    if GS < 4:
+        E(fill if fill else "s_nop 1")
+    for j in range(GS):
         E(f"v_alignbit_b32 {w}, {w}, {a[j]}, 31")
 
 
 def screen_ranged8(tag, pws, w0, w1):
     """z8: as screen_ranged, without z words to fetch: the computed jump lands on the highest group in reach"""
-    w = lambda g: w1 if 4 * g >= 32 else w0
+    w = lambda g: w1 if GS * g >= 32 else w0
     E(f"""
     v_mov_b32 {w0}, 0
     v_mov_b32 {w1}, 0
@@ -1370,9 +1380,11 @@ def screen_ranged8(tag, pws, w0, w1):
             E("L_jb:", " @S" if PEEL else "")   # what the computed jumps of BOTH copies of the move are relative to (the
                                                  # steady copy lies first: every offset is positive)
         E(f"L_sg{g}_{tag}:")
-        screen_group8(4 * g, v('pxy'), w(g))
+        # (2-slot groups: the exit test and one s_nop stand between the dot products and the shifts that read them)
+        screen_group8(GS * g, v('pxy'), w(g), f"s_cmp_eq_u32 {st(4)}, {g}\ns_nop 0" if (g > 0 and GS < 4) else "")
         if g > 0:
-            E(f"s_cmp_eq_u32 {st(4)}, {g}")
+            if GS == 4:
+                E(f"s_cmp_eq_u32 {st(4)}, {g}")
             E(f"s_cbranch_scc1 L_sfin_{tag}")
     E(f"L_sfin_{tag}:")
     if Z8C:   # executed work: groups of this pass = highest - lowest + 1 = 32 - flbit - ff1 (in st(1) since the jump)
@@ -1384,7 +1396,7 @@ def screen_ranged8(tag, pws, w0, w1):
         s_mov_b64 exec, -1
         """)
     E(f"""
-    s_lshl_b32 {st(0)}, {st(4)}, 2
+    s_lshl_b32 {st(0)}, {st(4)}, {GSH}
     v_lshlrev_b32 {w0}, {st(0)}, {w0}
     """)
     if NS == 64:
@@ -3048,7 +3060,7 @@ else:
         ds_write_b16 {v('S6')}, {v('T',1)}
         """)
     E(f"""
-    s_lshr_b32 {st(1)}, {st(1)}, 2
+    s_lshr_b32 {st(1)}, {st(1)}, {GSH}
     s_lshl_b64 {stp(2)}, 1, {st(1)}
     {f"v_readfirstlane_b32 {st(6)}, {KRZ}" if TT else f"s_mov_b32 {st(6)}, {s('RZ')}" if (Z8 and not W4) else f"s_load_dword {st(6)}, {KARG}, {K_RZ}"}
     s_sext_i32_i16 {st(0)}, {s('axys') if Z8 else s('az16')}

@@ -232,23 +232,10 @@ __global__ void __launch_bounds__(256, 1) sweep_kernel_mc32x4(MaArgs a)
         : "memory", "vcc", "scc", "m0", SMCX_MA_SGPRS, SMCX_MA_V95);
 }
 // TWO TEAMS of wavefronts per replica (gen_sweep_ma.py ... z8t): team A (waves 0..K-1) evaluates probe A while team B
-// (waves K..2K-1) evaluates probe B; both hold all cells, wave w owns slab w mod K of the z order; one exchange per move
-__global__ void __launch_bounds__(128, 1) sweep_kernel_mt16x2(MaArgs a)
-{
-    unsigned lane = threadIdx.x & 63;
-    unsigned long long kp = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
-    unsigned rep = blockIdx.x;
-    unsigned wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    asm volatile(
-#ifdef SMCX_CHECK
-#include "smcx_sweep_mtc_body16.inc"
-#else
-#include "smcx_sweep_mt_body16.inc"
-#endif
-        : "+v"(lane), "+s"(kp), "+s"(rep), "+s"(wv)
-        :
-        : "memory", "vcc", "scc", "m0", SMCX_MA_SGPRS, SMCX_MA_V95); // v80..v85: per-lane constants behind the cells
-}
+// (waves K..2K-1) evaluates probe B; both hold all cells, wave w owns slab w mod K of the z order; one exchange per move.
+// Built: 64 cells per lane x 8 wavefronts (8192 < N <= 16384 with at most 256 replicas per GPU: BASELINE config 5).  Round 3
+// also built 16 x 2 (N <= 1024; slower than sweep_kernel_ml16 since round 4) and 32 x 16 (never the fastest): retired; the
+// generator still writes them (gen_sweep_ma.py ... 16 z8t 2 / 32 z8t 16).
 __global__ void __launch_bounds__(512, 1) sweep_kernel_mt64x8(MaArgs a)
 {
     unsigned lane = threadIdx.x & 63;
@@ -264,24 +251,6 @@ __global__ void __launch_bounds__(512, 1) sweep_kernel_mt64x8(MaArgs a)
         : "+v"(lane), "+s"(kp), "+s"(rep), "+s"(wv)
         :
         : "memory", "vcc", "scc", "m0", SMCX_MA_SGPRS, SMCX_MA_V127, "v128", "v129", "v130", "v131", "v132", "v133", "v134", "v135");
-}
-// sixteen wavefronts: eight slabs of 32 cells per lane x two teams (thinner slabs: a probe's candidates spread over more
-// wavefronts, fewer second rounds on dense states)
-__global__ void __launch_bounds__(1024, 1) sweep_kernel_mt32x16(MaArgs a)
-{
-    unsigned lane = threadIdx.x & 63;
-    unsigned long long kp = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
-    unsigned rep = blockIdx.x;
-    unsigned wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    asm volatile(
-#ifdef SMCX_CHECK
-#include "smcx_sweep_mtc_body32.inc"
-#else
-#include "smcx_sweep_mt_body32.inc"
-#endif
-        : "+v"(lane), "+s"(kp), "+s"(rep), "+s"(wv)
-        :
-        : "memory", "vcc", "scc", "m0", SMCX_MA_SGPRS, SMCX_MA_V127);
 }
 // LDS of the two-team kernels: a row cache per wave, the exchange area [2][waves][64] doubles, the side area
 #ifdef SMCX_CHECK
@@ -468,9 +437,8 @@ bool mcw_built(int S, int WPR, int N, int M2, double L, double Lz, double cutoff
 // two teams of wavefronts per replica: 16 cells per lane x 2 waves (512 < N <= 1024) or 64 x 8 (8192 < N <= 16384)
 bool mt_built(int S, int WPR, int N, int M2, double L, double Lz, double cutoff2)
 {
-    const bool small = S == 16 && WPR == 2 && N > 512 && N <= 1024;
-    const bool big = ((S == 64 && WPR == 8) || (S == 32 && WPR == 16)) && N > 8192 && N <= 16384;
-    return (small || big) && M2 + 2 <= 30 && mc_box_supported(L, Lz, cutoff2);
+    const bool big = S == 64 && WPR == 8 && N > 8192 && N <= 16384;
+    return big && M2 + 2 <= 30 && mc_box_supported(L, Lz, cutoff2);
 }
 
 hipError_t launch_sweeps_mt(const SweepArgs &s, const DevCtx &c, const KernelPlan &pl, int nsweeps, double A, hipStream_t st,
@@ -494,20 +462,12 @@ hipError_t launch_sweeps_mt(const SweepArgs &s, const DevCtx &c, const KernelPla
 #endif
     const double toFix16 = 65536.0 / c.L;
     for (int sw = 0; sw < nsweeps; sw++) {
-        if (pl.S == 16)
-            hipLaunchKernelGGL((zsort_kernel<16 * 64, 256>), dim3(c.nrep), dim3(256), 0, st, (const double *)s.R, c.Rs, c.loc, s.N, toFix16, 1);
-        else
-            hipLaunchKernelGGL((zsort_kernel<4 * 64 * 64, 1024>), dim3(c.nrep), dim3(1024), 0, st, (const double *)s.R, c.Rs, c.loc, s.N, toFix16,
+        hipLaunchKernelGGL((zsort_kernel<4 * 64 * 64, 1024>), dim3(c.nrep), dim3(1024), 0, st, (const double *)s.R, c.Rs, c.loc, s.N, toFix16,
                                pl.WPR / 2);
         a.sw0 = sw;
         hipError_t rc = tm ? tm->mark(st) : hipSuccess;
         if (rc != hipSuccess) return rc;
-        if (pl.S == 16)
-            hipLaunchKernelGGL(sweep_kernel_mt16x2, dim3(c.nrep), dim3(128), mt_lds_bytes(2) + 16u * 64u * 24u + 1024u, st, a); // + positions, wall table
-        else if (pl.S == 32)
-            hipLaunchKernelGGL(sweep_kernel_mt32x16, dim3(c.nrep), dim3(1024), mt_lds_bytes(16), st, a);
-        else
-            hipLaunchKernelGGL(sweep_kernel_mt64x8, dim3(c.nrep), dim3(512), mt_lds_bytes(8), st, a);
+        hipLaunchKernelGGL(sweep_kernel_mt64x8, dim3(c.nrep), dim3(512), mt_lds_bytes(8), st, a);
         rc = hipGetLastError();
         if (rc == hipSuccess && tm) rc = tm->mark(st);
         if (rc != hipSuccess) return rc;
@@ -584,7 +544,7 @@ void mc_bound(double L, double cutoff2, double *toFix, double *zsafe, int *negC,
 
 const char *ma_kernel_name(int form, int S, int WPR)
 {
-    if (form == FORM_MT) return S == 16 ? "smcx::sweep_kernel_mt16x2" : S == 32 ? "smcx::sweep_kernel_mt32x16" : "smcx::sweep_kernel_mt64x8";
+    if (form == FORM_MT) return "smcx::sweep_kernel_mt64x8";
     if (form == FORM_MC && WPR == 4 && S == 32) return "smcx::sweep_kernel_mc32x4";
     if (form == FORM_MC && WPR == 4) return "smcx::sweep_kernel_mc64x4";
     if (form == FORM_MC && WPR == 8) return "smcx::sweep_kernel_mc32x8";
@@ -685,8 +645,8 @@ int ma_resident_replicas(const KernelPlan &pl, int device)
                                                                                          : (const void *)sweep_kernel_mc32x8;
     } else if (pl.form == FORM_MT) {
         threads = 64 * pl.WPR;
-        lds = pl.S == 16 ? mt_lds_bytes(2) + 16u * 64u * 24u + 1024u : mt_lds_bytes(pl.WPR);
-        f = pl.S == 16 ? (const void *)sweep_kernel_mt16x2 : pl.S == 32 ? (const void *)sweep_kernel_mt32x16 : (const void *)sweep_kernel_mt64x8;
+        lds = mt_lds_bytes(pl.WPR);
+        f = (const void *)sweep_kernel_mt64x8;
     }
     if (!f) return 0;
     int per_cu = 0, cus = 0;

@@ -43,7 +43,6 @@ def oracle_chains(O, s, seeds, R0, eq, nsw, gl, workers=16):
     (32, 8, "smcx::sweep_kernel_mc32x8"),                # the same with 8 wavefronts x 32 cells
     (64, 8, "smcx::sweep_kernel_mt64x8"),                # two teams of 4 wavefronts x 64 cells (round 3): the rule's choice
                                                          # up to 256 replicas per GPU
-    (32, 16, "smcx::sweep_kernel_mt32x16"),              # two teams of 8 wavefronts x 32 cells
 ])
 def test_config5_N16384_against_oracle(S, O, slots, waves, name):
     """BASELINE configs[4]: N=16384 + wall, fcc(16,16) (the reference's own dense lattice),
@@ -71,7 +70,7 @@ def test_config5_N16384_against_oracle(S, O, slots, waves, name):
         assert np.array_equal(ob["zhist"][r], ref["zhist"])
 
 
-@pytest.mark.parametrize("slots,waves", [(64, 4), (32, 8), (64, 8), (32, 16)])
+@pytest.mark.parametrize("slots,waves", [(64, 4), (32, 8), (64, 8)])
 def test_several_wavefront_kernel_with_many_accepted_moves(S, O, slots, waves):
     """config 5's lattice is a crystal (66 of 16384 moves accepted per sweep).  The same N in the widest box the byte
     screen serves (L = 48: fcc(16,16) at spacing 3, a third of the density) accepts thousands of moves per sweep, so
@@ -83,7 +82,7 @@ def test_several_wavefront_kernel_with_many_accepted_moves(S, O, slots, waves):
     p = S.default_params(16384, nrep, L=L, flags=S.FLAGS_REFERENCE | S.FLAG_SERIES, tune_slots=slots, tune_waves=waves)
     with S.Engine(p) as eng:
         assert eng.kernel_form[1] == {(64, 4): "smcx::sweep_kernel_mc64x4", (32, 8): "smcx::sweep_kernel_mc32x8",
-                                      (64, 8): "smcx::sweep_kernel_mt64x8", (32, 16): "smcx::sweep_kernel_mt32x16"}[(slots, waves)]
+                                      (64, 8): "smcx::sweep_kernel_mt64x8"}[(slots, waves)]
         eng.upload(R0, O.W_FIXTURE)
         eng.run(0, nsw, 1)
         ob = eng.observables()
@@ -425,9 +424,7 @@ def test_ranged_screen_sets_every_bit_of_the_full_screen(tmp_path, N, lat, nrep,
     (16384, (16, 16), 4, 2, 1, 64, 4, "mc64x4"), (16384, (16, 16), 4, 2, 1, 32, 8, "mc32x8"),   # config 5's kernels
     (9000, (15, 10), 4, 2, 2, 64, 4, "mc64x4"), (10000, (10, 25), 4, 2, 1, 32, 8, "mc32x8"),    # ragged, tall
     (8192, (16, 8), 4, 2, 1, 32, 4, "mc32x4"), (4800, (10, 12), 4, 2, 2, 32, 4, "mc32x4"),      # 4096 < N <= 8192
-    (1024, (8, 4), 16, 3, 1, 16, 2, "mt16x2"), (1000, (5, 10), 8, 3, 1, 16, 2, "mt16x2"),        # two teams of wavefronts
-    (16384, (16, 16), 4, 2, 1, 64, 8, "mt64x8"), (9000, (15, 10), 4, 2, 1, 64, 8, "mt64x8"),
-    (16384, (16, 16), 4, 2, 1, 32, 16, "mt32x16"), (10000, (10, 25), 4, 2, 1, 32, 16, "mt32x16")])
+    (16384, (16, 16), 4, 2, 1, 64, 8, "mt64x8"), (9000, (15, 10), 4, 2, 1, 64, 8, "mt64x8")])    # two teams of wavefronts
 def test_byte_screen_kernel_misses_no_pair_inside_the_cutoff(tmp_path, N, lat, nrep, nsw, gl, slots, waves, kernel):
     """sweep_kernel_mc64 (the benchmark's kernel), mc16 / mc32 (N <= 2048) and the several-wavefront forms mc64x4 /
     mc32x8 (8192 < N <= 16384): one word per cell screened by v_dot4_i32_i8, only the groups in

@@ -91,35 +91,32 @@ def _state(O, case):
     raise ValueError(case)
 
 
-# the two-team kernels (round 3) run the same states as the kernels they stand in for
+# the states of round 3's two-team kernel for N <= 1024 now run sweep_kernel_ml16 (which replaced it in the plan); the two-team
+# kernel that remains, mt64x8, runs the states of the several-wavefront kernels it stands in for
 def _tt_state(O, case):
-    if case == "mt16x2_benchmark":
-        return O.fcc(8, 4), 33.0, 240.0, None, "mt16x2", {}
-    if case == "mt16x2_dense":
-        R0, L, Lz, mode, _, _ = _state(O, "ml16_dense")
-        return R0, L, Lz, mode, "mt16x2", {}
-    if case == "mt16x2_ragged_no_walls":
+    if case == "ml16_benchmark":
+        return O.fcc(8, 4), 33.0, 240.0, None, "ml16", {}
+    if case == "ml16_ragged_no_walls":
         rs = np.random.RandomState(5)
         R = O.fcc(8, 4).reshape(-1, 3)[:900].copy()
         R += 0.05 * rs.standard_normal(R.shape)
         R[R[:, 2] > 6.0, 2] += 40.0
-        return _wrap(R, 33.0).ravel(), 33.0, 240.0, "nowalls", "mt16x2", {}
-    if case == "mt16x2_at_wall":
+        return _wrap(R, 33.0).ravel(), 33.0, 240.0, "nowalls", "ml16", {}
+    if case == "ml16_at_wall":
         rs = np.random.RandomState(6)
         R = O.fcc(8, 4).reshape(-1, 3).copy()
         R += 0.05 * rs.standard_normal(R.shape)
         R[:, 2] += -118.6 - R[:, 2].min()
-        return _wrap(R, 33.0).ravel(), 33.0, 240.0, None, "mt16x2", {}
-    if case in ("mt64x8_benchmark", "mt32x16_benchmark"):
-        return O.fcc(16, 16), 33.0, 240.0, None, case.split("_")[0], {}
-    if case in ("mt64x8_two_slabs", "mt32x16_two_slabs"):
+        return _wrap(R, 33.0).ravel(), 33.0, 240.0, None, "ml16", {}
+    if case == "mt64x8_benchmark":
+        return O.fcc(16, 16), 33.0, 240.0, None, "mt64x8", {}
+    if case == "mt64x8_two_slabs":
         R0, L, Lz, mode, _, extra = _state(O, "mc64x4_two_slabs")
-        return R0, L, Lz, mode, case.split("_")[0], extra
+        return R0, L, Lz, mode, "mt64x8", extra
     raise ValueError(case)
 
 
-TT_CASES = ["mt16x2_benchmark", "mt16x2_dense", "mt16x2_ragged_no_walls", "mt16x2_at_wall", "mt64x8_benchmark", "mt64x8_two_slabs",
-            "mt32x16_benchmark", "mt32x16_two_slabs"]
+TT_CASES = ["ml16_benchmark", "ml16_ragged_no_walls", "ml16_at_wall", "mt64x8_benchmark", "mt64x8_two_slabs"]
 
 CASES = ["dense_film", "dense_film_at_wall", "thin_film", "two_slabs_ragged", "unsafe_z_mb64", "unsafe_z_ma64", "resort_3", "mc16_dense",
          "ml16_dense", "mc32_two_slabs", "mc32x4_dense", "mc64x4_two_slabs"]
@@ -132,7 +129,7 @@ def test_rare_path_against_oracle(S, O, case):
     nrep, eq, nsw = 2, 0, (3 if case == "resort_3" else 4 if N <= 1024 else 2 if N <= 2304 else 1)
     flags = S.FLAG_SERIES | (S.FLAG_E0_RESTART if mode == "nowalls" else S.FLAGS_REFERENCE)
     geom = {"mc64": (64, 1), "mb64": (64, 1), "ma64": (64, 1), "mc32": (32, 1), "mc16": (16, 1), "ml16": (16, 1), "mc32x4": (0, 0),
-            "mc64x4": (64, 4), "mt16x2": (16, 2), "mt64x8": (64, 8), "mt32x16": (32, 16)}[kernel]
+            "mc64x4": (64, 4), "mt64x8": (64, 8)}[kernel]
     p = S.default_params(N, nrep, L=L, Lz=Lz, flags=flags, tune_slots=geom[0], tune_waves=geom[1], **extra)
     with S.Engine(p) as eng:
         assert eng.kernel_form[1] == "smcx::sweep_kernel_" + kernel, eng.kernel_form

@@ -23,12 +23,11 @@ CASES = [  # N, lattice, replicas, thermalisation sweeps (at 2A), production swe
     (4096, (16, 4), 32, 5, 10, 5, 64, 1),        # dense film
     (4000, (10, 10), 64, 10, 20, 7, 64, 1),      # ragged N
     (2100, (5, 21), 64, 10, 20, 3, 64, 1),       # thin tall start, a gather every third sweep
-    (1024, (8, 4), 256, 20, 60, 10, 16, 2),      # config 2, two teams
-    (1000, (5, 10), 128, 20, 60, 10, 16, 2),     # ragged, two teams
-    (1024, (8, 4), 128, 20, 60, 10, 16, 1),      # mc16
+    (1024, (8, 4), 256, 20, 60, 10, 16, 1),      # config 2's kernel: ml16 (few replicas of N <= 1024: positions in LDS)
+    (1000, (5, 10), 128, 20, 60, 10, 16, 1),     # ragged, ml16
+    (1024, (8, 4), 1100, 4, 12, 6, 16, 1),       # mc16 (more than 1024 replicas)
     (2048, (8, 8), 64, 10, 30, 10, 32, 1),       # mc32
     (16384, (16, 16), 8, 2, 6, 3, 64, 8),        # config 5, two teams
-    (16384, (16, 16), 8, 2, 6, 3, 32, 16),       # ... sixteen wavefronts
     (16384, (16, 16), 8, 2, 6, 3, 32, 8),        # mc32x8
     (16384, (16, 16), 8, 2, 6, 3, 64, 4),        # mc64x4
     (9000, (15, 10), 8, 4, 8, 4, 64, 8),         # ragged, two teams
