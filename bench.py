@@ -77,8 +77,25 @@ def issue_roofline(kname, sweep_ms_per_sweep, nrep, N, clock_ghz, start=None):
     need_hi = b32 * MEASURED_COST_HI["b32"] + f64 * MEASURED_COST_HI["f64"] + tr * MEASURED_COST_HI["trans_f64"]
     peak = N_SIMD * clock_ghz                                        # G SIMD-cycles per second
     achieved = need * wave_moves_per_s / 1e9
+    # Round 4 measured what ONE instruction of each kind costs the running kernel at four wavefronts per SIMD (40 extra
+    # instructions per move, profiles/r04_instruction_costs_in_kernel.txt): scalar ALU 2.0 SIMD cycles, fast VALU form 1.8, slow
+    # 32-bit VALU form 3.2, fp64 3.4 -- and their sum over the kernel's instructions IS its time: a SIMD issues one instruction
+    # of any kind at a time.  So besides the VALU-only fraction (`frac`, the guide's costs) the line carries the fraction of
+    # the SIMDs' cycles that ALL executed instructions account for at those measured costs, bracketed because the PMC classes do
+    # not separate fast from slow 32-bit VALU forms (LDS / memory / scalar-memory instructions priced like a scalar one).
+    other = ((m.get("SQ_INSTS_SALU") or 0) + (m.get("SQ_INSTS_BRANCH") or 0) + (m.get("SQ_INSTS_LDS") or 0) +
+             (m.get("SQ_INSTS_VMEM_RD") or 0) + (m.get("SQ_INSTS_VMEM_WR") or 0) + (m.get("SQ_INSTS_SMEM") or 0))
+    all_lo = b32 * 1.8 + f64 * 3.4 + tr * 8.0 + other * 2.0
+    all_hi = b32 * 3.2 + f64 * 3.4 + tr * 8.0 + other * 2.0
     out = {"bound": "valu_issue", "achieved": achieved, "peak": peak, "unit": "G SIMD-cycles/s of VALU issue",
            "frac": achieved / peak,
+           "frac_all_instruction_kinds_at_measured_costs_range": [all_lo * wave_moves_per_s / 1e9 / peak,
+                                                                  all_hi * wave_moves_per_s / 1e9 / peak],
+           "all_kinds_note": "SIMD cycles that ALL executed instructions (VALU, scalar, branch, LDS, memory) account for at the "
+                             "per-kind issue costs measured inside this kernel (profiles/r04_instruction_costs_in_kernel.txt), "
+                             "over the SIMD cycles that passed; 32-bit VALU all-fast .. all-slow.  Near 1: the issue port is the "
+                             "bound and `frac` (VALU only, guide costs) is the share of it that is vector work",
+           "wave_instr_per_move_all_kinds": m["SQ_INSTS_VALU"] + other,
            "frac_at_measured_costs_range": [need_lo * wave_moves_per_s / 1e9 / peak, need_hi * wave_moves_per_s / 1e9 / peak],
            # SQ_ACTIVE_INST_VALU is NOT a busy time: it advances by exactly 1 per VALU instruction of any form
            # (tools/ubench/active_valu.hip), so "ACTIVE_INST_VALU x 4 cycles / kernel time" (0.99 for sweep_kernel_mc64)
@@ -283,7 +300,7 @@ def side_config(S, label, N, nrep, lattice, sweeps, device, kernel=0, executed=T
     rl = issue_roofline(kname, ms / sweeps, nrep, N, ghz, start="fcc(%d,%d)" % tuple(lattice))
     out["roofline"] = rl if rl else {"bound": "valu_issue", "frac": None, "clock_ghz": ghz,
                                      "note": "no PMC counters committed for this kernel and workload"}
-    if executed and ("kernel_mc" in kname or "kernel_mt" in kname):
+    if executed and ("kernel_mc" in kname or "kernel_mt" in kname or "kernel_ml" in kname):
         out["executed"] = executed_work(kname, N, lattice, s_, w_, device, nrep=min(nrep, 64 if N <= 4096 else 8))
     return out
 
@@ -343,6 +360,7 @@ def main():
     p = S.default_params(N, nrep, device=local_rank, first_replica=first,
                          tune_slots=a.slots, tune_waves=a.waves, tune_resort=a.resort, tune_kernel=a.kernel)
     eng = S.Engine(p)
+    granule, granule_note = eng.replica_granule()      # replicas the device runs at once with this kernel (sizing rule)
     eng.upload(S.fcc_init(*lattice), S.W_REFERENCE)   # inputs resident in HBM before timing
     gather_lapse = 10                                  # SURVEY.md 8d throughput runs
 
@@ -411,6 +429,7 @@ def main():
                                    % (N, nrep, lattice[0], lattice[1]),
                        "N": N, "replicas_per_gpu": nrep, "replicas_total": nrep * world,
                        "gather_lapse": gather_lapse,
+                       "replicas_resident_at_once": granule, "replica_count_advice": granule_note,
                        "geometry": "S=%d particles/lane, %d wavefront(s)/replica" % (S_, W_),
                        "parallelism": "replica-sharded x%d, no data-path collective; %s all-gather of "
                                       "observables at the end (%.2f ms)" % (world, "RCCL" if backend == "nccl" else backend, gather_ms)},
@@ -471,7 +490,7 @@ def main():
                                                 "unit": "pair-evals/s (sweep kernels only)"}
             except Exception as e:
                 out["fp64_only_kernels"] = {"value": None, "note": "failed: %r" % (e,)}
-        if world == 1 and not a.no_cpu and ("kernel_mc" in kname or "kernel_mt" in kname):
+        if world == 1 and not a.no_cpu and ("kernel_mc" in kname or "kernel_mt" in kname or "kernel_ml" in kname):
             # what the timed kernel executed per probe (diagnostic build, sample of the same start)
             eng.close()
             out["executed"] = executed_work(kname, N, lattice, S_, W_, local_rank, nrep=64 if N <= 4096 else 8)

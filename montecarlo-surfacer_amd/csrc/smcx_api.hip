@@ -530,11 +530,19 @@ extern "C" int smcx_replica_granule(smcx_handle *hh, int *granule, char *note, i
         note[0] = 0;
         if (g > 0 && h.p.nrep % g != 0) {
             const int rounds = (h.p.nrep + g - 1) / g, last = h.p.nrep - (rounds - 1) * g;
-            std::snprintf(note, (size_t)len,
-                          "%d replicas with %s: the device runs %d of them at once and a sweep is sequential inside a replica, so a "
-                          "sweep takes %d rounds, the last with %d replica(s) on a nearly empty chip (a lone wavefront still needs "
-                          "about half the time of a full round).  Use a multiple of %d replicas per GPU: %d cost the same time.",
-                          h.p.nrep, h.plan.name, g, rounds, last, g, rounds * g);
+            if (rounds == 1)
+                std::snprintf(note, (size_t)len,
+                              "%d replicas with %s: the device could run %d of them at once; a sweep is sequential inside a replica, "
+                              "so fewer replicas do not make it proportionally shorter (half of them: about 80 %% of the time).  "
+                              "%d replicas per GPU use the device fully.",
+                              h.p.nrep, h.plan.name, g, g);
+            else
+                std::snprintf(note, (size_t)len,
+                              "%d replicas with %s: the device runs %d of them at once and a sweep is sequential inside a replica, so "
+                              "a sweep takes %d rounds, the last with %d replica(s) on a nearly empty chip (a lone wavefront still "
+                              "needs about half the time of a full round).  Use a multiple of %d replicas per GPU: %d cost about the "
+                              "same time.",
+                              h.p.nrep, h.plan.name, g, rounds, last, g, rounds * g);
         }
     }
     return SMCX_OK;

@@ -8,7 +8,7 @@ TAG=${1:-run}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 cd "$ROOT"
 tools/profile_valu.sh ${TAG}_c3 > gpurun_out/pmc_${TAG}_c3.txt 2>&1
-PMC_N=1024 PMC_NREP=1024 PMC_WPR=2 tools/profile_valu.sh ${TAG}_c2 --N 1024 --replicas 1024 > gpurun_out/pmc_${TAG}_c2.txt 2>&1
+PMC_N=1024 PMC_NREP=1024 PMC_WPR=1 tools/profile_valu.sh ${TAG}_c2 --N 1024 --replicas 1024 > gpurun_out/pmc_${TAG}_c2.txt 2>&1
 PMC_N=16384 PMC_NREP=256 PMC_WPR=8 tools/profile_valu.sh ${TAG}_c5 --N 16384 --replicas 256 > gpurun_out/pmc_${TAG}_c5.txt 2>&1
 # the adverse start of other_configs (dense film, most groups in reach): same kernel as config 3, keyed "kernel@start"
 tools/profile_valu.sh ${TAG}_dense --lattice 16,4 > gpurun_out/pmc_${TAG}_dense.txt 2>&1
