@@ -160,7 +160,11 @@ MG = Z8 and not TT and os.environ.get("SMCX_GEN_NOMERGE") != "1"      # (switch 
 # are added in ONE exchange per move (two before); the wall sites, planes and the side pair work on the slab-0 wave
 # z8t with 16 cells per lane ("LP"): the fp64 positions of all cells (24 KB, what candidates are fetched from) and the
 # wall table live in LDS at offset 0, shared by the two wavefronts of the replica; every other LDS area moves up
-PF2 = TT and NS >= 32     # z8t with many cells: the first TWO candidates of a lane are fetched together (dense states: the
+# z8t, round 4 ("TL"): the candidates of a team's probe are handed over to working lanes through a list in LDS as in the
+# merged pass (all 64 lanes work for the ONE probe of the wave; wall lanes and side lanes on fixed lanes in front), so a lane
+# with two candidates costs a second hand-over instead of a second pass of the fp64 body (round 3's PF2)
+TL = TT and os.environ.get("SMCX_GEN_TTLIST", "1") != "0"
+PF2 = TT and NS >= 32 and not TL     # z8t with many cells: the first TWO candidates of a lane are fetched together (dense states: the
                           # second round's memory round trip was the longest stretch of the slowest wavefront's move)
 LP = (TT and NS == 16) or ZL
 assert not ZL or NS == 16
@@ -176,8 +180,9 @@ if W4:
     LDS_CNT = LDS_X + 2 * WPR * 512 + 128                 # z8wc: 8 counter words per wave behind the exchange and side areas
 LDS_TM = LDS_SIDE + 128                                   # z8t stamps variant: per wave {t0, cycles before the barrier, cycles at it}
 LDS_LIST, LDS_SIDEM = LDS_BASE + 2048, LDS_BASE + 2304    # mg: hand-over list [64] words; side results [old, new][e, fx, fy, fz]
-if W4 and not TT:   # z8w: the list inside the wave's own block (behind its row cache; addressed through v1), the side results
-    LDS_LIST = 1600                                       # -- [2 buffers by the parity of the move] -- behind the exchange area
+if W4:              # z8w, z8t: the list inside the wave's own block (behind its row cache; addressed through v1)
+    LDS_LIST = 1600
+if W4 and not TT:   # z8w: the side results -- [2 buffers by the parity of the move] -- behind the exchange area
     LDS_SIDEM = LDS_X + 2 * WPR * 512
 LANE, KARG, REP, WAVE = "%0", "%1", "%2", "%3"
 # z8t: the slab of a wave is wave mod K (team B = waves K .. 2K-1), formed with s_and_b32 in a scratch register where
@@ -502,6 +507,24 @@ if TT:
     KR = XY0 + NS
     KINV, KFIX, KPROW, KSIDE = f"v[{KR}:{KR+1}]", f"v[{KR+2}:{KR+3}]", f"v{KR+4}", f"v{KR+5}"
     KRZ = f"v{KR+6}"          # the reach of a group's z range (an accepted move widens its group's range by it)
+    KL4T = f"v{KR+7}"         # TL: 4 lane + this wave's LDS block (the hand-over list is read from there)
+    if TL:
+        # per-wave constants of the special lanes: wall sites and plane on lanes 0 .. M2w (the plane last; none off the slab-0
+        # waves, where M2w = -1), the side pair on the two lanes behind them (team B's slab-0 wave)
+        E(f"""
+        v_lshl_add_u32 {KL4T}, {LANE}, 2, v1
+        s_add_u32 {st(0)}, {s('M2w')}, 1
+        s_bfm_b64 {sp('wallM')}, {st(0)}, 0
+        s_mov_b64 {sp('wallB')}, {sp('wallM')}
+        s_mov_b64 {sp('planeM')}, 0
+        s_cmp_lt_i32 {s('M2w')}, 0
+        s_cbranch_scc1 L_nopw
+        s_lshl_b64 {sp('planeM')}, 1, {s('M2w')}
+        L_nopw:
+        s_mov_b64 {sp('planeB')}, {sp('planeM')}
+        s_add_u32 {s('sideL')}, {s('M2w')}, 1
+        s_add_u32 {s('sideN')}, {s('M2w')}, 2
+        """)
     E(f"""
     s_load_dword {st(0)}, {KARG}, {K_RZ}
     s_waitcnt lgkmcnt(0)
@@ -1904,6 +1927,99 @@ def second_regs(tag):
     return ["v[26:27]", "v[28:29]", "v[4:5]"], 26, 4, sp('wallM')    # team B: probe A's coefficients and flag words
 
 
+def mg_handover(w0, w1, h, start, off, n, cap=32):
+    """every lane with a candidate in (w0, w1) hands its lowest one over: working lane = start + its rank among those lanes
+    (of this probe's half; only below `cap`), through list[off / 4 + lane]; h (s pair) <- the lanes that did, n (s) <- how many"""
+    hlo, hhi = (int(x) for x in h[2:-1].split(":"))
+    E(f"""
+    v_cmp_ne_u64 {h}, 0, v[{w0}:{w1}]
+    v_ffbl_b32 v46, v{w0}
+    v_ffbl_b32 v47, v{w1}
+    {"v_or_b32 v47, 32, v47" if start.startswith("v") else f"v_mov_b32 v45, {start}"}
+    v_mbcnt_lo_u32_b32 v45, s{hlo}, {start if start.startswith("v") else "v45"}
+    v_mbcnt_hi_u32_b32 v45, s{hhi}, v45
+    {"" if start.startswith("v") else "v_or_b32 v47, 32, v47"}
+    v_cmp_gt_u32 vcc, {cap}, v45
+    v_min_u32 v46, v46, v47
+    v_lshl_add_u64 v[48:49], v[{w0}:{w1}], 0, -1
+    s_and_b64 {h}, {h}, vcc
+    v_lshl_or_b32 v46, v46, 6, {LANE}
+    s_bcnt1_i32_b64 {n}, {h}
+    {"v_lshl_add_u32 v45, v45, 2, v1" if W4 else "v_lshlrev_b32 v45, 2, v45"}
+    s_mov_b64 exec, {h}
+    v_and_b32 v{w0}, v{w0}, v48
+    v_and_b32 v{w1}, v{w1}, v49
+    ds_write_b32 v45, v46 offset:{LDS_LIST + off}
+    s_mov_b64 exec, -1
+    """)
+
+
+def mg_handover2(tagc, w0, w1, h, start, off, n, cap=32, flag=True):
+    """the lanes that STILL hold a candidate after the hand-over (two of one probe in one lane: ~15 % of the probes) hand
+    that one over as well, to the working lanes behind the first batch, so that it is evaluated in the same pass instead
+    of a round of its own; what remains after that (a third candidate, a full half) sets bit 1 of nearB = "more rounds".
+    Cold piece; start (s), n (s): first working lane and count of the first batch, n is updated"""
+    def emit(txt):
+        (COLD if REDIR[0] is None else E)(txt)
+    E(f"""
+    v_cmp_ne_u64 vcc, 0, v[{w0}:{w1}]
+    s_cbranch_vccnz L_ho2{tagc}
+    L_ho2r{tagc}:
+    """)
+    save, REDIR[0] = REDIR[0], (cold if REDIR[0] is None else REDIR[0])
+    if save is not None:      # already among the cold pieces: in line, jumped over
+        E(f"s_branch L_ho2x{tagc}")
+    E(f"""
+    L_ho2{tagc}:
+    s_add_u32 {st(7)}, {start}, {n}
+    """)
+    mg_handover(w0, w1, h, st(7), off, st(7), cap)
+    E(f"s_add_u32 {n}, {n}, {st(7)}")
+    if flag:   # (the two-team kernels look at the flag words again after round 0 instead)
+        E(f"""
+        v_cmp_ne_u64 vcc, 0, v[{w0}:{w1}]
+        s_cbranch_vccz L_ho2r{tagc}
+        s_bitset1_b32 {s('nearB')}, 1
+        """)
+    E(f"s_branch L_ho2r{tagc}")
+    if save is not None:
+        E(f"L_ho2x{tagc}:")
+    REDIR[0] = save
+
+
+def tt_assign(tag, w0, w1, X, C, wl, pl, with_side, have):
+    """z8t (TL), round 0 of this wave's probe: its candidates are handed over to working lanes through the list -- behind the
+    wall lanes (table row = lane; wl, pl, sideL, sideN are per-wave constants set in the prologue) and, on team B's slab-0
+    wave, the two side lanes; `have` <- the lanes whose candidate load is in flight"""
+    E(f"""
+    s_add_u32 {st(3)}, {s('M2w')}, 1
+    {f"s_lshl_b32 {st(6)}, {s('hasAw')}, 1" if with_side else ""}
+    {f"s_add_u32 {st(6)}, {st(6)}, {st(3)}" if with_side else ""}
+    """)
+    start = st(6) if with_side else st(3)
+    mg_handover(w0, w1, have, start, 0, st(5), cap=64)
+    mg_handover2(tag + "t", w0, w1, have, start, 0, st(5), cap=64, flag=False)
+    E(f"""
+    ds_read_b32 v44, {KL4T} offset:{LDS_LIST}
+    s_bfm_b64 {have}, {st(5)}, {start}
+    v_lshlrev_b32 v49, 5, {LANE}
+    s_waitcnt lgkmcnt(0)
+    v_mul_u32_u24 v45, 24, v44
+    {"v_mov_b32 v45, 0" if FAKE else ""}
+    s_mov_b64 exec, {have}
+    global_load_dwordx4 v[{X}:{X+3}], v45, {SRC}
+    global_load_dwordx2 v[{X+4}:{X+5}], v45, {SRC} offset:16
+    s_mov_b64 exec, -1
+    """)
+    coeff_one(C)
+    E(f"""
+    s_mov_b64 exec, {wl}
+    global_load_dwordx4 v[{X}:{X+3}], v49, {sp('wtab')}
+    global_load_dwordx4 v[{C}:{C+3}], v49, {sp('wtab')} offset:16
+    s_mov_b64 exec, -1
+    """)
+
+
 def assign_specials(tag, w0, w1, X, C, wl, pl, with_side, have):
     """zb, round 0 of a probe: every lane with a candidate takes its lowest one (load of its fp64 position asked
     for; `have` <- those lanes); the wall sites, the plane and -- for probe B after a move -- the side pair go to
@@ -2108,7 +2224,7 @@ if Z8C:
 if MG:
     pass
 elif ZB:
-    assign_specials("A", V['wa0'], V['wa1'], XA_, CA_, sp('wallM'), sp('planeM'), False, sp('haveA'))
+    (tt_assign if TL else assign_specials)("A", V['wa0'], V['wa1'], XA_, CA_, sp('wallM'), sp('planeM'), False, sp('haveA'))
 else:
     pick_fetch(V['wa0'], V['wa1'], XA_, sp('wallM'), sp('haveA'))
     wall_fetch(XA_, CA_)
@@ -2209,7 +2325,7 @@ if Z8C:
 if MG:
     pass
 elif ZB:
-    assign_specials("B", V['wb0'], V['wb1'], XB_, CB_, sp('wallB'), sp('planeB'), True, sp('haveB'))
+    (tt_assign if TL else assign_specials)("B", V['wb0'], V['wb1'], XB_, CB_, sp('wallB'), sp('planeB'), True, sp('haveB'))
 else:
     pick_fetch(V['wb0'], V['wb1'], XB_, stp(0), sp('haveB'))
     wall_fetch(XB_, CB_)
@@ -2235,65 +2351,6 @@ PV = ["v[14:15]", "v[16:17]", "v[18:19]"]      # mg: the probe of this lane's ha
 KSTA, KSTB = "v22", "v23"                      # mg: wlp's low word and stB as vector constants (start values of the ranks)
 MGW = "v[20:21]"                               # mg: probe B's sums (without the side pair), in both halves
 DdNm = "v[12:13]"                              # mg: displacement of move i+1 in group layout, asked for during the pass
-
-
-def mg_handover(w0, w1, h, start, off, n):
-    """every lane with a candidate in (w0, w1) hands its lowest one over: working lane = start + its rank among those lanes
-    (of this probe's half; only below 32), through list[off / 4 + lane]; h (s pair) <- the lanes that did, n (s) <- how many"""
-    hlo, hhi = (int(x) for x in h[2:-1].split(":"))
-    E(f"""
-    v_cmp_ne_u64 {h}, 0, v[{w0}:{w1}]
-    v_ffbl_b32 v46, v{w0}
-    v_ffbl_b32 v47, v{w1}
-    {"v_or_b32 v47, 32, v47" if start.startswith("v") else f"v_mov_b32 v45, {start}"}
-    v_mbcnt_lo_u32_b32 v45, s{hlo}, {start if start.startswith("v") else "v45"}
-    v_mbcnt_hi_u32_b32 v45, s{hhi}, v45
-    {"" if start.startswith("v") else "v_or_b32 v47, 32, v47"}
-    v_cmp_gt_u32 vcc, 32, v45
-    v_min_u32 v46, v46, v47
-    v_lshl_add_u64 v[48:49], v[{w0}:{w1}], 0, -1
-    s_and_b64 {h}, {h}, vcc
-    v_lshl_or_b32 v46, v46, 6, {LANE}
-    s_bcnt1_i32_b64 {n}, {h}
-    {"v_lshl_add_u32 v45, v45, 2, v1" if W4 else "v_lshlrev_b32 v45, 2, v45"}
-    s_mov_b64 exec, {h}
-    v_and_b32 v{w0}, v{w0}, v48
-    v_and_b32 v{w1}, v{w1}, v49
-    ds_write_b32 v45, v46 offset:{LDS_LIST + off}
-    s_mov_b64 exec, -1
-    """)
-
-
-def mg_handover2(tagc, w0, w1, h, start, off, n):
-    """the lanes that STILL hold a candidate after the hand-over (two of one probe in one lane: ~15 % of the probes) hand
-    that one over as well, to the working lanes behind the first batch, so that it is evaluated in the same pass instead
-    of a round of its own; what remains after that (a third candidate, a full half) sets bit 1 of nearB = "more rounds".
-    Cold piece; start (s), n (s): first working lane and count of the first batch, n is updated"""
-    def emit(txt):
-        (COLD if REDIR[0] is None else E)(txt)
-    E(f"""
-    v_cmp_ne_u64 vcc, 0, v[{w0}:{w1}]
-    s_cbranch_vccnz L_ho2{tagc}
-    L_ho2r{tagc}:
-    """)
-    save, REDIR[0] = REDIR[0], (cold if REDIR[0] is None else REDIR[0])
-    if save is not None:      # already among the cold pieces: in line, jumped over
-        E(f"s_branch L_ho2x{tagc}")
-    E(f"""
-    L_ho2{tagc}:
-    s_add_u32 {st(7)}, {start}, {n}
-    """)
-    mg_handover(w0, w1, h, st(7), off, st(7))
-    E(f"""
-    s_add_u32 {n}, {n}, {st(7)}
-    v_cmp_ne_u64 vcc, 0, v[{w0}:{w1}]
-    s_cbranch_vccz L_ho2r{tagc}
-    s_bitset1_b32 {s('nearB')}, 1
-    s_branch L_ho2r{tagc}
-    """)
-    if save is not None:
-        E(f"L_ho2x{tagc}:")
-    REDIR[0] = save
 
 
 def mg_probes():
@@ -2827,7 +2884,8 @@ if TT:
     # out the latency of every dependent instruction): M = the Metropolis argument of this move (SMC.c:326-335; row 0:
     # 4 (eA - eB), by selection instead of an exec mask), P = the proposal of particle n+1 (SMC.c:307-316) for both
     # outcomes: Fm = team B's total + the side result of the lane's half, q = p + (Fm A/T + displ), wrap of rows 1-2 by the
-    # per-row constants (0 in rows 0 and 3: no wrap), fixed point; the unsafe-z test of every lane goes to planeM's pair
+    # per-row constants (0 in rows 0 and 3: no wrap), fixed point; the unsafe-z test of every lane goes to planeM's pair (list hand-over: planeM is
+    # a constant of the launch there, so haveB's pair, dead once the probes are done)
     Mc = f"""
     v_add_f64 {vp('D',0)}, {FnV}, -{vp('FmV')}
     v_add_f64 {vp('D',1)}, {FnV}, {vp('FmV')}
@@ -2856,7 +2914,7 @@ if TT:
     v_rndne_f64 v[18:19], v[18:19]
     v_fma_f64 v[16:17], -v[18:19], {sp('L')}, v[16:17]
     v_mul_f64 v[18:19], v[16:17], {KFIX}
-    v_cmp_nlt_f64 {sp('planeM')}, |v[16:17]|, {sp('zsafe')}
+    v_cmp_nlt_f64 {sp('haveB' if TL else 'planeM')}, |v[16:17]|, {sp('zsafe')}
     v_rndne_f64 v[18:19], v[18:19]
     v_mov_b32 v24, 0x7fff
     v_mov_b32 v25, 0xffff8001
@@ -3162,7 +3220,7 @@ if TT:
     s_add_u32 {st(7)}, {st(4)}, 48
     v_cndmask_b32 {v('FmV')}, v14, {v('T')}, {stp(2)}
     v_cndmask_b32 {v('FmV',1)}, v15, {v('T',1)}, {stp(2)}
-    s_lshr_b64 {stp(2)}, {sp('planeM')}, {st(7)}
+    s_lshr_b64 {stp(2)}, {sp('haveB' if TL else 'planeM')}, {st(7)}
     s_and_b32 {s('ua')}, {st(2)}, 1
     v_readlane_b32 {s('Q',0)}, v16, {st(5)}
     v_readlane_b32 {s('Q',1)}, v17, {st(5)}
