@@ -1842,6 +1842,16 @@ def xchg2(part, fn, fb, extra=""):
     E("s_barrier")
     mark(6)
     E(extra)      # further LDS reads of the caller: they travel with the exchange reads
+    if KS == 4:   # all eight reads in flight at once (team B's into v24..v31, dead since the probes): one LDS round trip instead of two
+        for t0, w0_ in ((46, 0), (24, KS)):
+            for j in range(4):
+                E(f"ds_read_b64 v[{t0 + 2 * j}:{t0 + 2 * j + 1}], v45 offset:{LDS_X + 512 * (w0_ + j)}")
+        for dst, t0, cnt in ((fn, 46, 4), (fb, 24, 0)):
+            E(f"""s_waitcnt lgkmcnt({cnt})
+            v_add_f64 {dst}, v[{t0}:{t0 + 1}], v[{t0 + 2}:{t0 + 3}]
+            v_add_f64 {dst}, {dst}, v[{t0 + 4}:{t0 + 5}]
+            v_add_f64 {dst}, {dst}, v[{t0 + 6}:{t0 + 7}]""")
+        return
     for dst, w0_ in ((fn, 0), (fb, KS)):
         if KS == 1:
             E(f"ds_read_b64 {dst}, v45 offset:{LDS_X + 512 * w0_}")

@@ -110,13 +110,19 @@ def _tt_state(O, case):
         return _wrap(R, 33.0).ravel(), 33.0, 240.0, None, "ml16", {}
     if case == "mt64x8_benchmark":
         return O.fcc(16, 16), 33.0, 240.0, None, "mt64x8", {}
+    if case == "mt64x8_at_wall":       # the dense start pressed against the lower wall: wall sites, plane and side pair beside a
+        rs = np.random.RandomState(8)  # hand-over list that fills the wavefront (second hand-over, lanes left with a third candidate)
+        R = O.fcc(16, 16).reshape(-1, 3).copy()
+        R += 0.03 * rs.standard_normal(R.shape)
+        R[:, 2] += -118.9 - R[:, 2].min()
+        return _wrap(R, 33.0).ravel(), 33.0, 240.0, None, "mt64x8", {}
     if case == "mt64x8_two_slabs":
         R0, L, Lz, mode, _, extra = _state(O, "mc64x4_two_slabs")
         return R0, L, Lz, mode, "mt64x8", extra
     raise ValueError(case)
 
 
-TT_CASES = ["ml16_benchmark", "ml16_ragged_no_walls", "ml16_at_wall", "mt64x8_benchmark", "mt64x8_two_slabs"]
+TT_CASES = ["ml16_benchmark", "ml16_ragged_no_walls", "ml16_at_wall", "mt64x8_benchmark", "mt64x8_two_slabs", "mt64x8_at_wall"]
 
 CASES = ["dense_film", "dense_film_at_wall", "thin_film", "two_slabs_ragged", "unsafe_z_mb64", "unsafe_z_ma64", "resort_3", "mc16_dense",
          "ml16_dense", "mc32_two_slabs", "mc32x4_dense", "mc64x4_two_slabs"]
@@ -126,7 +132,7 @@ CASES = ["dense_film", "dense_film_at_wall", "thin_film", "two_slabs_ragged", "u
 def test_rare_path_against_oracle(S, O, case):
     R0, L, Lz, mode, kernel, extra = _tt_state(O, case) if case in TT_CASES else _state(O, case)
     N = R0.size // 3
-    nrep, eq, nsw = 2, 0, (3 if case == "resort_3" else 4 if N <= 1024 else 2 if N <= 2304 else 1)
+    nrep, eq, nsw = 2, 0, (3 if case == "resort_3" else 4 if N <= 1024 else 2 if N <= 2304 or case.startswith("mt64x8") else 1)
     flags = S.FLAG_SERIES | (S.FLAG_E0_RESTART if mode == "nowalls" else S.FLAGS_REFERENCE)
     geom = {"mc64": (64, 1), "mb64": (64, 1), "ma64": (64, 1), "mc32": (32, 1), "mc16": (16, 1), "ml16": (16, 1), "mc32x4": (0, 0),
             "mc64x4": (64, 4), "mt64x8": (64, 8)}[kernel]
@@ -151,7 +157,7 @@ def test_rare_path_against_oracle(S, O, case):
         assert np.abs(Rg[r] - ref["R"]).max() < 1e-8, (case, r)
         assert np.array_equal(ob["zhist"][r], ref["zhist"]), (case, r)
         total += int(ref["accepted"])
-    assert total > 0 or case in ("dense_film", "dense_film_at_wall", "mc32x4_dense"), case
+    assert total > 0 or case in ("dense_film", "dense_film_at_wall", "mc32x4_dense", "mt64x8_at_wall"), case
 
 
 def test_benchmark_kernel_ensemble_statistics_against_the_oracle(S, O):
