@@ -2858,7 +2858,7 @@ if TT:
     s_add_u32 {st(1)}, {s('i')}, 1
     s_mul_i32 {st(1)}, {st(1)}, 24
     v_add_u32 {v('S6')}, {st(1)}, {KPROW}
-    global_load_dwordx2 {DdN}, {v('S6')}, {sp('dK')}
+    global_load_dwordx2 {DdN}, {v('S6')}, {sp('dK')}{NT}
     L_nodd:
     // what the part after the exchange reads from LDS, per lane: component (row - 1) of particle n+1's position (row cache)
     // and the side pair's result [row][rejected | accepted] of this move's buffer

@@ -720,7 +720,8 @@ def test_byte_screen_kernel_corner_cases_against_fp64_kernel(S, O, case):
 @pytest.mark.parametrize("M,N,lat,slots,waves", [(1, 4096, (8, 16), 64, 1), (2, 4096, (8, 16), 64, 1), (5, 4096, (8, 16), 64, 1),
                                                 (2, 1024, (8, 4), 16, 1), (5, 2048, (8, 8), 32, 1),
                                                 (1, 1024, (8, 4), 16, 1), (5, 1024, (8, 4), 16, 1),   # N <= 1024: ml16
-                                                (2, 9216, (12, 16), 64, 8), (5, 6144, (16, 6), 32, 4)])  # two teams; 4 wavefronts
+                                                (2, 9216, (12, 16), 64, 8), (5, 9216, (12, 16), 64, 8),   # two teams (M = 5: 26 wall lanes + 2 side lanes in front of the list)
+                                                (5, 6144, (16, 6), 32, 4)])                                # 4 wavefronts
 def test_wall_grids_other_than_3x3_against_oracle(S, O, M, N, lat, slots, waves):
     """the hand-scheduled kernels give the M^2 wall sites and the plane to the first lanes without a candidate
     (their rank = row of the wall table): M = 1, 2, 5 (2, 5 and 26 special lanes) against the oracle, with the film
