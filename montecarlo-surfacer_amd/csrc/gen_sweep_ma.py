@@ -71,9 +71,13 @@ MUTE = [False]     # while set, nothing is emitted (the sections a variant repla
 REDIR = [None]     # while set to a list, E() appends there (whole sections emitted among the cold pieces)
 
 
+FORCE_TAG = [""]   # while set, lines without a tag of their own get this one (whole helpers emitted for one copy of the move only)
+
+
 def E(txt="", tag=""):
     if MUTE[0]:
         return
+    tag = tag or FORCE_TAG[0]
     for ln in txt.strip("\n").split("\n"):
         ln = ln.strip()
         if ln and not ln.startswith("//"):
@@ -164,6 +168,12 @@ MG = Z8 and not TT and os.environ.get("SMCX_GEN_NOMERGE") != "1"      # (switch 
 # merged pass (all 64 lanes work for the ONE probe of the wave; wall lanes and side lanes on fixed lanes in front), so a lane
 # with two candidates costs a second hand-over instead of a second pass of the fp64 body (round 3's PF2)
 TL = TT and os.environ.get("SMCX_GEN_TTLIST", "1") != "0"
+# "XC" (one wavefront per replica, steady copy of the move): the cells that are no neighbours of a probe -- the moving particle n
+# for both, particle n+1 itself for probe B -- keep their candidate bits and travel through the hand-over list like any other; the
+# working lane that reads one of them as its item is taken out of the pass by a compare of the item with the cell (4 instructions
+# where clearing the three bits in their owner lanes took 18).  The generic copy (moves without a proposal or without a next
+# particle, where locA / locB may be stale) keeps the bit clearing.
+XC = MG and not W4 and PEEL and os.environ.get("SMCX_GEN_XCMP", "1") != "0"
 PF2 = TT and NS >= 32 and not TL     # z8t with many cells: the first TWO candidates of a lane are fetched together (dense states: the
                           # second round's memory round trip was the longest stretch of the slowest wavefront's move)
 LP = (TT and NS == 16) or ZL
@@ -988,13 +998,17 @@ def rotate(tag):
 fill_p0("init")
 
 if Z8:
-    # the nlu pair holds the address the screens' computed jumps are relative to: block NG-1 of probe A's pass
-    # (a label further down: the offset is positive)
+    # the nlu pair holds the address the screens' computed jumps are relative to: where block 31 of probe A's pass in the steady
+    # copy would start if there were 32 (s_flbit counts from bit 31), so that pass adds nothing to flbit x block size
+    # (L_jb is a label further down, its offset positive; the step back is taken apart from it: the sum can be negative, and
+    # an unsigned add of a negative literal would carry into the high word)
     E(f"""
     s_getpc_b64 {sp('nlu')}
     L_jbase:
     s_add_u32 {s('nlu')}, {s('nlu')}, L_jb-L_jbase
     s_addc_u32 {s('nlu',1)}, {s('nlu',1)}, 0
+    s_sub_u32 {s('nlu')}, {s('nlu')}, {32 - NG}*(L_sg{NG-2}_A-L_sg{NG-1}_A)
+    s_subb_u32 {s('nlu',1)}, {s('nlu',1)}, 0
     """)
 
 # ---------------------------------------------------------------------------------------------- sweeps, runs
@@ -1206,19 +1220,20 @@ else:
   s_cmp_eq_u32 {s('hasA')}, 0
   s_cbranch_scc1 L_bfirst
   """)
+  RW = s('ub') if Z8 else st(1)   # z8: the row word itself stays in ub (its bit 16 = particle n+1 is beyond the safe z range)
   COLD(f"""
   L_bfirst:
   s_mov_b32 {s('bxys')}, {s('nxy')}
-  s_mov_b32 {st(1)}, {s('nzl')}
+  s_mov_b32 {RW}, {s('nzl')}
   s_branch L_bjoin
   """)
   E(f"""
   v_readlane_b32 {s('bxys')}, {v('rxy')}, {s('tl')}
-  v_readlane_b32 {st(1)}, {v('rzl')}, {s('tl')}
+  v_readlane_b32 {RW}, {v('rzl')}, {s('tl')}
   L_bjoin:
-  s_bfe_u32 {s('ub')}, {st(1)}, 0x10010
-  {f"s_lshr_b32 {s('nearB')}, {st(1)}, 31" if MG else ""}
-  {f"s_bfe_u32 {s('locB')}, {st(1)}, 0xe0011" if MG else f"s_lshr_b32 {s('locB')}, {st(1)}, 17"}
+  {"" if Z8 else f"s_bfe_u32 {s('ub')}, {st(1)}, 0x10010"}
+  {f"s_lshr_b32 {s('nearB')}, {RW}, 31" if MG else ""}
+  {f"s_bfe_u32 {s('locB')}, {RW}, 0xe0011" if MG else f"s_lshr_b32 {s('locB')}, {RW}, 17"}
   {"" if Z8 else f"s_and_b32 {st(1)}, {st(1)}, 0xffff"}
   {"" if Z8 else f"s_mul_i32 {s('bzz')}, {st(1)}, 0x10001"}
   L_nob1:
@@ -1385,18 +1400,21 @@ def screen_ranged8(tag, pws, w0, w1):
     v_cmp_ge_i32 vcc, {st(0)}, {v('gloR')}
     v_cmp_le_i32 {stp(2)}, {st(0)}, {v('ghiR')}
     s_and_b32 {st(1)}, vcc_lo, {st(2)}
-    s_cmp_eq_u32 {st(1)}, 0
-    s_cbranch_scc1 L_sdone_{tag}
+    s_cbranch_scc0 L_sdone_{tag}
     s_ff1_i32_b32 {st(4)}, {st(1)}
     s_flbit_i32_b32 {st(5)}, {st(1)}
     {f"s_add_u32 {st(1)}, {st(4)}, {st(5)}" if Z8C else ""}
     {f"s_sub_u32 {st(1)}, 32, {st(1)}" if Z8C else ""}
     s_mul_i32 {st(5)}, {st(5)}, L_sg{NG-2}_{tag}-L_sg{NG-1}_{tag}
-    s_add_u32 {st(5)}, {st(5)}, L_sg{NG-1}_{tag}-L_jb-{32 - NG}*(L_sg{NG-2}_A-L_sg{NG-1}_A)
+    """)
+    # (probe A's pass of the steady copy starts at L_jb: nothing to add)
+    (G if (tag == "A" and PEEL) else E)(f"s_add_u32 {st(5)}, {st(5)}, L_sg{NG-1}_{tag}-L_jb" if (tag != "A" or PEEL) else "")
+    E(f"""
     s_add_u32 {st(2)}, {s('nlu')}, {st(5)}
     s_addc_u32 {st(3)}, {s('nlu',1)}, 0
     s_setpc_b64 {stp(2)}
     """)
+    TWO = NS == 64 and GS == 4 and not Z8C    # two exits: a pass that ends in the upper word shifts that one only
     # blocks in descending group order; flbit = 31 - highest group, so block g sits (flbit - (32 - NG)) blocks in
     for g in range(NG - 1, -1, -1):
         if g == NG - 1 and tag == "A":
@@ -1408,7 +1426,22 @@ def screen_ranged8(tag, pws, w0, w1):
         if g > 0:
             if GS == 4:
                 E(f"s_cmp_eq_u32 {st(4)}, {g}")
-            E(f"s_cbranch_scc1 L_sfin_{tag}")
+            E(f"s_cbranch_scc1 L_sfin{('H' if GS * g >= 32 else 'L') if TWO else ''}_{tag}")
+    if TWO:
+        # the bits of the groups in reach lie at the bottom of their word: the word that holds the lowest group is shifted to
+        # its slots (4 x lowest group, mod 32: v_lshlrev reads five bits); a pass that crossed into the lower word left the
+        # upper one's bits where they belong
+        E(f"""
+        L_sfinL_{tag}:
+        s_lshl_b32 {st(0)}, {st(4)}, {GSH}
+        v_lshlrev_b32 {w0}, {st(0)}, {w0}
+        s_branch L_sdone_{tag}
+        L_sfinH_{tag}:
+        s_lshl_b32 {st(0)}, {st(4)}, {GSH}
+        v_lshlrev_b32 {w1}, {st(0)}, {w1}
+        L_sdone_{tag}:
+        """)
+        return
     E(f"L_sfin_{tag}:")
     if Z8C:   # executed work: groups of this pass = highest - lowest + 1 = 32 - flbit - ff1 (in st(1) since the jump)
         cnt_addr("v16")
@@ -2220,7 +2253,9 @@ E(f"""
 L_ua0:
 """)
 if ZB:
+    FORCE_TAG[0] = " @G" if XC else ""
     excl(v('wa0'), v('wa1'), s('locA'))    # the moving particle itself is not a neighbour of its proposal
+    FORCE_TAG[0] = ""
 else:
     E(f"""
     // the moving particle itself (slot 0 of lane tl) is not a neighbour of its proposal
@@ -2277,8 +2312,9 @@ if not Z8:
     s_lshl_b32 {st(0)}, {st(0)}, 3
     s_load_dwordx2 {sp('nlu')}, {sp('uK')}, {st(0)}
     """)
+UBTEST = f"s_bitcmp1_b32 {s('ub')}, 16" if Z8 else ("s_cmp_%s_u32 %s, 0" % ("lg" if ZB else "eq", s('ub')))
 E(f"""
-s_cmp_{"lg" if ZB else "eq"}_u32 {s('ub')}, 0
+{UBTEST}
 s_cbranch_scc1 {"L_ubC" if ZB else "L_ub0"}
 """)
 if ZB:
@@ -2292,12 +2328,16 @@ L_ub0:
 """)
 if ZB:
     # not neighbours of B: the particle it stands for, and the moving particle n, which reaches B through the side pair
+    FORCE_TAG[0] = " @G" if XC else ""
     excl(v('wb0'), v('wb1'), s('locB'))
+    FORCE_TAG[0] = ""
     G(f"""
     s_cmp_eq_u32 {s('hasA')}, 0
     s_cbranch_scc1 L_fb1
     """)
+    FORCE_TAG[0] = " @G" if XC else ""
     excl(v('wb0'), v('wb1'), s('locA'))
+    FORCE_TAG[0] = ""
     E(f"""
     L_fb1:
     // B's four loads (candidate x2, wall row x2) are asked for without waiting for probe A's: probe A's body waits
@@ -2576,6 +2616,13 @@ def mg_round0(near):
         """)
         for j in range(4):
             E(f"v_mov_b64 {vp('acc', j)}, 0")
+    if XC:   # steady copy: a lane whose item is particle n's cell (either half) or particle n+1's (half B) has no item
+        SO(f"""
+        v_cmp_ne_u32 vcc, {s('locA')}, v44
+        s_and_b64 {stp(0)}, {stp(0)}, vcc
+        v_cmp_ne_u32 vcc, {s('locB')}, v44
+        s_and_b32 {st(1)}, {st(1)}, vcc_hi
+        """)
     # everything that has an item: candidates, wall lanes, side lanes
     E(f"""
     s_or_b64 {stp(6)}, {stp(0)}, {wl}
@@ -2635,6 +2682,13 @@ def mg_more():
     s_mov_b64 exec, -1
     """)
     coeff_one(CA_)
+    if XC:
+        SO(f"""
+        v_cmp_ne_u32 vcc, {s('locA')}, v44
+        s_and_b64 {stp(0)}, {stp(0)}, vcc
+        v_cmp_ne_u32 vcc, {s('locB')}, v44
+        s_and_b32 {st(1)}, {st(1)}, vcc_hi
+        """)
     E("s_waitcnt vmcnt(0) lgkmcnt(0)")
     body("mm", PV, XA_, CA_, stp(0), False)
     E("s_branch L_mgR0")
@@ -3324,7 +3378,7 @@ if Z8:
     s_lshl_b32 {st(1)}, {st(1)}, 8
     s_and_b32 {st(1)}, {st(1)}, 0xff00
     s_or_b32 {st(0)}, {st(0)}, {st(1)}
-    s_pack_ll_b32_b16 {st(0)}, {st(2)}, {st(0)}
+    s_pack_ll_b32_b16 {s('axys')}, {st(2)}, {st(0)}
     """)
 else:
     E(f"""
@@ -3335,7 +3389,7 @@ else:
     s_mul_i32 {s('azz')}, {s('az16')}, 0x10001
     """)
 E(f"""
-{f"s_mov_b32 {s('axys')}, {st(0)}" if ZB else f"v_mov_b32 {v('axy')}, {st(0)}"}
+{"" if Z8 else f"s_mov_b32 {s('axys')}, {st(0)}" if ZB else f"v_mov_b32 {v('axy')}, {st(0)}"}
 """)
 E(f"s_cmp_eq_u32 {s('tl')}, 63" if ZB else f"s_cmp_eq_u32 {s('cross')}, 1")
 E("s_cbranch_scc0 L_nocross")
@@ -3528,10 +3582,25 @@ if PEEL:
     out[MOVE_AT:MOVE_END] = ste + gen
 elif COLD_AT is not None:
     out[COLD_AT:COLD_AT] = cold
+# peephole: a full write of exec that the next instruction (labels in between do not matter: whoever jumps there arrives behind
+# it) overwrites in full is dead -- the helpers each restore exec = -1 at their end, and the next one sets its own mask
+def _dead_exec_writes(lines):
+    keep, n = [], 0
+    for i, l in enumerate(lines):
+        if l.startswith("s_mov_b64 exec, "):
+            j = i + 1
+            while j < len(lines) and re.fullmatch(r"L_\w+:", lines[j]):
+                j += 1
+            if j < len(lines) and lines[j].startswith("s_mov_b64 exec, "):
+                n += 1
+                continue
+        keep.append(l)
+    return keep, n
+out, NDEAD = _dead_exec_writes(out)
 with open(sys.argv[1] if len(sys.argv) > 1 else "smcx_sweep_ma_body.inc", "w") as f:
     f.write("// generated by gen_sweep_ma.py -- do not edit\n")
     for ln in out:
         # labels are per variant: the three bodies are assembled into one object
         ln = re.sub(r"\bL_(\w+)", r"L%d%s%s_\1" % (NS, MODE, "x%d" % WPR if W4 else ""), ln)
         f.write('"%s\\n\\t"\n' % ln)
-print("%d lines" % len(out), file=sys.stderr)
+print("%d lines (%d dead exec writes dropped)" % (len(out), NDEAD), file=sys.stderr)

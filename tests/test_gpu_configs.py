@@ -282,7 +282,13 @@ def test_hand_scheduled_kernel_matches_compiled_kernel(S, O, tmp_path, N, lat, n
         assert np.array_equal(out[tag]["jj"], out["mi"]["jj"]) and out[tag]["jj"].sum() > 0, tag
         dE = np.abs(out[tag]["E"] - out["mi"]["E"])
         assert np.all(dE <= 1e-9 * (1.0 + np.abs(out["mi"]["E"]))), (tag, dE.max())
-        assert np.abs(out[tag]["R"] - out["mi"]["R"]).max() < 1e-8, tag
+        # positions: two correct kernels drift apart by rounding alone, a factor 30-500 per sweep in the worst replica
+        # (tools/probes/ragged_divergence.py, profiles/r04_rounding_drift_two_kernels.txt: N = 4000, max over 64 replicas
+        # 2e-11 / 3e-10 / 1e-8 .. 1.5e-7 after 1 / 2 / 3 sweeps, the median replica 1e-13 / 1e-12 / 1e-11, and either
+        # kernel as far from the ORACLE as from the other) -- so the typical replica is held to 1e-9 and the worst to
+        # 1e-5, still 500 x below the shift of one missed pair
+        dR = np.abs(out[tag]["R"] - out["mi"]["R"]).max(axis=1)
+        assert np.median(dR) < 1e-9 and dR.max() < 1e-5, (tag, np.median(dR), dR.max())
 
 
 def test_several_sweeps_per_launch_between_sorts(S, O, tmp_path):
