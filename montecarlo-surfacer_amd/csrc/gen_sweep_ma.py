@@ -2380,8 +2380,8 @@ else:
     pick_fetch(V['wb0'], V['wb1'], XB_, stp(0), sp('haveB'))
     wall_fetch(XB_, CB_)
 MUTE[0] = MG
+# probe B's fp64 position from the LDS cache: row = cross ? 64 : tl + 1 (= tl + 1 either way)
 E(f"""
-// probe B's fp64 position from the LDS cache: row = cross ? 64 : tl + 1 (= tl + 1 either way)
 s_add_u32 {st(0)}, {s('tl')}, 1
 s_mul_i32 {st(0)}, {st(0)}, 24
 {f"v_add_u32 {v('T')}, {st(0)}, v1" if W4 else f"v_mov_b32 {v('T')}, {st(0)}"}
@@ -2404,8 +2404,11 @@ DdNm = "v[12:13]"                              # mg: displacement of move i+1 in
 
 
 def mg_probes():
-    """the probes of the two halves: lanes 0..31 <- Q (the proposal, s), lanes 32..63 <- p0[tl + 1] (particle n+1)"""
-    E(f"""
+    """the probes of the two halves: lanes 0..31 <- Q (the proposal, s), lanes 32..63 <- p0[tl + 1] (particle n+1); the steady
+    copy leaves v47 = the address of row tl of the row cache (mg_side_sources reads particle n's position through it)"""
+    # (the steady copy's tl and i are never negative: one 24-bit multiply-add and the instruction's offset field; the first pass
+    # of a run, with tl = -1 or i = -1, is the generic copy's and keeps the scalar arithmetic)
+    old = f"""
     s_add_u32 {st(7)}, {s('tl')}, 1
     s_mul_i32 {st(7)}, {st(7)}, 24
     {f"v_add_u32 v44, {st(7)}, v1" if W4 else f"v_mov_b32 v44, {st(7)}"}
@@ -2416,6 +2419,21 @@ def mg_probes():
     ds_read_b64 {PV[0]}, v44 offset:{LDS_P0}
     ds_read_b64 {PV[1]}, v44 offset:{LDS_P0 + 8}
     ds_read_b64 {PV[2]}, v44 offset:{LDS_P0 + 16}
+    s_mov_b32 exec_lo, -1
+    """
+    if not PEEL:
+        E(old)
+        return
+    G(old)
+    SO(f"""
+    v_mad_u32_u24 v47, {s('tl')}, 24, {"v1" if W4 else "0"}
+    v_mov_b64 {PV[0]}, {sp('Q',0)}
+    v_mov_b64 {PV[1]}, {sp('Q',1)}
+    v_mov_b64 {PV[2]}, {sp('Q',2)}
+    s_mov_b32 exec_lo, 0
+    ds_read_b64 {PV[0]}, v47 offset:{LDS_P0 + 24}
+    ds_read_b64 {PV[1]}, v47 offset:{LDS_P0 + 32}
+    ds_read_b64 {PV[2]}, v47 offset:{LDS_P0 + 40}
     s_mov_b32 exec_lo, -1
     """)
 
@@ -2455,9 +2473,11 @@ def mg_wall_dz(tag):
 def mg_side_sources(lane_old):
     """the side pair's sources: lane `lane_old` (s) of half B <- particle n's CURRENT position p0[tl], the next lane <- the
     proposal Q; both evaluate against probe B (particle n+1)"""
-    E(f"""
+    (G if PEEL else E)(f"""
     s_mul_i32 {st(7)}, {s('tl')}, 24
     {f"v_add_u32 v47, {st(7)}, v1" if W4 else f"v_mov_b32 v47, {st(7)}"}
+    """)
+    E(f"""
     s_lshl_b64 exec, 1, {lane_old}
     ds_read_b64 v[{XA_}:{XA_+1}], v47 offset:{LDS_P0}
     ds_read_b64 v[{XA_+2}:{XA_+3}], v47 offset:{LDS_P0 + 8}
@@ -2527,9 +2547,19 @@ def mg_round0(near):
     E(f"""
     ds_read_b32 v44, {KL4} offset:{LDS_LIST}
     s_bfm_b64 {stp(0)}, {st(5)}, {startA}
-    s_bfm_b64 {stp(6)}, {st(6)}, {startB}
-    s_mov_b32 {st(1)}, {st(6)}
     """)
+    if near or not PEEL or W4:
+        E(f"""
+        s_bfm_b64 {stp(6)}, {st(6)}, {startB}
+        s_mov_b32 {st(1)}, {st(6)}
+        """)
+    else:   # steady copy, one wavefront per replica: half B has its two side lanes in front, so fewer than 32 candidate lanes --
+            # a 32-bit field does (with several, the waves without special lanes can have all 32)
+        G(f"""
+        s_bfm_b64 {stp(6)}, {st(6)}, {startB}
+        s_mov_b32 {st(1)}, {st(6)}
+        """)
+        SO(f"s_bfm_b32 {st(1)}, {st(6)}, {startB}")
     if near:
         # wl = the wall lanes, pl = the planes (last wall lane of a half), the side lanes behind half B's wall lanes
         E(f"""
@@ -2595,13 +2625,17 @@ def mg_round0(near):
     s_cmp_eq_u32 {s('hasB')}, 0
     s_cbranch_scc1 L_ndd_{tag}
     """)
-    E(f"""
+    (G if PEEL else E)(f"""
     s_add_u32 {st(2)}, {s('i')}, 1
     s_mul_i32 {st(2)}, {st(2)}, 24
     v_add_u32 v45, {st(2)}, {KC}
     global_load_dwordx2 {DdNm}, v45, {sp('dK')}{NT}
-    L_ndd_{tag}:
     """)
+    SO(f"""
+    v_mad_u32_u24 v45, {s('i')}, 24, {KC}
+    global_load_dwordx2 {DdNm}, v45, {sp('dK')} offset:24{NT}
+    """)
+    E(f"L_ndd_{tag}:")
     # coefficients: 1 for the candidates, (a0, b0) for a plane, the table's for wall sites
     if near:
         coeff_one(CA_)
@@ -2908,6 +2942,9 @@ if TT:
     s_cmp_eq_u32 {s('hasB')}, 0
     s_cbranch_scc1 L_nodd
     """)
+    # (one v_mad_u32_u24 + the offset field instead of the scalar arithmetic, as in the merged pass, measured here: config 5
+    # 22.15 -> 22.51 ms per sweep -- a VALU result that the next memory instruction needs costs this kernel's lone wavefronts
+    # more than two scalar instructions do; profiles/r04_address_arithmetic_ab.txt)
     E(f"""
     s_add_u32 {st(1)}, {s('i')}, 1
     s_mul_i32 {st(1)}, {st(1)}, 24
@@ -3091,7 +3128,7 @@ v_mov_b32 {v('T',1)}, {st(1)}
 v_fma_f64 {vp('T')}, {vp('T')}, 4.0, {sp('E')}
 s_lshl_b64 {stp(0)}, 1, {s('tl')}
 s_add_u32 {st(2)}, {s('first')}, {s('i')}
-s_mul_i32 {st(2)}, {st(2)}, 24
+{"" if ZB else f"s_mul_i32 {st(2)}, {st(2)}, 24"}
 v_readfirstlane_b32 {s('E')}, {v('T')}
 v_readfirstlane_b32 {s('E',1)}, {v('T',1)}
 """)
@@ -3124,7 +3161,6 @@ else:
     # the particle's cell: packed x,y (indexed register write), unsafe bit, int16 z; then lane g: the group's range
     E(f"""
     {f"s_and_b32 {st(3)}, {s('locA')}, {NS * 64 - 1}" if W4 else ""}
-    s_mul_i32 {st(3)}, {st(3) if W4 else s('locA')}, 24
     s_mov_b64 exec, {stp(0)}
     v_mov_b32 v50, {s('Q',0)}
     v_mov_b32 v51, {s('Q',1)}
@@ -3132,8 +3168,8 @@ else:
     v_mov_b32 v53, {s('Q',3)}
     v_mov_b32 v54, {s('Q',4)}
     v_mov_b32 v55, {s('Q',5)}
-    v_mov_b32 {v('T',1)}, {st(2)}
-    v_mov_b32 {v('T')}, {st(3)}
+    v_mad_u32_u24 {v('T',1)}, {st(2)}, 24, 0
+    v_mad_u32_u24 {v('T')}, {st(3) if W4 else s('locA')}, 24, 0
     {f"v_mad_u32_u24 {v('S6')}, {LANE}, 24, v1" if W4 else f"v_mul_u32_u24 {v('S6')}, 24, {LANE}"}
     global_store_dwordx4 {v('T',1)}, v[50:53], {sp('Rg')}{NT}
     global_store_dwordx2 {v('T',1)}, v[54:55], {sp('Rg')} offset:16{NT}
@@ -3209,10 +3245,19 @@ if MG:
     # ---- Fm of particle n+1 = probe B's sums + the side result that applies; then its proposal, in group layout
     E(f"""
     s_mov_b64 {sp('lu')}, {sp('nxy')}
+    """)
+    (G if PEEL else E)(f"""
     s_add_u32 {st(2)}, {s('tl')}, 1
     s_mul_i32 {st(2)}, {st(2)}, 24
     {f"v_add3_u32 v49, {st(2)}, {KC}, v1" if W4 else f"v_add_u32 v49, {st(2)}, {KC}"}
     ds_read_b64 {vp('D',0)}, v49 offset:{LDS_P0}
+    """)
+    SO(f"""
+    v_mad_u32_u24 v49, {s('tl')}, 24, {KC}
+    {"v_add_u32 v49, v49, v1" if W4 else ""}
+    ds_read_b64 {vp('D',0)}, v49 offset:{LDS_P0 + 24}
+    """)
+    E(f"""
     v_mov_b32 {v('FmV')}, v20
     v_mov_b32 {v('FmV',1)}, v21
     """)
