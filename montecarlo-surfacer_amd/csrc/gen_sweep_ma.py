@@ -940,12 +940,27 @@ def fill_p0(tag):
     fill_p0_end()
 
 
+def mg_coeff_init(emit):
+    """the merged pass's coefficient registers: 1 for candidates and side lanes, (a0, b0) on the plane lanes (the words of wlp).
+    The steady copy of the move keeps them from move to move: they are set where wlp changes (end of a generic pass), after
+    a row fill (which uses the registers) and behind the cold pieces that write them (near pass, further rounds)"""
+    emit(f"""
+    v_mov_b64 v[{V["C"]}:{V["C"]+1}], 1.0
+    v_mov_b64 v[{V["C"]+2}:{V["C"]+3}], 1.0
+    s_mov_b64 exec, {sp('wlp')}
+    v_mov_b64 v[{V["C"]}:{V["C"]+1}], {sp('a0s')}
+    v_mov_b64 v[{V["C"]+2}:{V["C"]+3}], {sp('b0s')}
+    s_mov_b64 exec, -1
+    """)
+
+
 def fill_p0_end():
     if MG:   # the row fill used the registers of the merged pass's vector constants
         E(f"""
         v_mov_b32 v22, {s('wlp')}
         v_mov_b32 v23, {s('stB')}
         """)
+        mg_coeff_init(E)
         if W4:
             E(f"""
             v_bfe_u32 v14, {LANE}, 3, 1
@@ -1744,9 +1759,10 @@ def body(tag, P, X, C, items, round0, wl=None, pl=None):
     """)
     if round0:
         E(f"s_or_b64 vcc, vcc, {pl}")
+    # (round 0 of the merged pass: with walls a plane lane is always in, and without them an empty exec costs the same instructions)
     E(f"""
     s_and_b64 exec, exec, vcc
-    s_cbranch_execz L_nolj_{tag}
+    {"" if (MG and round0) else f"s_cbranch_execz L_nolj_{tag}"}
     v_rcp_f64 {vp('ir2')}, {vp('dr2')}
     s_nop 0
     v_fma_f64 {vp('T')}, -{vp('dr2')}, {vp('ir2')}, 1.0
@@ -2593,13 +2609,7 @@ def mg_round0(near):
     mg_side_sources(lane_old)
     E(f"L_nss_{tag}:")
     if not near:   # what does not depend on the LDS reads in flight (list item, probe B, side sources) goes in front of the wait
-        coeff_one(CA_)
-        E(f"""
-        s_mov_b64 exec, {pl}
-        v_mov_b64 v[{CA_}:{CA_+1}], {sp('a0s')}
-        v_mov_b64 v[{CA_+2}:{CA_+3}], {sp('b0s')}
-        s_mov_b64 exec, -1
-        """)
+        mg_coeff_init(G if PEEL else E)      # (the steady copy finds them set)
         for j in range(4):
             E(f"v_mov_b64 {vp('acc', j)}, 0")
     E(f"""
@@ -2678,6 +2688,7 @@ def mg_round0(near):
     mg_side_capture(sides, lane_old)
     E(f"L_nsc_{tag}:")
     if near:
+        mg_coeff_init(SO)     # (the wall lanes held the table's coefficients)
         E("s_branch L_mgR0")
 
 
@@ -2725,6 +2736,7 @@ def mg_more():
         """)
     E("s_waitcnt vmcnt(0) lgkmcnt(0)")
     body("mm", PV, XA_, CA_, stp(0), False)
+    mg_coeff_init(SO)         # (the plane lanes worked with 1, 1)
     E("s_branch L_mgR0")
 
 
@@ -3257,7 +3269,8 @@ if MG:
     {"v_add_u32 v49, v49, v1" if W4 else ""}
     ds_read_b64 {vp('D',0)}, v49 offset:{LDS_P0 + 24}
     """)
-    E(f"""
+    # (a pass without the side pair -- generic copy only -- takes probe B's sums as they are)
+    (G if PEEL else E)(f"""
     v_mov_b32 {v('FmV')}, v20
     v_mov_b32 {v('FmV',1)}, v21
     """)
@@ -3271,10 +3284,14 @@ if MG:
     {f"s_add_u32 {st(0)}, {st(0)}, {s('accf')}" if W4 else ""}
     v_lshl_add_u32 v48, {st(0) if W4 else s('accf')}, 5, {KSD}
     ds_read_b64 v[46:47], v48 offset:{LDS_SIDEM}
-    s_waitcnt lgkmcnt(0)
-    v_add_f64 {vp('FmV')}, {MGW}, v[46:47]
-    L_nsr:
-    s_waitcnt vmcnt(0) lgkmcnt(0)
+    """)
+    # (steady copy: one wait for the side result and the displacement, which the next instruction but one needs anyway)
+    (G if PEEL else E)("s_waitcnt lgkmcnt(0)")
+    SO("s_waitcnt vmcnt(0) lgkmcnt(0)")
+    E(f"v_add_f64 {vp('FmV')}, {MGW}, v[46:47]")
+    E("L_nsr:")
+    (G if PEEL else E)("s_waitcnt vmcnt(0) lgkmcnt(0)")
+    E(f"""
     v_mov_b32 {v('DdV')}, v12
     v_mov_b32 {v('DdV',1)}, v13
     v_fma_f64 {vp('D',1)}, {vp('FmV')}, {sp('AoT')}, {DdNm}
@@ -3473,8 +3490,9 @@ if MG:   # what the next pass has: plane of half A (a proposal and walls), of ha
     s_lshl_b32 {s('sidesHi')}, {st(1)}, {s('wlp',1)}
     v_mov_b32 v22, {s('wlp')}
     v_mov_b32 v23, {s('stB')}
-    s_cmp_lt_i32 {st(0)}, {s('len')}
     """)
+    mg_coeff_init(G)
+    G(f"s_cmp_lt_i32 {st(0)}, {s('len')}")
 # the next pass has a proposal to decide (hasA) and a next particle (hasB): the steady copy runs it
 E("s_cbranch_scc1 L_S_move" if PEEL else "")
 SO(f"""
