@@ -174,6 +174,10 @@ TL = TT and os.environ.get("SMCX_GEN_TTLIST", "1") != "0"
 # where clearing the three bits in their owner lanes took 18).  The generic copy (moves without a proposal or without a next
 # particle, where locA / locB may be stale) keeps the bit clearing.
 XC = MG and not W4 and PEEL and os.environ.get("SMCX_GEN_XCMP", "1") != "0"
+# ... and in the two-team kernel with the list hand-over ("XCT"): a wave's list items are cells of ITS slab (slot << 6 | lane), so
+# the compare is with cell - (slab << WSH), which no item equals when the cell belongs to another wave (3 instructions per
+# exclusion on every wave, where the bit clearing took 4 on the waves that do not own the cell and 10 on the one that does)
+XCT = TL and PEEL and os.environ.get("SMCX_GEN_XCMP", "1") != "0"
 PF2 = TT and NS >= 32 and not TL     # z8t with many cells: the first TWO candidates of a lane are fetched together (dense states: the
                           # second round's memory round trip was the longest stretch of the slowest wavefront's move)
 LP = (TT and NS == 16) or ZL
@@ -256,6 +260,7 @@ if MG:
     if W4:   # the real cells of this wave move to azz (the merged pass needs no hasAw; M2w and hasAw are never written: the
         S.update(Nw=S['azz'])   # state of the pass -- wlp, stB, sidesHi -- is per wave, empty off the slab-0 wave)
 if TT:
+    S.update(wbase=S['cross'])    # XCT: slab << WSH (cross is not used by the z-ordered kernels)
     # team B's waves never use probe A's masks: haveA's low word holds the lane of the side pair evaluated with the
     # PROPOSAL (sideL: with n's current position); its high word carries the accept flag from the Metropolis step to
     # the point where the side result that applies is added (every wave; team A's haveA is dead by then)
@@ -523,6 +528,8 @@ if TT:
         # waves, where M2w = -1), the side pair on the two lanes behind them (team B's slab-0 wave)
         E(f"""
         v_lshl_add_u32 {KL4T}, {LANE}, 2, v1
+        s_and_b32 {st(0)}, {WAVE}, {KS - 1}
+        s_lshl_b32 {s('wbase')}, {st(0)}, {WSH}
         s_add_u32 {st(0)}, {s('M2w')}, 1
         s_bfm_b64 {sp('wallM')}, {st(0)}, 0
         s_mov_b64 {sp('wallB')}, {sp('wallM')}
@@ -1972,6 +1979,8 @@ def probe(tag, P, pz_sgpr, pz, w0, w1, X, C, have, side, wait, wl=None, pl=None)
         """)
     coeff_one(C)
     pick_fetch(w0, w1, X, "0", stp(6))
+    if TT:
+        tt_exclude(tag, stp(6))       # (v44 = the cell pick_fetch took from this lane's flag words)
     E("s_waitcnt lgkmcnt(0)" if LP else "s_waitcnt vmcnt(0)")
     body(tag + "rm", P, X, C, stp(6), False)
     E(f"s_branch L_more_{tag}")
@@ -2046,6 +2055,19 @@ def mg_handover2(tagc, w0, w1, h, start, off, n, cap=32, flag=True):
     REDIR[0] = save
 
 
+def tt_exclude(tag, items):
+    """XCT, steady copy: the lanes whose item (v44: a cell of this wave's slab) is a cell that is no neighbour of the probe --
+    particle n for both teams, particle n+1 itself for team B -- leave `items` (s pair)"""
+    if not XCT:
+        return
+    for loc in ([s('locA')] if tag.startswith("A") else [s('locB'), s('locA')]):
+        SO(f"""
+        s_sub_u32 {st(1)}, {loc}, {s('wbase')}
+        v_cmp_ne_u32 vcc, {st(1)}, v44
+        s_and_b64 {items}, {items}, vcc
+        """)
+
+
 def tt_assign(tag, w0, w1, X, C, wl, pl, with_side, have):
     """z8t (TL), round 0 of this wave's probe: its candidates are handed over to working lanes through the list -- behind the
     wall lanes (table row = lane; wl, pl, sideL, sideN are per-wave constants set in the prologue) and, on team B's slab-0
@@ -2077,6 +2099,7 @@ def tt_assign(tag, w0, w1, X, C, wl, pl, with_side, have):
     global_load_dwordx4 v[{C}:{C+3}], v49, {sp('wtab')} offset:16
     s_mov_b64 exec, -1
     """)
+    tt_exclude(tag, have)
 
 
 def assign_specials(tag, w0, w1, X, C, wl, pl, with_side, have):
@@ -2269,7 +2292,7 @@ E(f"""
 L_ua0:
 """)
 if ZB:
-    FORCE_TAG[0] = " @G" if XC else ""
+    FORCE_TAG[0] = " @G" if (XC or XCT) else ""
     excl(v('wa0'), v('wa1'), s('locA'))    # the moving particle itself is not a neighbour of its proposal
     FORCE_TAG[0] = ""
 else:
@@ -2344,14 +2367,14 @@ L_ub0:
 """)
 if ZB:
     # not neighbours of B: the particle it stands for, and the moving particle n, which reaches B through the side pair
-    FORCE_TAG[0] = " @G" if XC else ""
+    FORCE_TAG[0] = " @G" if (XC or XCT) else ""
     excl(v('wb0'), v('wb1'), s('locB'))
     FORCE_TAG[0] = ""
     G(f"""
     s_cmp_eq_u32 {s('hasA')}, 0
     s_cbranch_scc1 L_fb1
     """)
-    FORCE_TAG[0] = " @G" if XC else ""
+    FORCE_TAG[0] = " @G" if (XC or XCT) else ""
     excl(v('wb0'), v('wb1'), s('locA'))
     FORCE_TAG[0] = ""
     E(f"""
