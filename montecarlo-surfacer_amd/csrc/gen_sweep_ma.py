@@ -541,6 +541,15 @@ if TT:
         s_mov_b64 {sp('planeB')}, {sp('planeM')}
         s_add_u32 {s('sideL')}, {s('M2w')}, 1
         s_add_u32 {s('sideN')}, {s('M2w')}, 2
+        // the wall lanes' rows of the wall table, once per launch (tt_wall_rows restores them behind a further round)
+        v_mov_b64 v[{KR+14}:{KR+15}], 1.0
+        v_mov_b64 v[{KR+16}:{KR+17}], 1.0
+        v_lshlrev_b32 v49, 5, {LANE}
+        s_mov_b64 exec, {sp('wallM')}
+        global_load_dwordx4 v[{KR+8}:{KR+11}], v49, {sp('wtab')}
+        global_load_dwordx4 v[{KR+14}:{KR+17}], v49, {sp('wtab')} offset:16
+        s_mov_b64 exec, -1
+        s_waitcnt vmcnt(0)
         """)
     E(f"""
     s_load_dword {st(0)}, {KARG}, {K_RZ}
@@ -1968,6 +1977,7 @@ def probe(tag, P, pz_sgpr, pz, w0, w1, X, C, have, side, wait, wl=None, pl=None)
     v_cmp_ne_u64 vcc, 0, v[{w0}:{w1}]
     {"s_cbranch_vccz L_done_" + tag if ZB else "s_cmp_lg_u64 vcc, 0"}
     {"" if ZB else "s_cbranch_scc0 L_done_" + tag}
+    {f"L_moreB_{tag}:" if TL else ""}
     """)
     if Z8C:   # executed work: rounds beyond the first of a probe (a lane held two candidates)
         cnt_addr("v46")
@@ -1983,7 +1993,14 @@ def probe(tag, P, pz_sgpr, pz, w0, w1, X, C, have, side, wait, wl=None, pl=None)
         tt_exclude(tag, stp(6))       # (v44 = the cell pick_fetch took from this lane's flag words)
     E("s_waitcnt lgkmcnt(0)" if LP else "s_waitcnt vmcnt(0)")
     body(tag + "rm", P, X, C, stp(6), False)
-    E(f"s_branch L_more_{tag}")
+    if TL:   # a further round gave every lane coefficients 1, 1 and its own candidate: the wall lanes take their rows back
+        E(f"""
+        v_cmp_ne_u64 vcc, 0, v[{w0}:{w1}]
+        s_cbranch_vccnz L_moreB_{tag}
+        """)
+        tt_wall_rows()
+    else:
+        E(f"s_branch L_more_{tag}")
     E(f"L_done_{tag}:")
 
 
@@ -2055,6 +2072,20 @@ def mg_handover2(tagc, w0, w1, h, start, off, n, cap=32, flag=True):
     REDIR[0] = save
 
 
+def tt_wall_rows():
+    """TL: the wall lanes' items (site x, y) and coefficients from the wall table (row = lane), 1, 1 on the other lanes"""
+    E(f"""
+    v_mov_b64 v[{KR+14}:{KR+15}], 1.0
+    v_mov_b64 v[{KR+16}:{KR+17}], 1.0
+    v_lshlrev_b32 v49, 5, {LANE}
+    s_mov_b64 exec, {sp('wallM')}
+    global_load_dwordx4 v[{KR+8}:{KR+11}], v49, {sp('wtab')}
+    global_load_dwordx4 v[{KR+14}:{KR+17}], v49, {sp('wtab')} offset:16
+    s_mov_b64 exec, -1
+    s_waitcnt vmcnt(0)
+    """)
+
+
 def tt_exclude(tag, items):
     """XCT, steady copy: the lanes whose item (v44: a cell of this wave's slab) is a cell that is no neighbour of the probe --
     particle n for both teams, particle n+1 itself for team B -- leave `items` (s pair)"""
@@ -2083,7 +2114,6 @@ def tt_assign(tag, w0, w1, X, C, wl, pl, with_side, have):
     E(f"""
     ds_read_b32 v44, {KL4T} offset:{LDS_LIST}
     s_bfm_b64 {have}, {st(5)}, {start}
-    v_lshlrev_b32 v49, 5, {LANE}
     s_waitcnt lgkmcnt(0)
     v_mul_u32_u24 v45, 24, v44
     {"v_mov_b32 v45, 0" if FAKE else ""}
@@ -2092,13 +2122,7 @@ def tt_assign(tag, w0, w1, X, C, wl, pl, with_side, have):
     global_load_dwordx2 v[{X+4}:{X+5}], v45, {SRC} offset:16
     s_mov_b64 exec, -1
     """)
-    coeff_one(C)
-    E(f"""
-    s_mov_b64 exec, {wl}
-    global_load_dwordx4 v[{X}:{X+3}], v49, {sp('wtab')}
-    global_load_dwordx4 v[{C}:{C+3}], v49, {sp('wtab')} offset:16
-    s_mov_b64 exec, -1
-    """)
+    # (the wall lanes' rows of the table and every lane's coefficients are where the launch's prologue put them)
     tt_exclude(tag, have)
 
 
@@ -2246,6 +2270,12 @@ def all_real_cells(w0, w1, back):
 
 
 XA_, CA_, XB_, CB_ = 30, 26, 20, 10   # round-0 data: A in the D registers (d = p - X in place), B in v20..25; coefficients
+if TL:
+    # z8t with the list hand-over: the wall lanes are the same lanes in every move, so what they work with -- the site's
+    # (x, y) and its two coefficients, a row of the wall table -- is loaded ONCE per launch into registers of their own (and
+    # 1, 1 on every other lane) that nothing else writes: items and coefficients of both teams' probes live there
+    XA_ = XB_ = KR + 8
+    CA_ = CB_ = KR + 14
 
 # ---------------------------------------------------------------------------------------------- screen + fetch, probe A first
 if TT:   # team A screens and fetches for probe A only, team B for probe B only
