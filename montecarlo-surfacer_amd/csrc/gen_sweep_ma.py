@@ -523,6 +523,11 @@ if TT:
     KINV, KFIX, KPROW, KSIDE = f"v[{KR}:{KR+1}]", f"v[{KR+2}:{KR+3}]", f"v{KR+4}", f"v{KR+5}"
     KRZ = f"v{KR+6}"          # the reach of a group's z range (an accepted move widens its group's range by it)
     KL4T = f"v{KR+7}"         # TL: 4 lane + this wave's LDS block (the hand-over list is read from there)
+    # TL: the addresses that alternate with the parity of the move counter (exchange buffer: where this wave writes its partial
+    # sums, where every wave reads them; the side result's row of this move's buffer) are three registers toggled by one v_xor
+    # each where the counter is incremented, instead of being formed from the counter in every move (v{KR+8}..v{KR+17}: the
+    # wall lanes' rows, below)
+    VXW, VXR, VSR = f"v{KR+18}", f"v{KR+19}", f"v{KR+20}"
     if TL:
         # per-wave constants of the special lanes: wall sites and plane on lanes 0 .. M2w (the plane last; none off the slab-0
         # waves, where M2w = -1), the side pair on the two lanes behind them (team B's slab-0 wave)
@@ -1147,6 +1152,14 @@ else:
     E(f"""
     s_and_b32 {s('tl')}, {s('first')}, 63
     s_sub_u32 {s('tl')}, {s('tl')}, 1
+    """)
+if TL:   # the addresses that alternate with the parity of i, for i = -1 (odd)
+    E(f"""
+    s_movk_i32 {st(0)}, {WPR * 512}
+    v_lshl_add_u32 {VXR}, {LANE}, 3, {st(0)}
+    s_lshl_b32 {st(0)}, {WAVE}, 9
+    v_add_u32 {VXW}, {st(0)}, {VXR}
+    v_add_u32 {VSR}, 64, {KSIDE}
     """)
 E(f"""
 s_mov_b32 {s('i')}, -1
@@ -1867,11 +1880,11 @@ def side_capture():
     s_cbranch_scc1 L_nocap
     s_lshl_b64 {stp(0)}, 1, {s('sideL')}
     s_lshl_b64 {stp(2)}, 1, {s('sideN')}
-    s_and_b32 {st(4)}, {s('i')}, 1
-    s_lshl_b32 {st(4)}, {st(4)}, 6
+    {"" if TL else f"s_and_b32 {st(4)}, {s('i')}, 1"}
+    {"" if TL else f"s_lshl_b32 {st(4)}, {st(4)}, 6"}
     s_or_b64 exec, {stp(0)}, {stp(2)}
     v_cmp_eq_u32 vcc, {s('sideN')}, {LANE}
-    v_mov_b32 v44, {st(4)}
+    {f"v_and_b32 v44, 64, {VSR}" if TL else f"v_mov_b32 v44, {st(4)}"}
     s_nop 1
     v_cndmask_b32_e64 v45, 0, 32, vcc
     v_add_u32 v44, v44, v45
@@ -1893,14 +1906,20 @@ def xchg2(part, fn, fb, extra=""):
     fn = sum over team A's waves (probe A), fb = sum over team B's (probe B without the side pair), added in wave order
     by every wave alike.  Two buffers alternate with the parity of the move counter, so that a wave that is already in
     the next move cannot overwrite what a slower one still reads (the next barrier stops it before the move after)."""
+    if TL:
+        XW_, XR_ = VXW, VXR
+    else:
+        XW_, XR_ = "v44", "v45"
+        E(f"""
+        s_and_b32 {st(1)}, {s('i')}, 1
+        s_mul_i32 {st(1)}, {st(1)}, {WPR * 512}
+        s_lshl_b32 {st(0)}, {WAVE}, 9
+        s_add_u32 {st(0)}, {st(0)}, {st(1)}
+        v_lshl_add_u32 v44, {LANE}, 3, {st(0)}
+        v_lshl_add_u32 v45, {LANE}, 3, {st(1)}
+        """)
     E(f"""
-    s_and_b32 {st(1)}, {s('i')}, 1
-    s_mul_i32 {st(1)}, {st(1)}, {WPR * 512}
-    s_lshl_b32 {st(0)}, {WAVE}, 9
-    s_add_u32 {st(0)}, {st(0)}, {st(1)}
-    v_lshl_add_u32 v44, {LANE}, 3, {st(0)}
-    v_lshl_add_u32 v45, {LANE}, 3, {st(1)}
-    ds_write_b64 v44, {part} offset:{LDS_X}
+    ds_write_b64 {XW_}, {part} offset:{LDS_X}
     s_waitcnt lgkmcnt(0)
     """)
     mark(5)
@@ -1910,7 +1929,7 @@ def xchg2(part, fn, fb, extra=""):
     if KS == 4:   # all eight reads in flight at once (team B's into v24..v31, dead since the probes): one LDS round trip instead of two
         for t0, w0_ in ((46, 0), (24, KS)):
             for j in range(4):
-                E(f"ds_read_b64 v[{t0 + 2 * j}:{t0 + 2 * j + 1}], v45 offset:{LDS_X + 512 * (w0_ + j)}")
+                E(f"ds_read_b64 v[{t0 + 2 * j}:{t0 + 2 * j + 1}], {XR_} offset:{LDS_X + 512 * (w0_ + j)}")
         for dst, t0, cnt in ((fn, 46, 4), (fb, 24, 0)):
             E(f"""s_waitcnt lgkmcnt({cnt})
             v_add_f64 {dst}, v[{t0}:{t0 + 1}], v[{t0 + 2}:{t0 + 3}]
@@ -1919,12 +1938,12 @@ def xchg2(part, fn, fb, extra=""):
         return
     for dst, w0_ in ((fn, 0), (fb, KS)):
         if KS == 1:
-            E(f"ds_read_b64 {dst}, v45 offset:{LDS_X + 512 * w0_}")
+            E(f"ds_read_b64 {dst}, {XR_} offset:{LDS_X + 512 * w0_}")
             continue
         for k in range(0, KS, 4):
             n = min(4, KS - k)
             for j in range(n):
-                E(f"ds_read_b64 v[{46 + 2 * j}:{47 + 2 * j}], v45 offset:{LDS_X + 512 * (w0_ + k + j)}")
+                E(f"ds_read_b64 v[{46 + 2 * j}:{47 + 2 * j}], {XR_} offset:{LDS_X + 512 * (w0_ + k + j)}")
             E("s_waitcnt lgkmcnt(0)")
             for j in range(n):
                 if k == 0 and j == 0:
@@ -2276,6 +2295,7 @@ if TL:
     # 1, 1 on every other lane) that nothing else writes: items and coefficients of both teams' probes live there
     XA_ = XB_ = KR + 8
     CA_ = CB_ = KR + 14
+
 
 # ---------------------------------------------------------------------------------------------- screen + fetch, probe A first
 if TT:   # team A screens and fetches for probe A only, team B for probe B only
@@ -3021,9 +3041,9 @@ if TT:
     s_add_u32 {st(0)}, {s('tl')}, 1
     s_mul_i32 {st(0)}, {st(0)}, 24
     v_add3_u32 v22, {st(0)}, {KPROW}, v1
-    s_and_b32 {st(1)}, {s('i')}, 1
-    s_lshl_b32 {st(1)}, {st(1)}, 6
-    v_add_u32 v23, {st(1)}, {KSIDE}
+    {"" if TL else f"s_and_b32 {st(1)}, {s('i')}, 1"}
+    {"" if TL else f"s_lshl_b32 {st(1)}, {st(1)}, 6"}
+    {"" if TL else f"v_add_u32 v23, {st(1)}, {KSIDE}"}
     v_mov_b32 v14, 0
     v_mov_b32 v15, 0
     """)
@@ -3032,7 +3052,7 @@ if TT:
     ds_read_b64 v[16:17], v22 offset:{LDS_P0}
     s_cmp_lg_u32 {s('hasA')}, 0{TG}
     s_cselect_b64 exec, -1, 0{TG}
-    ds_read_b64 v[14:15], v23 offset:{LDS_SIDE}
+    ds_read_b64 v[14:15], {VSR if TL else "v23"} offset:{LDS_SIDE}
     s_mov_b64 exec, -1{TG}
     """)
     # this move's dX = Fm A/T + displ (D2; harmless without a move to decide), then the displacement of move i+1 (asked
@@ -3517,6 +3537,12 @@ mark(10)
 if ZB:
     E(f"s_mov_b32 {s('locA')}, {s('locB')}")
 E(f"s_add_u32 {s('i')}, {s('i')}, 1")
+if TL:
+    E(f"""
+    v_xor_b32 {VXR}, {WPR * 512}, {VXR}
+    v_xor_b32 {VXW}, {WPR * 512}, {VXW}
+    v_xor_b32 {VSR}, 64, {VSR}
+    """)
 G(f"""
 s_mov_b32 {s('hasA')}, 1
 {f"s_and_b32 {st(0)}, {WAVE}, {KS - 1}" if TT else ""}

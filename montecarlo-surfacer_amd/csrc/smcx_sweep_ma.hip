@@ -250,7 +250,7 @@ __global__ void __launch_bounds__(512, 1) sweep_kernel_mt64x8(MaArgs a)
 #endif
         : "+v"(lane), "+s"(kp), "+s"(rep), "+s"(wv)
         :
-        : "memory", "vcc", "scc", "m0", SMCX_MA_SGPRS, SMCX_MA_V127, "v128", "v129", "v130", "v131", "v132", "v133", "v134", "v135", "v136", "v137", "v138", "v139", "v140", "v141", "v142", "v143", "v144", "v145");
+        : "memory", "vcc", "scc", "m0", SMCX_MA_SGPRS, SMCX_MA_V127, "v128", "v129", "v130", "v131", "v132", "v133", "v134", "v135", "v136", "v137", "v138", "v139", "v140", "v141", "v142", "v143", "v144", "v145", "v146", "v147", "v148");
 }
 // LDS of the two-team kernels: a row cache per wave, the exchange area [2][waves][64] doubles, the side area
 #ifdef SMCX_CHECK

@@ -1,0 +1,14 @@
+# round-4 session 19 (through gpurun, repo root): two-team kernel with the parity-dependent addresses kept in registers and toggled -- its tests, then config 5
+# against the build before (libsmcx_prev.so)
+set -o pipefail
+timeout -k 10 700 python -m pytest tests -q -m gpu -k "mt64x8 or config5 or 64-8 or 9216 or several_wavefront" > gpurun_out/r04_toggle_tests.log 2>&1; tail -3 gpurun_out/r04_toggle_tests.log
+grep -q "failed\|error" gpurun_out/r04_toggle_tests.log && { grep "^FAILED" gpurun_out/r04_toggle_tests.log; exit 1; }
+for lib in smcx smcx_prev smcx smcx_prev; do
+SMCX_LIB=$PWD/montecarlo-surfacer_amd/lib$lib.so python bench.py --no-cpu --steps 6 --warmup 2 --N 16384 --replicas 256 2>/dev/null | python -c "
+import sys, json
+for l in sys.stdin:
+    if l.startswith('{'):
+        j = json.loads(l); r = j['roofline']
+        print('%-12s %8.4f ms/step  %.4e  sweep %.4f ms  %s' % ('$lib', j['ms_per_step'], j['value'], r['ms_per_sweep'], r['kernel']))
+"
+done | tee gpurun_out/r04_toggle_ab.txt
