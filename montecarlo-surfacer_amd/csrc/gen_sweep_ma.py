@@ -168,12 +168,12 @@ MG = Z8 and not TT and os.environ.get("SMCX_GEN_NOMERGE") != "1"      # (switch 
 # merged pass (all 64 lanes work for the ONE probe of the wave; wall lanes and side lanes on fixed lanes in front), so a lane
 # with two candidates costs a second hand-over instead of a second pass of the fp64 body (round 3's PF2)
 TL = TT and os.environ.get("SMCX_GEN_TTLIST", "1") != "0"
-# "XC" (one wavefront per replica, steady copy of the move): the cells that are no neighbours of a probe -- the moving particle n
+# "XC" (merged pass, steady copy of the move): the cells that are no neighbours of a probe -- the moving particle n
 # for both, particle n+1 itself for probe B -- keep their candidate bits and travel through the hand-over list like any other; the
 # working lane that reads one of them as its item is taken out of the pass by a compare of the item with the cell (4 instructions
 # where clearing the three bits in their owner lanes took 18).  The generic copy (moves without a proposal or without a next
 # particle, where locA / locB may be stale) keeps the bit clearing.
-XC = MG and not W4 and PEEL and os.environ.get("SMCX_GEN_XCMP", "1") != "0"
+XC = MG and PEEL and os.environ.get("SMCX_GEN_XCMP", "1") != "0"
 # ... and in the two-team kernel with the list hand-over ("XCT"): a wave's list items are cells of ITS slab (slot << 6 | lane), so
 # the compare is with cell - (slab << WSH), which no item equals when the cell belongs to another wave (3 instructions per
 # exclusion on every wave, where the bit clearing took 4 on the waves that do not own the cell and 10 on the one that does)
@@ -2492,6 +2492,29 @@ MGW = "v[20:21]"                               # mg: probe B's sums (without the
 DdNm = "v[12:13]"                              # mg: displacement of move i+1 in group layout, asked for during the pass
 
 
+def mg_exclude():
+    """XC, steady copy: a working lane whose item (v44) is particle n's cell (either half) or particle n+1's (half B) leaves the
+    candidates' mask stp(0).  Several wavefronts: an item is a cell of THIS wave's slab, so the compare is with cell - slab base
+    (no item equals it when the cell is another wave's)"""
+    if W4:
+        SO(f"""
+        s_lshl_b32 {st(6)}, {WAVE}, {WSH}
+        s_sub_u32 {st(7)}, {s('locA')}, {st(6)}
+        v_cmp_ne_u32 vcc, {st(7)}, v44
+        s_and_b64 {stp(0)}, {stp(0)}, vcc
+        s_sub_u32 {st(7)}, {s('locB')}, {st(6)}
+        v_cmp_ne_u32 vcc, {st(7)}, v44
+        s_and_b32 {st(1)}, {st(1)}, vcc_hi
+        """)
+    else:
+        SO(f"""
+        v_cmp_ne_u32 vcc, {s('locA')}, v44
+        s_and_b64 {stp(0)}, {stp(0)}, vcc
+        v_cmp_ne_u32 vcc, {s('locB')}, v44
+        s_and_b32 {st(1)}, {st(1)}, vcc_hi
+        """)
+
+
 def mg_probes():
     """the probes of the two halves: lanes 0..31 <- Q (the proposal, s), lanes 32..63 <- p0[tl + 1] (particle n+1); the steady
     copy leaves v47 = the address of row tl of the row cache (mg_side_sources reads particle n's position through it)"""
@@ -2734,12 +2757,7 @@ def mg_round0(near):
         for j in range(4):
             E(f"v_mov_b64 {vp('acc', j)}, 0")
     if XC:   # steady copy: a lane whose item is particle n's cell (either half) or particle n+1's (half B) has no item
-        SO(f"""
-        v_cmp_ne_u32 vcc, {s('locA')}, v44
-        s_and_b64 {stp(0)}, {stp(0)}, vcc
-        v_cmp_ne_u32 vcc, {s('locB')}, v44
-        s_and_b32 {st(1)}, {st(1)}, vcc_hi
-        """)
+        mg_exclude()
     # everything that has an item: candidates, wall lanes, side lanes
     E(f"""
     s_or_b64 {stp(6)}, {stp(0)}, {wl}
@@ -2801,12 +2819,7 @@ def mg_more():
     """)
     coeff_one(CA_)
     if XC:
-        SO(f"""
-        v_cmp_ne_u32 vcc, {s('locA')}, v44
-        s_and_b64 {stp(0)}, {stp(0)}, vcc
-        v_cmp_ne_u32 vcc, {s('locB')}, v44
-        s_and_b32 {st(1)}, {st(1)}, vcc_hi
-        """)
+        mg_exclude()
     E("s_waitcnt vmcnt(0) lgkmcnt(0)")
     body("mm", PV, XA_, CA_, stp(0), False)
     mg_coeff_init(SO)         # (the plane lanes worked with 1, 1)
