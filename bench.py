@@ -171,6 +171,9 @@ def executed_work(kname, N, lattice, slots, waves, device, nrep=64, sweeps=2):
             "fraction_of_all_pairs_screened": d["groups"] * 256.0 / moves / (2.0 * (N - 1)),
             "candidate_bits_per_probe": d["cand"] / (2.0 * moves), "pairs_inside_cutoff_per_probe": d["inside"] / (2.0 * moves),
             "pairs_inside_cutoff_missed": d["miss"],
+            "candidate_bits_note": "the bits of the cells that are no neighbours by construction (the moving particle, the probe's own "
+                                   "particle) are counted: the kernels drop those cells by a compare of the hand-over item, not by clearing "
+                                   "the bit (about 1.3 of the bits per probe at the benchmark start)",
             # rounds of the fp64 body beyond the first, per probe (a lane held two candidates of one probe)
             "further_rounds_per_probe": d.get("more_rounds", 0) / (2.0 * moves),
             # design statistic: probes in which some lanes l and l + 32 both held a candidate (per probe evaluated)
