@@ -15,7 +15,8 @@ NAMES = {1: "screen", 2: "excl/assign/fetch", 3: "probe round 0", 4: "further ro
          5: "displ load + write partials", 6: "AT the barrier", 7: "exchange + Metropolis + proposal chains",
          8: "accept (or not)", 9: "select", 10: "readlanes + row change"}
 ORDER = [1, 2, 3, 4, 11, 5, 6, 7, 8, 9, 10]
-for label, N, nrep, lat, g in (("config 2", 1024, 1024, (8, 4), (16, 2)), ("config 5", 16384, 256, (16, 16), (64, 8))):
+# (round 4: the 16 x 2 two-team kernel of config 2 is retired -- sweep_kernel_ml16 serves it; mt64x8 is the one two-team kernel left)
+for label, N, nrep, lat, g in (("config 5", 16384, 256, (16, 16), (64, 8)),):
     p = S.default_params(N, nrep, tune_slots=g[0], tune_waves=g[1])
     with S.Engine(p) as e:
         e.upload(S.fcc_init(*lat), S.W_REFERENCE)
