@@ -507,7 +507,10 @@ if TT:
     # (measured, config 2 / config 5 ms per sweep: none 1.562 / 27.11; all 1.403 / 25.91; team B until its reduction is
     # done 1.451 / 25.65; until its probe is done 1.467 / 25.67)
     # team B always + team A from its probe to the end of its reduction ("allA"): 1.43 / 25.40
-    TTP = os.environ.get("SMCX_GEN_TT_PRIO", "all" if NS == 16 else "allA")     # all | allA | probe | red | 0
+    TTP = os.environ.get("SMCX_GEN_TT_PRIO", "all" if NS == 16 else "allA")     # all | allA | allA2 | allA1 | probe | red | 0
+    TTPA = {"allA": 3, "allA2": 2, "allA1": 1}.get(TTP)       # team A's level from its probe to the end of its reduction
+    if TTPA:
+        TTP = "allA"
     if TTP in ("all", "allA"):
         E(f"""
         s_cmp_ge_u32 {WAVE}, {KS}
@@ -3005,7 +3008,7 @@ if TT:
     """)
     mark(2)
     if TTP == "allA":
-        E("s_setprio 3")
+        E(f"s_setprio {TTPA}")
     probe("A", QP, True, (s('Q', 4), s('Q', 5)), V['wa0'], V['wa1'], XA_, CA_, sp('haveA'), False,
           "s_waitcnt lgkmcnt(0)" if LP else "s_waitcnt vmcnt(0)")
     mark(4)
