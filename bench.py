@@ -9,8 +9,11 @@ GPU (N=4096 + wall, 4096 replicas, fcc(8,16) start, T=A=1.1, M=3, W fixture, see
 independent (the reference's intended MPI fan-out), so ranks share nothing while
 sampling; the only collective is the final RCCL all-gather of the observables.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--replicas R] [--no-cpu]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--replicas R] [--no-cpu] [--equilibrate E]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+The JSON line carries numbers and kernel names only (round 5: < 6 KB, so that every entry survives in the driver's tail); what
+each key means, how it is measured and the caveats that used to ride along as note strings are in DESIGN.md section 8.
 """
 import argparse
 import json
@@ -22,6 +25,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+# bytes of HBM traffic per byte of FETCH_SIZE for THIS path's reads (24-byte gathers of candidate positions, scalar loads, row
+# fills): calibrated by tools/ubench/gather24.hip on a known record count (profiles/r05_fetch_size_24B_gather.txt).  WRITE_SIZE is
+# exact (guide).  bytes = HBM_FETCH_FACTOR * FETCH_SIZE + WRITE_SIZE.
+HBM_FETCH_FACTOR = 1.0
 BYTES_PER_PAIR_EVAL = 24  # one neighbour position = 3 fp64 per pair-eval
 N_SIMD = 256 * 4          # MI355X_MICROARCH.md: 256 CUs x 4 SIMD-32
 # issue cost of one wave64 VALU instruction on a SIMD-32, MI355X_MICROARCH.md ("v_fma_f32 (wave64) 2 cyc",
@@ -87,99 +94,97 @@ def issue_roofline(kname, sweep_ms_per_sweep, nrep, N, clock_ghz, start=None):
              (m.get("SQ_INSTS_VMEM_RD") or 0) + (m.get("SQ_INSTS_VMEM_WR") or 0) + (m.get("SQ_INSTS_SMEM") or 0))
     all_lo = b32 * 1.8 + f64 * 3.4 + tr * 8.0 + other * 2.0
     all_hi = b32 * 3.2 + f64 * 3.4 + tr * 8.0 + other * 2.0
+    int32 = (m.get("SQ_INSTS_VALU_INT32") or 0) + (m.get("SQ_INSTS_VALU_INT64") or 0)
+    cvt = m.get("SQ_INSTS_VALU_CVT") or 0
     out = {"bound": "valu_issue", "achieved": achieved, "peak": peak, "unit": "G SIMD-cycles/s of VALU issue",
            "frac": achieved / peak,
+           # all executed instructions at the per-kind costs measured inside this kernel, 32-bit VALU all-fast .. all-slow
            "frac_all_instruction_kinds_at_measured_costs_range": [all_lo * wave_moves_per_s / 1e9 / peak,
                                                                   all_hi * wave_moves_per_s / 1e9 / peak],
-           "all_kinds_note": "SIMD cycles that ALL executed instructions (VALU, scalar, branch, LDS, memory) account for at the "
-                             "per-kind issue costs measured inside this kernel (profiles/r04_instruction_costs_in_kernel.txt), "
-                             "over the SIMD cycles that passed; 32-bit VALU all-fast .. all-slow.  Near 1: the issue port is the "
-                             "bound and `frac` (VALU only, guide costs) is the share of it that is vector work",
            "wave_instr_per_move_all_kinds": m["SQ_INSTS_VALU"] + other,
-           "frac_at_measured_costs_range": [need_lo * wave_moves_per_s / 1e9 / peak, need_hi * wave_moves_per_s / 1e9 / peak],
-           # SQ_ACTIVE_INST_VALU is NOT a busy time: it advances by exactly 1 per VALU instruction of any form
-           # (tools/ubench/active_valu.hip), so "ACTIVE_INST_VALU x 4 cycles / kernel time" (0.99 for sweep_kernel_mc64)
-           # restates the instruction count at a nominal 4-cycle cadence; DESIGN section 6
-           "issue_slots_all_kinds_per_simd_cycle": (m["SQ_INSTS_VALU"] + (m.get("SQ_INSTS_SALU") or 0) + (m.get("SQ_INSTS_LDS") or 0)
-                                                    + (m.get("SQ_INSTS_VMEM_RD") or 0) + (m.get("SQ_INSTS_VMEM_WR") or 0)
-                                                    + (m.get("SQ_INSTS_SMEM") or 0)) * wave_moves_per_s / 1e9 / peak,
-           "clock_ghz": clock_ghz, "clock_source": "s_memtime / s_memrealtime inside the timed sweep launch, median over wavefronts",
-           "waves_per_replica": wpr,
-           "valu_wave_instr_per_move": m["SQ_INSTS_VALU"], "of_which_fp64": f64, "fp64_transcendental": tr,
-           "salu_per_move": m.get("SQ_INSTS_SALU"), "lds_per_move": m.get("SQ_INSTS_LDS"),
-           "vmem_rd_per_move": m.get("SQ_INSTS_VMEM_RD"), "guide_issue_cycles_per_wave_move": need,
-           "simd_cycles_per_wave_move": peak * 1e9 / wave_moves_per_s,
-           "counters": "profiles/kernel_counters.json (rocprofv3 --pmc, %d-sweep launch)" % kc["workload"]["sweeps_in_launch"]}
+           "clock_ghz": clock_ghz, "waves_per_replica": wpr,
+           "valu_per_move": m["SQ_INSTS_VALU"], "fp64_per_move": f64, "fp64_trans_per_move": tr,
+           "int_per_move": int32 or None, "cvt_per_move": cvt or None,
+           "salu_per_move": m.get("SQ_INSTS_SALU"), "branch_per_move": m.get("SQ_INSTS_BRANCH"), "lds_per_move": m.get("SQ_INSTS_LDS"),
+           "vmem_per_move": (m.get("SQ_INSTS_VMEM_RD") or 0) + (m.get("SQ_INSTS_VMEM_WR") or 0),
+           "guide_issue_cycles_per_wave_move": need, "simd_cycles_per_wave_move": peak * 1e9 / wave_moves_per_s,
+           "wait_any_frac": kc.get("wait_any_frac"), "wait_inst_any_frac": kc.get("wait_inst_any_frac")}
     hb = kc.get("hbm_bytes_per_sweep")
     if hb:
         sec = sweep_ms_per_sweep * 1e-3
-        out["hbm"] = {"bytes_per_sweep_fetch_x2": hb["fetch_x2_plus_write"], "bytes_per_sweep_fetch_x1": hb["fetch_x1_plus_write"],
-                      "gbs_fetch_x2": hb["fetch_x2_plus_write"] / sec / 1e9, "gbs_fetch_x1": hb["fetch_x1_plus_write"] / sec / 1e9,
-                      "frac_of_peak_fetch_x2": hb["fetch_x2_plus_write"] / sec / 1e9 / HBM_PEAK_GBS,
-                      "frac_of_peak_fetch_x1": hb["fetch_x1_plus_write"] / sec / 1e9 / HBM_PEAK_GBS,
-                      "compulsory_bytes_per_sweep": nrep * (48.0 * N + 32.0 * N + 8),
-                      "note": "PMC FETCH_SIZE/WRITE_SIZE of the profiled launch over this run's time per sweep; x2 = the guide's "
-                              "gfx950 correction for wide reads, x1 = raw (these are 24-byte gathers: uncalibrated); compulsory = "
-                              "read+write every position once, one sweep of random numbers"}
+        # ONE calibrated reading (round 5, tools/ubench/gather24.hip, profiles/r05_fetch_size_24B_gather.txt): see HBM_FETCH_FACTOR
+        fetch = hb["fetch_x2_plus_write"] - hb["fetch_x1_plus_write"]          # FETCH_SIZE and WRITE_SIZE in bytes per sweep
+        write = hb["fetch_x1_plus_write"] - fetch
+        byt = HBM_FETCH_FACTOR * fetch + write
+        out["hbm"] = {"bytes_per_sweep": byt, "gbs": byt / sec / 1e9, "frac_of_peak": byt / sec / 1e9 / HBM_PEAK_GBS,
+                      "compulsory_bytes_per_sweep": nrep * (48.0 * N + 32.0 * N + 8)}
     return out
 
 
 _EXEC_WORKER = r"""
 import sys, os, ctypes as C, importlib.util, json
+import numpy as np
 root = sys.argv[1]
 os.environ["SMCX_LIB"] = os.path.join(root, "montecarlo-surfacer_amd", "libsmcx_check.so")
 spec = importlib.util.spec_from_file_location("smcx_chk", os.path.join(root, "montecarlo-surfacer_amd", "__init__.py"))
 K = importlib.util.module_from_spec(spec); spec.loader.exec_module(K)
 N, Na, Nz, nrep, nsw, slots, waves, dev = (int(v) for v in sys.argv[2:10])
+state = sys.argv[10] if len(sys.argv) > 10 else ""     # positions [nrep][3N] of a run in progress instead of the lattice
 p = K.default_params(N, nrep, tune_slots=slots, tune_waves=waves, device=dev)
 with K.Engine(p) as eng:
     name = eng.kernel_form[1]
-    eng.upload(K.fcc_init(Na, Nz), K.W_REFERENCE)
+    eng.upload(np.load(state) if state else K.fcc_init(Na, Nz), K.W_REFERENCE)
     eng.run(0, nsw, 10)
     cnt = (C.c_uint64 * 8)()
     f = K._lib().smcx_debug_work_counts
     f.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
     assert f(eng._h, cnt) == 0
 print(json.dumps({"name": name, "inside": int(cnt[0]), "cand": int(cnt[1]), "miss": int(cnt[2]), "groups": int(cnt[3]),
-                  "passes": int(cnt[4]), "more_rounds": int(cnt[5]), "fold": int(cnt[6])}))
+                  "passes": int(cnt[4]), "more_rounds": int(cnt[5]), "fold": int(cnt[6]), "unworked": int(cnt[7])}))
 """
 
 
-def executed_work(kname, N, lattice, slots, waves, device, nrep=64, sweeps=2):
+def executed_work(kname, N, lattice, slots, waves, device, nrep=64, sweeps=2, state=None):
     """What the z-ordered kernels EXECUTE per probe, counted by the diagnostic build of the same sources
     (libsmcx_check.so, SMCX_CHECK_MB=2: counters beside every screen pass, plus the fp64 test of every cell) on a
-    sample of the same start, in a child process after the timed region: 4-slot groups screened per pass, hence
-    cells tested per move, candidate bits per probe, pairs truly inside the cutoff, pairs the screen missed (0)."""
+    sample of the same start -- or of `state`, positions [nrep][3N] taken from a run in progress -- in a child process
+    after the timed region: 4-slot groups screened per pass, hence cells tested per move, candidate bits per probe (the
+    cells that are no neighbours by construction included: the kernels drop them by a compare of the hand-over item), pairs
+    truly inside the cutoff, pairs the screen missed (0), rounds of the fp64 body beyond the first per probe."""
     import subprocess
+    import tempfile
     if not os.path.exists(os.path.join(ROOT, "montecarlo-surfacer_amd", "libsmcx_check.so")):
         return {"note": "libsmcx_check.so not built"}
     env = {k: v for k, v in os.environ.items() if not (k.startswith("SMCX_") and k not in ("SMCX_FORCE_DEVICE",))}
     env["SMCX_CHECK_MB"] = "2"
-    r = subprocess.run([sys.executable, "-c", _EXEC_WORKER, ROOT, str(N), str(lattice[0]), str(lattice[1]), str(nrep),
-                        str(sweeps), str(slots), str(waves), str(device)], env=env, capture_output=True, text=True, timeout=600)
+    args = [sys.executable, "-c", _EXEC_WORKER, ROOT, str(N), str(lattice[0]), str(lattice[1]), str(nrep), str(sweeps), str(slots),
+            str(waves), str(device)]
+    tmp = None
+    if state is not None:
+        import numpy as np
+        tmp = tempfile.NamedTemporaryFile(suffix=".npy", delete=False)
+        np.save(tmp, state[:nrep])
+        tmp.close()
+        args.append(tmp.name)
+    try:
+        r = subprocess.run(args, env=env, capture_output=True, text=True, timeout=600)
+    finally:
+        if tmp is not None:
+            os.unlink(tmp.name)
     if r.returncode != 0:
         return {"note": "diagnostic run failed: " + r.stderr[-300:]}
     d = json.loads(r.stdout.strip().splitlines()[-1])
     if d["name"] != kname:
         return {"note": "diagnostic build ran %s, not %s" % (d["name"], kname)}
     moves = float(nrep) * sweeps * N
-    groups_total = slots // 4
-    gpp = d["groups"] / max(d["passes"], 1)
-    return {"groups_screened_per_pass": gpp, "groups_per_wavefront": groups_total, "wavefronts_per_replica": waves,
-            "passes_per_move": d["passes"] / moves,
+    return {"groups_screened_per_pass": d["groups"] / max(d["passes"], 1), "groups_per_wavefront": slots // 4,
+            "wavefronts_per_replica": waves, "passes_per_move": d["passes"] / moves,
             "cells_screened_per_move": d["groups"] * 256.0 / moves, "cells_per_move_all_pairs": 2.0 * (N - 1),
             "fraction_of_all_pairs_screened": d["groups"] * 256.0 / moves / (2.0 * (N - 1)),
             "candidate_bits_per_probe": d["cand"] / (2.0 * moves), "pairs_inside_cutoff_per_probe": d["inside"] / (2.0 * moves),
-            "pairs_inside_cutoff_missed": d["miss"],
-            "candidate_bits_note": "the bits of the cells that are no neighbours by construction (the moving particle, the probe's own "
-                                   "particle) are counted: the kernels drop those cells by a compare of the hand-over item, not by clearing "
-                                   "the bit (about 1.3 of the bits per probe at the benchmark start)",
-            # rounds of the fp64 body beyond the first, per probe (a lane held two candidates of one probe)
+            "pairs_inside_cutoff_missed": d["miss"], "handed_over_without_working_lane": d.get("unworked", 0),
             "further_rounds_per_probe": d.get("more_rounds", 0) / (2.0 * moves),
-            # design statistic: probes in which some lanes l and l + 32 both held a candidate (per probe evaluated)
-            "probes_with_candidates_32_lanes_apart": d.get("fold", 0) / (2.0 * moves),
-            "source": "libsmcx_check.so (diagnostic build of the same sources, SMCX_CHECK_MB=2), %d replicas x %d sweeps "
-                      "of the same start, after the timed region" % (nrep, sweeps)}
+            "sample": "%d replicas x %d sweeps" % (nrep, sweeps)}
 
 
 def cpu_model():
@@ -226,9 +231,8 @@ def cpu_baseline_reference(N, Na, Nz, seconds_target=12.0):
     pe = cores * sweeps * 2.0 * N * (N - 1.0)
     return {"value": pe / wall, "unit": "pair-evals/s", "cores": cores, "kind": "reference", "cpu_model": cpu_model(),
             "per_core": pe / wall / cores,
-            "sample": "%d independent chains (one process per core) x %d sweeps of N=%d, fcc(%d,%d) start, the reference's "
-                      "own oneParticleMoves (SMC.c:278-351 compiled where it lies, gcc -O3 -march=x86-64-v3), slowest chain "
-                      "%.1f s" % (cores, sweeps, N, Na, Nz, wall)}
+            "sample": "%d chains (one process per core) x %d sweeps of N=%d, fcc(%d,%d), the reference's own oneParticleMoves "
+                      "(gcc -O3), slowest chain %.1f s" % (cores, sweeps, N, Na, Nz, wall)}
 
 
 def cpu_baseline(N, Na, Nz, seconds_target=12.0):
@@ -276,35 +280,52 @@ def cpu_baseline(N, Na, Nz, seconds_target=12.0):
     pe = cores * sweeps * 2.0 * N * (N - 1.0)
     return {"value": pe / wall, "unit": "pair-evals/s", "cores": cores, "kind": "port", "cpu_model": cpu_model(),
             "per_core": pe / wall / cores,
-            "sample": "%d independent chains (one per core) x %d sweeps of N=%d, fcc(%d,%d) start, "
-                      "oracle/smc_oracle.c built %s, %.1f s wall" % (cores, sweeps, N, Na, Nz, flags, wall)}
+            "sample": "%d chains (one per core) x %d sweeps of N=%d, fcc(%d,%d), oracle/smc_oracle.c built %s, %.1f s wall"
+                      % (cores, sweeps, N, Na, Nz, flags, wall)}
 
 
-def side_config(S, label, N, nrep, lattice, sweeps, device, kernel=0, executed=True):
-    """one of the other BASELINE configurations (or the headline workload through another kernel), run briefly
-    AFTER the timed region (not the headline)"""
+def z_profile_width(ob, p):
+    """standard deviation of z over the gathers of the last run (the wall-normal profile's width: identifies the state)"""
+    import numpy as np
+    zh = ob["zhist"].sum(axis=0).astype(float)
+    if zh.sum() == 0:
+        return None
+    zc = (np.arange(p.Ncz) + 0.5) / p.Ncz * p.Lz - p.Lz / 2
+    zm = (zh * zc).sum() / zh.sum()
+    return float(np.sqrt((zh * (zc - zm) ** 2).sum() / zh.sum()))
+
+
+def side_config(S, label, N, nrep, lattice, sweeps, device, kernel=0, executed=True, equilibrate=0):
+    """one of the other BASELINE configurations (or the headline workload through another kernel, or after `equilibrate`
+    sweeps of the chain: the state a production run sits in), run briefly AFTER the timed region (not the headline)"""
     p = S.default_params(N, nrep, device=device, tune_kernel=kernel)
+    state = None
     with S.Engine(p) as e:
         e.upload(S.fcc_init(*lattice), S.W_REFERENCE)
-        e.run(0, 1, 10)
-        e.run(0, sweeps, 10)
+        e.run(0, max(1, equilibrate), 10)
+        e.run(0, sweeps, min(10, sweeps))              # (a gather inside the measured run: the z profile of THIS state)
         ms, launches = e.last_kernel_ms()
         run_ms = e.last_run_ms()
+        ob = e.observables()
         try:
             ghz, _ = e.last_clock()
         except Exception:
             ghz = None
         s_, w_, _ = e.geometry
         kname = e.kernel_form[1]
+        zipped = "kernel_mc" in kname or "kernel_mt" in kname or "kernel_ml" in kname
+        if equilibrate and executed and zipped:
+            state = e.positions()[:64 if N <= 4096 else 8].copy()
     pe = nrep * sweeps * 2.0 * N * (N - 1.0)
-    out = {"workload": label, "N": N, "replicas": nrep, "sweeps": sweeps, "value": pe / (run_ms * 1e-3),
-           "unit": "reference-equivalent pair-evals/s (device time of the whole run)", "ms_per_sweep": ms / sweeps,
-           "kernel": kname, "geometry": "S=%d x %d wavefront(s)" % (s_, w_), "clock_ghz": ghz}
-    rl = issue_roofline(kname, ms / sweeps, nrep, N, ghz, start="fcc(%d,%d)" % tuple(lattice))
-    out["roofline"] = rl if rl else {"bound": "valu_issue", "frac": None, "clock_ghz": ghz,
-                                     "note": "no PMC counters committed for this kernel and workload"}
-    if executed and ("kernel_mc" in kname or "kernel_mt" in kname or "kernel_ml" in kname):
-        out["executed"] = executed_work(kname, N, lattice, s_, w_, device, nrep=min(nrep, 64 if N <= 4096 else 8))
+    start = "fcc(%d,%d)" % tuple(lattice) + ("+%d sweeps" % equilibrate if equilibrate else "")
+    out = {"workload": label, "N": N, "replicas": nrep, "start": start, "sweeps": sweeps, "value": pe / (run_ms * 1e-3),
+           "ms_per_sweep": ms / sweeps, "device_ms_per_sweep": run_ms / sweeps, "kernel": kname,
+           "geometry": "S=%d x %d" % (s_, w_), "acceptance": float(ob["acceptance_ratio"].mean()),
+           "mean_E_last": float(ob["E_last"].mean()), "z_std": z_profile_width(ob, p)}
+    rl = issue_roofline(kname, ms / sweeps, nrep, N, ghz, start=start)
+    out["roofline"] = rl if rl else {"bound": "valu_issue", "frac": None, "clock_ghz": ghz}
+    if executed and zipped:
+        out["executed"] = executed_work(kname, N, lattice, s_, w_, device, nrep=min(nrep, 64 if N <= 4096 else 8), state=state)
     return out
 
 
@@ -321,6 +342,9 @@ def main():
     ap.add_argument("--kernel", type=int, default=0, help="measurement switch: smcx_params.tune_kernel (SMCX_KERNEL_*)")
     ap.add_argument("--lattice", default="", help="measurement switch: fcc start Na,Nz other than the configuration's (e.g. 16,4: the "
                                                   "dense film of other_configs, for its PMC passes)")
+    ap.add_argument("--equilibrate", type=int, default=0,
+                    help="measurement switch: this many sweeps of the chain BEFORE the warm-up (the PMC passes of the state a "
+                         "production run sits in; the bench line's other_configs carry it without the switch)")
     ap.add_argument("--no-cpu", action="store_true",
                     help="skip the reference legs after the timed region (cpu_baseline, all-fp64 kernels): profiling runs")
     a = ap.parse_args()
@@ -372,6 +396,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if a.equilibrate > 0:
+        eng.run(0, a.equilibrate, gather_lapse)
     warm_ms, warm_launches = 0.0, 0
     if a.warmup > 0:
         eng.run(0, a.warmup, gather_lapse)
@@ -419,64 +445,51 @@ def main():
         algo_bytes_per_launch = pe_per_gpu_launchset * BYTES_PER_PAIR_EVAL / max(launches, 1)
         launch_s = sweep_ms * 1e-3 / max(launches, 1)
         achieved = algo_bytes_per_launch / launch_s / 1e9
-        traffic = None   # HBM bytes per launch from the committed PMC run of this kernel (set below)
+        start = "fcc(%d,%d)" % tuple(lattice) + ("+%d sweeps" % a.equilibrate if a.equilibrate else "")
         out = {
-            "metric": "reference-equivalent pair-evals/s (MC sweeps/s x replicas x 2N(N-1), the pair tests the reference's "
-                      "loops run per sweep, SMC.c:563-578; the z-ordered kernel bounds most of them in bulk: see `executed` "
-                      "and `all_pairs_kernel`) at N=%d" % N,
+            "metric": "reference-equivalent pair-evals/s (MC sweeps/s x replicas x 2N(N-1)) at N=%d" % N,
             "value": value, "unit": "pair-evals/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": dt * 1e3 / a.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "BASELINE config 3 per GPU: N=%d LJ + wall (M=3), %d replica chains "
-                                   "per GPU, fcc(%d,%d) start, L=33 Lz=240 T=A=1.1, seeds 12345+replica"
-                                   % (N, nrep, lattice[0], lattice[1]),
-                       "N": N, "replicas_per_gpu": nrep, "replicas_total": nrep * world,
-                       "gather_lapse": gather_lapse,
-                       "replicas_resident_at_once": granule, "replica_count_advice": granule_note,
+            "config": {"workload": "BASELINE config 3 per GPU: N=%d LJ + wall (M=3), %d replica chains per GPU, %s start, "
+                                   "L=33 Lz=240 T=A=1.1, seeds 12345+replica" % (N, nrep, start),
+                       "N": N, "replicas_per_gpu": nrep, "replicas_total": nrep * world, "gather_lapse": gather_lapse,
+                       "replicas_resident_at_once": granule,
                        "geometry": "S=%d particles/lane, %d wavefront(s)/replica" % (S_, W_),
-                       "parallelism": "replica-sharded x%d, no data-path collective; %s all-gather of "
-                                      "observables at the end (%.2f ms)" % (world, "RCCL" if backend == "nccl" else backend, gather_ms)},
+                       "parallelism": "replica-sharded x%d, no data-path collective; %s all-gather of observables at the end"
+                                      % (world, "RCCL" if backend == "nccl" else backend)},
             "roofline": None,
-            "roofline_hbm_model": {"bound": "hbm (streaming model: NOT the binding bound)", "achieved": achieved,
-                                   "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                                   "algorithmic_bytes_per_launch": algo_bytes_per_launch,
-                                   "note": "SURVEY 8d: 24 B x pair-evals; positions are register/LDS-resident, so this "
-                                           "exceeds the HBM peak and bounds nothing; measured HBM traffic is in roofline.traffic"},
-            # whole_run - sweep_kernels = the helpers between the sweep launches: rand() pre-pass with Box-Muller,
-            # the z sort of the cells before every launch of sweep_kernel_mb64 / mc64, bookkeeping
+            # SURVEY 8d's streaming model (24 B per pair-eval): NOT the binding bound -- positions are register-resident
+            "roofline_hbm_model": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                   "frac": achieved / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": algo_bytes_per_launch},
             "device_ms": {"sweep_kernels": sweep_ms, "whole_run": run_ms, "helpers": run_ms - sweep_ms},
             "observables": {"mean_acceptance": summ["mean_acceptance"], "mean_energy": summ["mean_of_meanE"],
                             "replicas_gathered": int(len(obs["accepted"]))},
         }
+        if granule_note:
+            out["config"]["replica_count_advice"] = granule_note
         if per_rank is not None:
             def stats(col):
                 v = per_rank[:, col]
                 return {"min": float(v.min()), "median": float(np.median(v)), "max": float(v.max()),
                         "ranks": [float(x) for x in v]}
             out["per_rank"] = {"ms_per_step": stats(0), "sweep_kernel_ms_per_step": stats(1), "device_ms_per_step": stats(2),
-                               "gather_ms": stats(3),
-                               "note": "ms_per_step = each rank's own wall time over the K steps between the two barriers (the "
-                                       "headline uses the MAX); gather_ms = its side of the one all-gather of observables"}
+                               "gather_ms": stats(3)}
         out["gather_ms"] = gather_ms
-        rl = issue_roofline(kname, sweep_ms / a.steps, nrep, N, clock_ghz, start="fcc(%d,%d)" % tuple(lattice))
+        rl = issue_roofline(kname, sweep_ms / a.steps, nrep, N, clock_ghz, start=start)
         base = {"kernel": kname, "launches": launches, "avg_launch_ms": sweep_ms / max(launches, 1),
                 # what `rocprofv3 --stats` averages over: the warm-up launches as well
                 "launches_incl_warmup": launches + warm_launches,
                 "avg_launch_ms_incl_warmup": (sweep_ms + warm_ms) / max(launches + warm_launches, 1),
-                "ms_per_sweep": sweep_ms / a.steps, "traffic": traffic}
+                "ms_per_sweep": sweep_ms / a.steps, "traffic": None}
         if rl is None:   # no committed counters for this kernel / workload: the clock and the time are still live
             rl = {"bound": "valu_issue", "achieved": None, "peak": N_SIMD * clock_ghz if clock_ghz else None,
                   "unit": "G SIMD-cycles/s of VALU issue", "frac": None, "clock_ghz": clock_ghz,
                   "note": "no PMC instruction counts committed for this kernel and workload (profiles/kernel_counters.json)"}
         elif rl.get("hbm"):
-            base["traffic"] = rl["hbm"]["bytes_per_sweep_fetch_x2"] * (a.steps / max(launches, 1))
+            base["traffic"] = rl["hbm"]["bytes_per_sweep"] * (a.steps / max(launches, 1))
         rl.update(base)
         out["roofline"] = rl
-        out["precision"] = ("every energy, force, acceptance test and position is fp64; the compact integer copies "
-                            "(sweep_kernel_mc64: int8 x, y and int16 z in units of L/256, one word per particle) only "
-                            "pre-select pairs with a conservative, proven threshold (DESIGN 4.1e; tests: CPU emulation "
-                            "of the screen and the fp64 all-cells diagnostic build); every pair inside the cutoff is "
-                            "evaluated in fp64")
         if world == 1 and kform == 2 and not a.no_cpu:
             # for reference, outside the timed region: the same workload through the all-fp64 sweep kernels
             try:
@@ -489,11 +502,11 @@ def main():
                     e64.run(0, nk, gather_lapse)
                     ms64, l64 = e64.last_kernel_ms()
                     out["fp64_only_kernels"] = {"kernel": e64.kernel_form[1], "sweeps": nk, "ms_per_sweep": ms64 / nk,
-                                                "value": nrep * nk * 2.0 * N * (N - 1.0) / (ms64 * 1e-3),
-                                                "unit": "pair-evals/s (sweep kernels only)"}
+                                                "value": nrep * nk * 2.0 * N * (N - 1.0) / (ms64 * 1e-3)}
             except Exception as e:
                 out["fp64_only_kernels"] = {"value": None, "note": "failed: %r" % (e,)}
-        if world == 1 and not a.no_cpu and ("kernel_mc" in kname or "kernel_mt" in kname or "kernel_ml" in kname):
+        zipped = "kernel_mc" in kname or "kernel_mt" in kname or "kernel_ml" in kname
+        if world == 1 and not a.no_cpu and zipped:
             # what the timed kernel executed per probe (diagnostic build, sample of the same start)
             eng.close()
             out["executed"] = executed_work(kname, N, lattice, S_, W_, local_rank, nrep=64 if N <= 4096 else 8)
@@ -502,20 +515,22 @@ def main():
             # every probe as the reference's loops do (SMC.c:563-578, 597-612)
             try:
                 eng.close()
-                out["all_pairs_kernel"] = side_config(S, "the timed workload through the last kernel that tests every pair "
-                                                         "(tune_kernel = SMCX_KERNEL_MA)", N, nrep, lattice, 5, local_rank,
-                                                      kernel=S.KERNEL_MA, executed=False)
+                apk = side_config(S, "the timed workload through the last kernel that tests every pair", N, nrep, lattice, 5,
+                                  local_rank, kernel=S.KERNEL_MA, executed=False)
+                out["all_pairs_kernel"] = {k: apk[k] for k in ("kernel", "value", "ms_per_sweep", "sweeps")}
             except Exception as e:
                 out["all_pairs_kernel"] = {"value": None, "note": "failed: %r" % (e,)}
-            # the other single-GPU BASELINE configurations and one adverse state, briefly, after the timed region
+            # the other single-GPU BASELINE configurations, one adverse state, and the states a PRODUCTION run sits in (the
+            # reference thermalises for ~4e6 sweeps, main.c:15-18, SMC.c:110-126): briefly, after the timed region
             out["other_configs"] = []
-            for label, n_, r_, lat_, sw_ in (("BASELINE config 2: N=1024 + wall, 1024 replicas, fcc(8,4)", 1024, 1024, (8, 4), 40),
-                                             ("BASELINE config 5 per GPU: N=16384 + wall, 256 of 2048 replicas, fcc(16,16)", 16384, 256, (16, 16), 4),
-                                             ("adverse state for the z-ordered screen: N=4096 + wall, 4096 replicas, dense film "
-                                              "fcc(16,4) 8.25 high (most groups in reach of every probe, ~46 pairs inside the "
-                                              "cutoff per probe, acceptance 0.007)", 4096, 4096, (16, 4), 5)):
+            for label, n_, r_, lat_, sw_, eq_ in (
+                    ("config 3 equilibrated: the timed workload after 2000 sweeps", 4096, 4096, (8, 16), 20, 2000),
+                    ("config 2: N=1024 + wall, 1024 replicas", 1024, 1024, (8, 4), 40, 0),
+                    ("config 5 per GPU: N=16384 + wall, 256 of 2048 replicas", 16384, 256, (16, 16), 4, 0),
+                    ("config 5 per GPU after 200 sweeps", 16384, 256, (16, 16), 4, 200),
+                    ("adverse for the z-ordered screen: N=4096, 4096 replicas, dense film", 4096, 4096, (16, 4), 5, 0)):
                 try:
-                    out["other_configs"].append(side_config(S, label, n_, r_, lat_, sw_, local_rank))
+                    out["other_configs"].append(side_config(S, label, n_, r_, lat_, sw_, local_rank, equilibrate=eq_))
                 except Exception as e:
                     out["other_configs"].append({"workload": label, "value": None, "note": "failed: %r" % (e,)})
         if world == 1 and not a.no_cpu:
@@ -525,7 +540,7 @@ def main():
                 ref = cpu_baseline_reference(N, *lattice)
                 port = cpu_baseline(N, *lattice, seconds_target=6.0 if ref else 12.0)
                 if ref:
-                    ref["oracle_port"] = {k: port[k] for k in ("value", "per_core", "sample")}
+                    ref["oracle_port"] = {k: port[k] for k in ("value", "per_core")}
                 out["cpu_baseline"] = ref or port
             except Exception as e:  # the baseline leg must never take the GPU number down
                 out["cpu_baseline"] = {"value": None, "unit": "pair-evals/s", "cores": 0, "kind": "port",

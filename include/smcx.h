@@ -71,7 +71,8 @@ extern "C" {
 #define SMCX_KERNEL_MB 6       /* sweep_kernel_mb64: cells in z order, only groups in reach are screened */
 #define SMCX_KERNEL_MC 7       /* sweep_kernel_mc16/32/64, mc32x4, mc64x4, mc32x8: one word per cell (default where built) */
 #define SMCX_KERNEL_MT 8       /* sweep_kernel_mt64x8: the same with TWO TEAMS of wavefronts per replica, probe A and probe B
-                                  evaluated side by side (8192 < N <= 16384; the plan's choice up to 256 replicas per GPU) */
+                                  evaluated side by side; built for 8192 < N <= 16384 ONLY (the plan's choice there up to 256
+                                  replicas per GPU): asked for at any other N, smcx_create answers SMCX_ERR_UNSUPPORTED */
 
 typedef struct smcx_params {
     int32_t N;       /* particles per replica            (SMC.h:29)  even, >= 2 */

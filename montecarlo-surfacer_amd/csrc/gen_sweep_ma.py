@@ -62,6 +62,13 @@ import os
 import re
 import sys
 
+# The experiment switches below change the generated kernel (SMCX_GEN_FAKEFETCH even its results).  They belong to VARIANT builds
+# (csrc/Makefile passes SMCX_GEN_ALLOW=1 there); the product and the diagnostic build refuse a stale one in the environment.
+_stale = sorted(k for k in os.environ if k.startswith("SMCX_GEN_") and k != "SMCX_GEN_ALLOW")
+if _stale and os.environ.get("SMCX_GEN_ALLOW") != "1":
+    sys.exit("gen_sweep_ma.py: generator switches %s are set but this is not a VARIANT build (make VARIANT=name GENENV=...); "
+             "unset them" % ", ".join(_stale))
+
 out = []
 
 
@@ -168,6 +175,7 @@ MG = Z8 and not TT and os.environ.get("SMCX_GEN_NOMERGE") != "1"      # (switch 
 # merged pass (all 64 lanes work for the ONE probe of the wave; wall lanes and side lanes on fixed lanes in front), so a lane
 # with two candidates costs a second hand-over instead of a second pass of the fp64 body (round 3's PF2)
 TL = TT and os.environ.get("SMCX_GEN_TTLIST", "1") != "0"
+TTCAP = int(os.environ.get("SMCX_GEN_TTCAP", "63"))       # working lanes of a two-team wave's list (64 = round 4's value: drops items, see tt_assign)
 # "XC" (merged pass, steady copy of the move): the cells that are no neighbours of a probe -- the moving particle n
 # for both, particle n+1 itself for probe B -- keep their candidate bits and travel through the hand-over list like any other; the
 # working lane that reads one of them as its item is taken out of the pass by a compare of the item with the cell (4 instructions
@@ -2131,11 +2139,26 @@ def tt_assign(tag, w0, w1, X, C, wl, pl, with_side, have):
     {f"s_add_u32 {st(6)}, {st(6)}, {st(3)}" if with_side else ""}
     """)
     start = st(6) if with_side else st(3)
-    mg_handover(w0, w1, have, start, 0, st(5), cap=64)
-    mg_handover2(tag + "t", w0, w1, have, start, 0, st(5), cap=64, flag=False)
+    # at most TTCAP = 63 working lanes: s_bfm_b64 below takes its COUNT from 6 bits, so 64 items from lane 0 (a wave without
+    # special lanes whose two hand-overs fill the wavefront: a condensed state) would give the mask 0 and drop all of them --
+    # their bits are already out of the flag words.  Lane 63's would-be item stays in its owner's flag word: a further round.
+    mg_handover(w0, w1, have, start, 0, st(5), cap=TTCAP)
+    mg_handover2(tag + "t", w0, w1, have, start, 0, st(5), cap=TTCAP, flag=False)
     E(f"""
     ds_read_b32 v44, {KL4T} offset:{LDS_LIST}
     s_bfm_b64 {have}, {st(5)}, {start}
+    """)
+    if Z8C:   # diagnostic build: items handed over for which no working lane is enabled (must stay 0) -> counter word 7
+        cnt_addr("v47")
+        E(f"""
+        s_bcnt1_i32_b64 {st(7)}, {have}
+        s_sub_u32 {st(7)}, {st(5)}, {st(7)}
+        v_mov_b32 v46, {st(7)}
+        s_mov_b64 exec, 1
+        ds_add_u32 v47, v46 offset:{LDS_CNT + 28}
+        s_mov_b64 exec, -1
+        """)
+    E(f"""
     s_waitcnt lgkmcnt(0)
     v_mul_u32_u24 v45, 24, v44
     {"v_mov_b32 v45, 0" if FAKE else ""}
@@ -3652,6 +3675,7 @@ if Z8C:
     ds_read_b32 v35, v25 offset:{LDS_CNT + 16}
     ds_read_b32 v40, v25 offset:{LDS_CNT + 20}
     ds_read_b32 v42, v25 offset:{LDS_CNT + 24}
+    ds_read_b32 v44, v25 offset:{LDS_CNT + 28}
     s_load_dwordx2 {stp(2)}, {KARG}, {K_DBG}
     v_mov_b32 v30, 0
     v_mov_b32 v27, 0
@@ -3675,6 +3699,8 @@ if Z8C:
     v_mov_b32 v43, 0
     global_atomic_add_x2 v30, v[40:41], {stp(2)} offset:40
     global_atomic_add_x2 v30, v[42:43], {stp(2)} offset:48
+    v_mov_b32 v45, 0
+    global_atomic_add_x2 v30, v[44:45], {stp(2)} offset:56
     s_mov_b64 exec, -1
     s_waitcnt vmcnt(0)
     """)

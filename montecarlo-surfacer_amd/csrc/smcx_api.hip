@@ -259,7 +259,7 @@ static int choose_geometry(const smcx_params *p, const Tune &t, int *S, int *WPR
     if (p->tune_slots > 0 || p->tune_waves > 0) {
         int s = p->tune_slots > 0 ? p->tune_slots : 16;
         int w = p->tune_waves > 0 ? p->tune_waves : 1;
-        if (plan_for(p, s, w, t, &pl) && pl.form == FORM_MT) { *S = s; *WPR = w; return SMCX_OK; } // (16 x 2, 64 x 8)
+        if (plan_for(p, s, w, t, &pl) && pl.form == FORM_MT) { *S = s; *WPR = w; return SMCX_OK; } // (64 x 8: the one two-team form built)
         if (!geometry_supported(s, w) || (long)s * w * 64 < p->N) return SMCX_ERR_UNSUPPORTED;
         if (p->tune_kernel == 1 && !fp64_supported(s, w)) return SMCX_ERR_UNSUPPORTED;
         if (p->tune_kernel >= 2 && !mx_supported(s, w)) return SMCX_ERR_UNSUPPORTED;
@@ -275,10 +275,9 @@ static int choose_geometry(const smcx_params *p, const Tune &t, int *S, int *WPR
     // chip has about two waves per SIMD to work on.
     auto pow2_at_least = [](long v) { int r = 1; while (r < v) r *= 2; return r; };
     int s, w;
-    if (p->tune_kernel == SMCX_KERNEL_MT) { // asked for by name: the two-team geometry of this N, if there is one
-        for (auto &g : {std::pair<int, int>(16, 2), std::pair<int, int>(32, 16), std::pair<int, int>(64, 8)})
-            if (plan_for(p, g.first, g.second, t, &pl) && pl.form == FORM_MT) { *S = g.first; *WPR = g.second; return SMCX_OK; }
-        return SMCX_ERR_UNSUPPORTED;
+    if (p->tune_kernel == SMCX_KERNEL_MT) { // asked for by name: sweep_kernel_mt64x8 (8192 < N <= 16384), the one two-team form built
+        if (plan_for(p, 64, 8, t, &pl) && pl.form == FORM_MT) { *S = 64; *WPR = 8; return SMCX_OK; }
+        return SMCX_ERR_UNSUPPORTED;        // (smcx.h: any other N; round 3's 16 x 2 and 32 x 16 forms were retired in round 4)
     }
     const bool fp64_only = (p->tune_kernel == 1);
     if (!fp64_only && (p->N > 512 || p->tune_kernel >= 2)) {
@@ -304,8 +303,9 @@ static int choose_geometry(const smcx_params *p, const Tune &t, int *S, int *WPR
             if (p->N > 8192 && (long)p->nrep * 8 <= 2048 && plan_for(p, 64, 8, t, &pl) && pl.form == FORM_MT) { s = 64; w = 8; one_wave = true; }
             // (N <= 1024 with at most 1024 replicas ran the two-team form 16 x 2 in round 3; round 4's one-wavefront kernel
             // with both probes in one pass and the cells' positions in LDS, sweep_kernel_ml16, is faster: 1.27 against 1.31 ms
-            // per sweep at 1024 replicas, 1.26 against 1.36 at 512 -- profiles/r04_config2_forms.txt; 16 x 2 stays available
-            // through tune_kernel = SMCX_KERNEL_MT or tune_slots / tune_waves)
+            // per sweep at 1024 replicas, 1.26 against 1.36 at 512 -- profiles/r04_config2_forms.txt; the 16 x 2 kernel was
+            // retired with it: tune_kernel = SMCX_KERNEL_MT at N <= 8192 answers SMCX_ERR_UNSUPPORTED, and tune_slots = 16 with
+            // tune_waves = 2 selects the compiled several-wavefront kernel sweep_kernel_mx<16, 2>)
         }
         while (!one_wave && (long)p->nrep * w < 2048 && s > 16 && w < 8 && geometry_supported(s / 2, w * 2)) { s /= 2; w *= 2; }
     } else {
@@ -947,7 +947,9 @@ extern "C" int smcx_debug_check_counts(smcx_handle *hh, uint64_t *out /*[3]*/)
     return SMCX_OK;
 }
 // the same plus the executed work of the z-ordered byte-screen kernels (SMCX_CHECK_MB=2): out[3] = 4-slot groups
-// screened (256 cells per wavefront each), out[4] = screen passes (one per probe and wavefront)
+// screened (256 cells per wavefront each), out[4] = screen passes (one per probe and wavefront), out[5] = rounds of the fp64
+// body beyond the first, out[6] = probes with candidates on lanes l and l + 32, out[7] = (two-team kernel) candidates handed over
+// to the list for which NO working lane was enabled -- must stay 0 (round 5: the s_bfm_b64 count of 64 wrapped to an empty mask)
 extern "C" int smcx_debug_work_counts(smcx_handle *hh, uint64_t *out /*[8]*/)
 {
     if (!hh || !out) return SMCX_ERR_PARAM;

@@ -578,7 +578,7 @@ hipError_t launch_sweeps_ma(const SweepArgs &s, const DevCtx &c, const KernelPla
         const long T = ((long)(-negC) + 255) >> 8;
         a.RZ = (int)std::floor(std::sqrt((double)T)) + 1;
         a.Rs = c.Rs; a.loc = c.loc;
-        // the cells are re-sorted by z every `every` sweeps (smcx_params.tune_resort, default 1): the groups' z ranges
+        // the cells are re-sorted by z every `every` sweeps (smcx_params.tune_resort, default 2 since round 4): the groups' z ranges
         // only widen inside a launch
         const bool mc = pl.form == FORM_MC;
         if (mc) {

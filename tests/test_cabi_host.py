@@ -38,7 +38,13 @@ def test_roofline_refuses_instruction_counts_of_another_build(S, tmp_path, monke
     kn = "smcx::sweep_kernel_mc64"
     sid = S.kernel_source_id(kn)
     assert sid and re.fullmatch(r"[0-9a-f]{16}", sid)
-    assert S.kernel_source_id("smcx::sweep_kernel_mt16x2") not in (None, sid)
+    assert S.kernel_source_id("smcx::sweep_kernel_mt64x8") not in (None, sid)
+    # names this library does not build -- retired kernels, typos, a bare prefix -- have NO id (smcx.h: SMCX_ERR_PARAM)
+    for unknown in ("smcx::sweep_kernel_mt16x2", "smcx::sweep_kernel_mt32x16", "smcx::sweep_kernel_mc128", "smcx::sweep_kernel",
+                    "smcx::sweep_kernel_mi", "smcx::sweep_kernel_mc64 "):
+        assert S.kernel_source_id(unknown) is None, unknown
+    assert S.kernel_source_id("smcx::sweep_kernel<8, 2, 4, 2>") == S.kernel_source_id("smcx::sweep_kernel_lead<16, 4, 3, 2>")
+    assert S.kernel_source_id("smcx::sweep_kernel_mx<64, 1, 4, true>")
     assert S.kernel_source_id("smcx::sweep_kernel_mi<64, 4, 4>") and S.kernel_source_id("smcx::sweep_kernel_lead<16, 4, 3, 2>")
     assert S.kernel_source_id("smcx::no_such_kernel") is None
     bench = importlib.import_module("bench")
@@ -52,7 +58,7 @@ def test_roofline_refuses_instruction_counts_of_another_build(S, tmp_path, monke
         json.dump({kn: entry}, open(tmp_path / "profiles" / "kernel_counters.json", "w"))
         r = bench.issue_roofline(kn, 10.0, 4096, 4096, 2.35, start="fcc(8,16)")
         if ok:
-            assert 0.1 < r["frac"] < 1.0 and r["valu_wave_instr_per_move"] == 300.0
+            assert 0.1 < r["frac"] < 1.0 and r["valu_per_move"] == 300.0
         else:
             assert r["frac"] is None and "another build" in r["note"]
 

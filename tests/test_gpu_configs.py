@@ -3,8 +3,9 @@ kernel's no-miss property on the device, of ensemble statistics beyond the chaos
 the multi-rank launch path of bench.py.  Everything goes through the C ABI (libsmcx.so); the CPU
 oracle is the checker only.
 
-Tolerances: as in test_gpu_parity.py (fp64 everywhere; 1e-9 relative on energies of
-teacher-equivalent short chains, bit-equal accept counts); statistical comparisons state theirs.
+Tolerances: tests/tolerances.py, the ONE statement of them (integers equal; single evaluations; the schedule in the sweep
+index for free-running chains, derived from the measured rounding drift; observables at north_star's 1e-6); statistical
+comparisons state theirs.
 """
 import importlib.util
 import json
@@ -16,14 +17,13 @@ from concurrent.futures import ThreadPoolExecutor
 import numpy as np
 import pytest
 
+import tolerances as TOL
+from tolerances import rel
+
 pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 T = A = 1.1
-
-
-def rel(a, b, scale=0.0):
-    return np.abs(np.asarray(a) - np.asarray(b)) / (np.abs(np.asarray(b)) + scale + 1e-300)
 
 
 def sys_of(O, p):
@@ -47,7 +47,8 @@ def oracle_chains(O, s, seeds, R0, eq, nsw, gl, workers=16):
 def test_config5_N16384_against_oracle(S, O, slots, waves, name):
     """BASELINE configs[4]: N=16384 + wall, fcc(16,16) (the reference's own dense lattice),
     several wavefronts per replica.  2 replicas x 2 sweeps against the oracle chain (SMC.c:278-351
-    with K1-K4 at that N): accept counts per sweep bit-equal, energies 1e-9, positions, z histogram."""
+    with K1-K4 at that N): accept counts per sweep bit-equal, energies and positions within the schedule of
+    tests/tolerances.py, z histogram equal."""
     R0 = O.fcc(16, 16)
     nsw, nrep = 2, 2
     p = S.default_params(16384, nrep, flags=S.FLAGS_REFERENCE | S.FLAG_SERIES, tune_slots=slots, tune_waves=waves)
@@ -61,12 +62,12 @@ def test_config5_N16384_against_oracle(S, O, slots, waves, name):
         Rg = eng.positions()
     s = sys_of(O, p)
     refs = oracle_chains(O, s, [12345 + r for r in range(nrep)], R0, 0, nsw, 1)
-    assert rel(E0[0], -41824.76491, 0) < 1e-9          # E0 of the real reference at this lattice
+    assert abs(E0[0] - -41824.76491) < TOL.printed(5)   # E0 of the real reference at this lattice (as printed there)
     for r, ref in enumerate(refs):
         assert np.array_equal(jj[r], ref["jj"]), (jj[r], ref["jj"])
-        assert np.all(rel(Es[r], ref["E"], scale=1.0) < 1e-9), (Es[r], ref["E"])
-        assert rel(ob["meanE"][r], ref["meanE"]) < 1e-9
-        assert np.abs(Rg[r] - ref["R"]).max() < 1e-8
+        TOL.assert_series(Es[r], ref["E"], what="replica %d" % r)
+        TOL.assert_mean_energy(ob["meanE"][r], ref["meanE"], nsw)
+        TOL.assert_positions(Rg[r], ref["R"], nsw, "replica %d" % r)
         assert np.array_equal(ob["zhist"][r], ref["zhist"])
 
 
@@ -91,8 +92,8 @@ def test_several_wavefront_kernel_with_many_accepted_moves(S, O, slots, waves):
     refs = oracle_chains(O, sys_of(O, p), [12345 + r for r in range(nrep)], R0, 0, nsw, 1)
     for r, ref in enumerate(refs):
         assert np.array_equal(jj[r], ref["jj"]) and ref["jj"].min() > 1000, (jj[r], ref["jj"])
-        assert np.all(rel(Es[r], ref["E"], scale=1.0) < 1e-9), (Es[r], ref["E"])
-        assert np.abs(Rg[r] - ref["R"]).max() < 1e-8
+        TOL.assert_series(Es[r], ref["E"], what="replica %d" % r)
+        TOL.assert_positions(Rg[r], ref["R"], nsw, "replica %d" % r)
         assert np.array_equal(ob["zhist"][r], ref["zhist"])
 
 
@@ -111,31 +112,34 @@ def test_config5_N16384_x256_invariants(S, O):
         ob = eng.observables()
         g, oob = eng.hist_info()
         Erec = eng.total_energy()
-    assert np.all(rel(ob["E_last"], Erec) < 1e-9)
+    assert np.all(rel(ob["E_last"], Erec, 1.0) < TOL.INCREMENTAL)
     assert np.all(g == 2) and np.all(oob == 0) and np.all(ob["zhist"].sum(axis=1) == 2 * 16384)
     assert len(np.unique(ob["accepted"])) > 8          # distinct seeds, distinct chains
-    # replicas spread over the launch (first, last, and two inside: all eight wavefronts of a workgroup resident beside
-    # those of other replicas) against the oracle chain (SMC.c:110-118 thermalisation at 2A, :134-195 production)
-    pick = [0, 85, 170, 255]
-    refs = [None] * len(pick)
-    with ThreadPoolExecutor(len(pick)) as ex:
+    # sixteen replicas spread evenly over the launch (round 5: as many as the oracle affords -- 3 sweeps of N = 16384 are ~10 s of
+    # a host core each -- instead of four picked by hand; all eight wavefronts of a workgroup resident beside those of other
+    # replicas) against the oracle chain (SMC.c:110-118 thermalisation at 2A, :134-195 production)
+    pick = [int(x) for x in np.linspace(0, nrep - 1, 16).round()]
+    with ThreadPoolExecutor(min(16, len(os.sched_getaffinity(0)))) as ex:
         refs = list(ex.map(lambda r: O.chain(sys_of(O, p), 12345 + r, R0, O.W_FIXTURE, T, A, 1, 2, 1, e0_restart=False), pick))
     for r, ref in zip(pick, refs):
         assert int(ob["accepted"][r]) == ref["accepted"], r
-        assert rel(ob["E_last"][r], ref["Efinal"]) < 1e-9, r
+        TOL.assert_energy(ob["E_last"][r], ref["Efinal"], 3, "replica %d" % r)
         assert np.array_equal(ob["zhist"][r], ref["zhist"]), r
 
 
 # ------------------------------------------------------------------ BASELINE config 3: N = 4096 x 4096 (the headline)
-CONFIG3_PICK = [0, 1, 1023, 2047, 2048, 3071, 4094, 4095]
+# 64 replicas spread evenly over the launch (round 5: every replica the oracle affords in ~10 s on the box's 16 cores instead of
+# eight picked by hand; first, second, last-but-one and last included)
+CONFIG3_PICK = sorted(set([0, 1, 4094, 4095] + [int(x) for x in np.linspace(0, 4095, 62).round()]))
 
 
 def test_config3_N4096_x4096_headline_launch_against_oracle(S, O):
     """BASELINE configs[2] exactly as bench.py runs it: default parameters, 4096 replicas of N=4096 on one GPU (four
     wavefronts on every SIMD of the chip, the issue-priority table live, `Rs` cycling through the L2s), gather_lapse 10,
-    kernel sweep_kernel_mc64.  Eight replicas spread over the launch against the oracle chain (SMC.c:278-351 sweeps
-    inside sMC's loop, SMC.c:134-195), three sweeps: accepted counts bit-equal, energies 1e-9, positions 1e-8; then the
-    same launch with a gather before every sweep for the per-sweep series and the z histogram (SMC.c:912-927)."""
+    kernel sweep_kernel_mc64.  64 replicas spread over the launch against the oracle chain (SMC.c:278-351 sweeps
+    inside sMC's loop, SMC.c:134-195), three sweeps: accepted counts bit-equal, energies and positions within the schedule
+    of tests/tolerances.py (every replica, and the median replica); then the same launch with a gather before every sweep
+    for the per-sweep series and the z histogram (SMC.c:912-927)."""
     R0 = O.fcc(8, 16)
     nrep, nsw, pick = 4096, 3, CONFIG3_PICK
     p = S.default_params(4096, nrep)                     # bench.py's parameters
@@ -147,15 +151,18 @@ def test_config3_N4096_x4096_headline_launch_against_oracle(S, O):
         Rg = eng.positions()[pick].copy()
         Erec = eng.total_energy()
     s = sys_of(O, p)
-    refs = oracle_chains(O, s, [12345 + r for r in pick], R0, 0, nsw, 10)
-    assert np.all(rel(ob["E_last"], Erec) < 1e-9)        # every replica: incremental energy = recomputed energy
+    # one oracle pass serves both launches: the chain does not depend on gather_lapse, only the histogram does (gathered
+    # before every sweep here; with gather_lapse 10 no gather falls into three sweeps)
+    refs = oracle_chains(O, s, [12345 + r for r in pick], R0, 0, nsw, 1)
+    assert np.all(rel(ob["E_last"], Erec, 1.0) < TOL.INCREMENTAL)   # every replica: incremental energy = recomputed energy
     assert len(np.unique(ob["E_last"])) > nrep // 2      # distinct seeds, distinct chains
     for k, (r, ref) in enumerate(zip(pick, refs)):
         assert int(ob["accepted"][r]) == ref["accepted"], r
-        assert rel(ob["E_last"][r], ref["Efinal"]) < 1e-9, r
-        assert rel(ob["meanE"][r], ref["meanE"]) < 1e-9, r
-        assert abs(ob["acceptance_ratio"][r] - ref["acceptance_ratio"]) < 1e-12, r
-        assert np.abs(Rg[k] - ref["R"]).max() < 1e-8, r
+        TOL.assert_energy(ob["E_last"][r], ref["Efinal"], nsw, "replica %d" % r)
+        TOL.assert_mean_energy(ob["meanE"][r], ref["meanE"], nsw, "replica %d" % r)
+        assert abs(ob["acceptance_ratio"][r] - ref["acceptance_ratio"]) < TOL.RATIO, r
+        assert ob["zhist"][r].sum() == 0
+    TOL.assert_positions(Rg, np.stack([ref["R"] for ref in refs]), nsw, "headline launch")
     # the same full launch with a gather before every sweep: per-sweep series and the wall-normal profile
     p = S.default_params(4096, nrep, flags=p.flags | S.FLAG_SERIES)
     with S.Engine(p) as eng:
@@ -166,11 +173,56 @@ def test_config3_N4096_x4096_headline_launch_against_oracle(S, O):
         Es, jj = eng.series(nsw)
         g, oob = eng.hist_info()
     assert np.all(g == nsw) and np.all(oob == 0) and np.all(ob["zhist"].sum(axis=1) == nsw * 4096)
-    refs = oracle_chains(O, s, [12345 + r for r in pick], R0, 0, nsw, 1)
     for r, ref in zip(pick, refs):
         assert np.array_equal(jj[r], ref["jj"]), (r, jj[r], ref["jj"])
-        assert np.all(rel(Es[r], ref["E"], scale=1.0) < 1e-9), r
+        TOL.assert_series(Es[r], ref["E"], what="replica %d" % r)
         assert np.array_equal(ob["zhist"][r], ref["zhist"]), r
+
+
+def test_config3_full_occupancy_from_equilibrating_per_replica_states(S, O):
+    """Round 5 (VERDICT r4 "what's weak" #3, next #1b): every other 4096-replica test starts all replicas from ONE fcc lattice and
+    runs <= 3 sweeps -- the z sort, the group ranges and the hand-over lists at full occupancy had only ever seen 4096 copies of
+    a relaxing crystal.  Here the headline launch runs 500 sweeps (the slab has spread from 66 to ~150 in z, acceptance 0.43 ->
+    0.51, every replica its own disordered state: profiles/r05_equil_config3.txt), all positions are downloaded and
+    uploaded again per replica (`r0_per_replica`) with fresh explicit seeds, and two further sweeps with a gather before each run
+    at full occupancy.  64 replicas spread over the launch are compared with the oracle chain started from THAT replica's
+    downloaded state (SMC.c:278-351 inside sMC's loop, SMC.c:134-195): accepted counts and z histograms equal, energies and
+    positions within the schedule of tests/tolerances.py.  Also: after the 500 sweeps the energy carried incrementally
+    (SMC.c:340-341) equals the energy recomputed from the positions, for every replica."""
+    R0 = O.fcc(8, 16)
+    nrep, long_run, nsw, pick = 4096, 500, 2, CONFIG3_PICK
+    p = S.default_params(4096, nrep)
+    with S.Engine(p) as eng:
+        assert eng.kernel_form == (2, "smcx::sweep_kernel_mc64"), eng.kernel_form
+        eng.upload(R0, O.W_FIXTURE)
+        eng.run(0, long_run, 10)
+        ob = eng.observables()
+        Erec = eng.total_energy()
+        Rall = eng.positions()
+    drift = rel(ob["E_last"], Erec, 1.0)
+    print("after %d sweeps: acceptance %.3f, mean E %.1f, max relative |E_incremental - E_recomputed| %.2e" %
+          (long_run, ob["acceptance_ratio"].mean(), ob["E_last"].mean(), drift.max()))
+    assert np.all(drift < TOL.INCREMENTAL)
+    assert 0.35 < ob["acceptance_ratio"].mean() < 0.7 and np.ptp(Rall[:, 2::3]) > 120.0       # it did leave the lattice
+    seeds = (900001 + 7 * np.arange(nrep)).astype(np.uint32)
+    p2 = S.default_params(4096, nrep, flags=p.flags | S.FLAG_SERIES)
+    with S.Engine(p2) as eng:
+        assert eng.kernel_form == (2, "smcx::sweep_kernel_mc64"), eng.kernel_form
+        eng.upload(Rall, O.W_FIXTURE, seeds)
+        E0 = eng.total_energy()
+        eng.run(0, nsw, 1)
+        ob2 = eng.observables()
+        Es, jj = eng.series(nsw)
+        Rg = eng.positions()[pick].copy()
+    assert np.all(rel(E0, Erec, 1.0) < TOL.SINGLE * 10)          # the same states (total_energy of either handle)
+    s = sys_of(O, p2)
+    with ThreadPoolExecutor(min(16, len(os.sched_getaffinity(0)))) as ex:
+        refs = list(ex.map(lambda r: O.chain(s, int(seeds[r]), Rall[r], O.W_FIXTURE, T, A, 0, nsw, 1), pick))
+    for r, ref in zip(pick, refs):
+        assert np.array_equal(jj[r], ref["jj"]) and ref["jj"].min() > 1000, (r, jj[r], ref["jj"])
+        TOL.assert_series(Es[r], ref["E"], what="replica %d" % r)
+        assert np.array_equal(ob2["zhist"][r], ref["zhist"]), r
+    TOL.assert_positions(Rg, np.stack([ref["R"] for ref in refs]), nsw, "full occupancy from per-replica states")
 
 
 # ------------------------------------------------------------------ BASELINE config 2: N = 1024 x 1024
@@ -190,13 +242,13 @@ def test_config2_N1024_x1024(S, O):
         Erec = eng.total_energy()
     # (round 3: two teams of one wavefront each, mt16x2; round 4: one wavefront, both probes in one pass, positions in LDS)
     assert form == 2 and name == "smcx::sweep_kernel_ml16", name
-    assert np.all(rel(ob["E_last"], Erec) < 1e-9)
+    assert np.all(rel(ob["E_last"], Erec, 1.0) < TOL.INCREMENTAL)
     assert np.all(g == nsw) and np.all(oob == 0) and np.all(ob["zhist"].sum(axis=1) == nsw * 1024)
-    pick = [0, 1, 127, 128, 511, 640, 1000, 1023]
+    pick = sorted(set([0, 1, 1022, 1023] + [int(x) for x in np.linspace(0, 1023, 126).round()]))   # 128 replicas: ~8 s of oracle
     refs = oracle_chains(O, sys_of(O, p), [12345 + r for r in pick], R0, 0, nsw, 1)
     for r, ref in zip(pick, refs):
         assert np.array_equal(jj[r], ref["jj"]), r
-        assert np.all(rel(Es[r], ref["E"], scale=1.0) < 1e-9), r
+        TOL.assert_series(Es[r], ref["E"], what="replica %d" % r)
         assert np.array_equal(ob["zhist"][r], ref["zhist"]), r
 
 
@@ -225,19 +277,14 @@ def test_screen_ab_against_fp64_kernel_at_scale(S, O, N, lat, nrep, nsw, mx_geom
     order, so they agree to rounding until chaos amplifies it: measured on MI355X at N=4096 the energy
     difference grows about tenfold per sweep from 1e-14 relative (2e-13 after five sweeps, 2e-8 after
     ten) and eventually flips an accept decision.  A pair dropped by the screen would instead shift E
-    by >= 4|V(rc)| = 5e-3 at once.  Required: over the first three sweeps |dE| <= 1e-9 (1 + |E|) for
-    every replica -- seven orders of magnitude below one missed pair --, |dE| < 5e-5 through sweep four (a hundred
-    times below one missed pair for as long as it is asserted; the z-ordered cells of sweep_kernel_mb64 / mc64 sum in
-    yet another order: 3e-6 at most after four sweeps, measured over 256 replicas) and equal accept counts over those
-    sweeps; over all sweeps at most
+    by >= 4|V(rc)| = 5e-3 at once.  Required: through sweep four |dE| within the schedule of tests/tolerances.py for
+    every replica (4e-9 .. 1e-3 + 1e-11 |E|: the z-ordered cells of sweep_kernel_mb64 / mc64 sum in yet another order: 3e-6 at
+    most after four sweeps, measured over 256 replicas) and equal accept counts over those sweeps; over all sweeps at most
     2 % of the replicas with a differing accept count.  (The counters of the diagnostic build, below, test
     every cell on every move directly.)"""
     (Ea, ja), (Eb, jb) = _ab_kernels(S, O, N, lat, nrep, nsw, mx_geom, fp_geom)
-    k = min(nsw, 3)
-    assert np.all(np.abs(Ea[:, :k + 1] - Eb[:, :k + 1]) <= 1e-9 * (1.0 + np.abs(Ea[:, :k + 1]))), \
-        np.abs(Ea[:, :k + 1] - Eb[:, :k + 1]).max()
     k = min(nsw, 4)
-    assert np.abs(Ea[:, :k + 1] - Eb[:, :k + 1]).max() < 5e-5      # 100 x below one missed pair (5e-3); measured <= 3e-6
+    TOL.assert_series(Ea[:, :k + 1], Eb[:, :k + 1], what="screened against fp64 kernel")
     assert np.array_equal(ja[:, :k], jb[:, :k]) and ja.sum() > 0
     diverged = int((ja != jb).any(axis=1).sum())
     assert diverged <= max(1, nrep // 50), diverged
@@ -280,15 +327,10 @@ def test_hand_scheduled_kernel_matches_compiled_kernel(S, O, tmp_path, N, lat, n
         if tag == "mi":
             continue
         assert np.array_equal(out[tag]["jj"], out["mi"]["jj"]) and out[tag]["jj"].sum() > 0, tag
-        dE = np.abs(out[tag]["E"] - out["mi"]["E"])
-        assert np.all(dE <= 1e-9 * (1.0 + np.abs(out["mi"]["E"]))), (tag, dE.max())
-        # positions: two correct kernels drift apart by rounding alone, a factor 30-500 per sweep in the worst replica
-        # (tools/probes/ragged_divergence.py, profiles/r04_rounding_drift_two_kernels.txt: N = 4000, max over 64 replicas
-        # 2e-11 / 3e-10 / 1e-8 .. 1.5e-7 after 1 / 2 / 3 sweeps, the median replica 1e-13 / 1e-12 / 1e-11, and either
-        # kernel as far from the ORACLE as from the other) -- so the typical replica is held to 1e-9 and the worst to
-        # 1e-5, still 500 x below the shift of one missed pair
-        dR = np.abs(out[tag]["R"] - out["mi"]["R"]).max(axis=1)
-        assert np.median(dR) < 1e-9 and dR.max() < 1e-5, (tag, np.median(dR), dR.max())
+        # energies of every sweep and final positions (worst and median replica): the schedule of tests/tolerances.py, which
+        # was derived from exactly this comparison (profiles/r04_rounding_drift_two_kernels.txt)
+        TOL.assert_series(out[tag]["E"], out["mi"]["E"], what=tag)
+        TOL.assert_positions(out[tag]["R"], out["mi"]["R"], nsw, tag)
 
 
 def test_several_sweeps_per_launch_between_sorts(S, O, tmp_path):
@@ -299,9 +341,8 @@ def test_several_sweeps_per_launch_between_sorts(S, O, tmp_path):
     assert str(out["third"]["name"]) == "smcx::sweep_kernel_mc64"
     k = 4
     assert np.array_equal(out["every"]["jj"][:, :k], out["third"]["jj"][:, :k]) and out["every"]["jj"].sum() > 0
-    dE = np.abs(out["every"]["E"][:, :k + 1] - out["third"]["E"][:, :k + 1])
-    assert np.all(dE <= 1e-9 * (1.0 + np.abs(out["every"]["E"][:, :k + 1]))), dE.max()
-    assert np.abs(out["every"]["E"] - out["third"]["E"]).max() < 1e-3
+    TOL.assert_series(out["every"]["E"][:, :k + 1], out["third"]["E"][:, :k + 1], what="sort every third sweep")
+    assert np.abs(out["every"]["E"] - out["third"]["E"]).max() < TOL.CAP_ENERGY
 
 
 def test_benchmark_kernel_ensemble_statistics_beyond_chaos_horizon(S, O, tmp_path):
@@ -380,10 +421,11 @@ os.environ["SMCX_LIB"] = os.path.join(root, "montecarlo-surfacer_amd", "libsmcx_
 spec = importlib.util.spec_from_file_location("smcx_chk", os.path.join(root, "montecarlo-surfacer_amd", "__init__.py"))
 K = importlib.util.module_from_spec(spec); spec.loader.exec_module(K)
 N, Na, Nz, nrep, nsw, gl, slots, waves = (int(v) for v in sys.argv[2:10])
-p = K.default_params(N, nrep, tune_slots=slots, tune_waves=waves)
+L, A = (float(v) for v in sys.argv[10:12]) if len(sys.argv) > 11 else (33.0, 1.1)     # box width, step size (condensed states)
+p = K.default_params(N, nrep, tune_slots=slots, tune_waves=waves, L=L, A=A)
 with K.Engine(p) as eng:
     name = eng.kernel_form[1]
-    eng.upload(K.fcc_init(Na, Nz), K.W_REFERENCE)
+    eng.upload(K.fcc_init(Na, Nz, L=L), K.W_REFERENCE)
     eng.run(0, nsw, gl)
     cnt = (C.c_uint64 * 8)()
     f = K._lib().smcx_debug_work_counts
@@ -391,15 +433,15 @@ with K.Engine(p) as eng:
     assert f(eng._h, cnt) == 0
     acc = int(eng.observables()["accepted"].sum())
 print(json.dumps({"name": name, "inside": int(cnt[0]), "cand": int(cnt[1]), "miss": int(cnt[2]), "groups": int(cnt[3]),
-                  "passes": int(cnt[4]), "acc": acc}))
+                  "passes": int(cnt[4]), "rounds": int(cnt[5]), "unworked": int(cnt[7]), "acc": acc}))
 """
 
 
-def _run_check_worker(tmp_path, mode, N, lat, nrep, nsw, gl, slots=64, waves=1):
+def _run_check_worker(tmp_path, mode, N, lat, nrep, nsw, gl, slots=64, waves=1, L=33.0, A=1.1):
     w = tmp_path / "mbc_worker.py"
     w.write_text(_MBC_WORKER)
     r = subprocess.run([sys.executable, str(w), ROOT, str(N), str(lat[0]), str(lat[1]), str(nrep), str(nsw), str(gl),
-                        str(slots), str(waves)],
+                        str(slots), str(waves), repr(L), repr(A)],
                        env=dict(os.environ, SMCX_CHECK_MB=mode), capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     return json.loads(r.stdout.strip().splitlines()[-1])
@@ -457,6 +499,25 @@ def test_byte_screen_kernel_misses_no_pair_inside_the_cutoff(tmp_path, N, lat, n
     assert d["cand"] < 3 * d["inside"] + 40 * moves
 
 
+@pytest.mark.parametrize("L,A", [(25.6, 0.004), (18.0, 4e-5)])
+def test_two_team_list_hands_every_item_to_a_working_lane(tmp_path, L, A):
+    """sweep_kernel_mt64x8 in a CONDENSED state (fcc(16,16) with a = 1.6: the Lennard-Jones crystal, ~160 candidate bits per
+    probe) and an OVERFULL one (a = 1.125: ~100 bits per wavefront and probe, both hand-overs fill the list).  Round 4's list of
+    64 entries let s_bfm_b64's 6-bit count wrap to an EMPTY mask of working lanes when exactly 64 items were handed over from
+    lane 0 (every wave without special lanes): all 64 candidates dropped, their bits already out of the flag words, nothing
+    noticed.  The diagnostic build now counts, at every hand-over, the items for which no working lane is enabled
+    (`unworked`, must be 0; with the round-4 generator, SMCX_GEN_TTCAP=64, this case counts thousands:
+    profiles/r05_two_team_list_overflow.txt) beside the screen's own miss count; `rounds` shows that the full-list path ran."""
+    d = _run_check_worker(tmp_path, "2", 16384, (16, 16), 2, 2, 1, 64, 8, L=L, A=A)
+    print("L=%.1f: %d pairs inside the cutoff, %d candidate bits, %d missed by the screen, %d further rounds, %d items without a "
+          "working lane, %d accepted" % (L, d["inside"], d["cand"], d["miss"], d["rounds"], d["unworked"], d["acc"]))
+    assert d["name"] == "smcx::sweep_kernel_mt64x8"
+    assert d["miss"] == 0 and d["unworked"] == 0
+    assert d["acc"] > 0 and d["cand"] > 100 * 2 * 2 * 16384
+    if L < 20:
+        assert d["rounds"] > 2 * 16384          # the list was full on most probes: the 64th item went to a further round
+
+
 def test_wavefront_lifetimes_of_a_launch_are_reported(S):
     """bench workload, sweep_kernel_mc64: 4096 wavefronts start together, four per SIMD.  Without the priority
     table the arbiter serves the oldest wavefront of a SIMD first and the lifetimes of one launch
@@ -494,7 +555,7 @@ def test_ensemble_statistics_beyond_chaos_horizon(S, O, N, lat):
     def check(name, a, b):
         a, b = np.asarray(a, float), np.asarray(b, float)
         se = np.sqrt(a.var(ddof=1) / len(a) + b.var(ddof=1) / len(b))
-        assert abs(a.mean() - b.mean()) <= 4 * se + 1e-12 * abs(b.mean()), (name, a.mean(), b.mean(), se)
+        assert abs(a.mean() - b.mean()) <= 4 * se + TOL.RATIO * abs(b.mean()), (name, a.mean(), b.mean(), se)
         return abs(a.mean() - b.mean()) / (se + 1e-300)
 
     zs = [check("meanE", ob["meanE"], [r["meanE"] for r in refs]),
@@ -533,11 +594,11 @@ def test_smcx_main_as_child_process(O):
     s = O.make_sys(256)
     R0 = O.fcc(4, 4)
     refs = [O.chain(s, 12345 + k, R0, O.W_FIXTURE, 1.1, 1.1, 1, 8, 2) for k in range(3)]
-    assert abs(E - np.mean([q["meanE"] for q in refs])) < 2e-6 * abs(E) + 1e-6      # printed with %f
-    assert abs(acc - np.mean([q["acceptance_ratio"] for q in refs])) < 1e-6
-    assert abs(therm - np.mean([q["therm_acceptance"] for q in refs])) < 1e-6
+    assert abs(E - np.mean([q["meanE"] for q in refs])) < TOL.OBSERVABLE * abs(E) + 2 * TOL.printed(6)      # printed with %f
+    assert abs(acc - np.mean([q["acceptance_ratio"] for q in refs])) < 2 * TOL.printed(6)
+    assert abs(therm - np.mean([q["therm_acceptance"] for q in refs])) < 2 * TOL.printed(6)
     ref_prof = np.sum([q["zhist"] for q in refs], axis=0) / float(sum(q["gathers"] for q in refs))
-    assert prof.shape == (33,) and np.abs(prof - ref_prof).max() < 1e-3              # %0.3f
+    assert prof.shape == (33,) and np.abs(prof - ref_prof).max() < 2 * TOL.printed(3)   # %0.3f
     # argument errors are reported, not crashed on
     bad = subprocess.run([exe, "1", "8"], capture_output=True, text=True, timeout=60)
     assert bad.returncode == 2 and "usage" in bad.stderr
@@ -566,5 +627,5 @@ def test_bench_launches_its_own_ranks():
     pr = out["per_rank"]
     for k in ("ms_per_step", "sweep_kernel_ms_per_step", "device_ms_per_step", "gather_ms"):
         assert len(pr[k]["ranks"]) == 2 and pr[k]["min"] <= pr[k]["median"] <= pr[k]["max"] and pr[k]["min"] > 0, k
-    assert abs(pr["ms_per_step"]["max"] - out["ms_per_step"]) < 1e-6 * out["ms_per_step"] + 1e-9
+    assert abs(pr["ms_per_step"]["max"] - out["ms_per_step"]) < TOL.OBSERVABLE * out["ms_per_step"]
     assert out["gather_ms"] > 0

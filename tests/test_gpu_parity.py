@@ -1,16 +1,10 @@
 """GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through
 the C ABI (libsmcx.so), against the CPU oracle on identical seeded inputs.
 
-Tolerances.  All arithmetic is fp64.  The GPU sums the neighbour loop in a
-different order (64-lane tree instead of l = 0..N-1), contracts a*b+c into FMA,
-multiplies by 1/L and 1/T where the reference divides, and uses the device libm;
-every such difference is a relative perturbation of ~1e-16 per operation.
- * single evaluations (K1-K5):   |gpu - oracle| <= 1e-12 * (|value| + scale)
- * one sweep, teacher-forced:    accept decisions identical; E, positions 1e-10
- * free-running chains <= 20 sweeps: north-star tolerance 1e-6 relative on
-   acceptance ratio, mean energy and the z-profile.  Chains are chaotic
-   (1e-13 grows to 1e-6 in 30-60 sweeps), so longer chains are
-   compared through invariants, not value by value.
+Tolerances: tests/tolerances.py states them ONCE (integers equal; single evaluations TOL.SINGLE; free-running
+chains by a schedule in the sweep index derived from the measured rounding drift; observables at north_star's
+TOL.OBSERVABLE = 1e-6 relative).  Chains are chaotic, so longer chains are compared through
+invariants, not value by value.
 """
 import os
 import subprocess
@@ -18,13 +12,12 @@ import subprocess
 import numpy as np
 import pytest
 
+import tolerances as TOL
+from tolerances import rel
+
 pytestmark = pytest.mark.gpu
 
 T = A = 1.1
-
-
-def rel(a, b, scale=0.0):
-    return np.abs(np.asarray(a) - np.asarray(b)) / (np.abs(np.asarray(b)) + scale + 1e-300)
 
 
 def make_engine(S, O, R0, nrep, **kw):
@@ -82,7 +75,7 @@ def test_eval_moves_matches_oracle(S, O, N):
         Um, Fm, Un, Fn = O.eval_move(s, Rb[r], O.W_FIXTURE, int(n[r]), prop[r])
         ref = np.array([Um, *Fm, Un, *Fn])
         sc = np.abs(ref).max()
-        assert np.all(np.abs(out[r] - ref) <= 1e-12 * (np.abs(ref) + sc)), (r, n[r], out[r], ref)
+        assert np.all(np.abs(out[r] - ref) <= TOL.SINGLE * (np.abs(ref) + sc)), (r, n[r], out[r], ref)
         nz += np.count_nonzero(ref)
     assert nz > 6 * nrep  # the in-cutoff and wall branches really ran
 
@@ -100,7 +93,7 @@ def test_eval_moves_without_walls(S, O):
         Rr[3 * n[r]:3 * n[r] + 3] = prop[r]
         Un = O.energy_single(s, Rr, int(n[r])); Fn = O.force_single(s, Rr, int(n[r]))
         ref = np.array([Um, *Fm, Un, *Fn])
-        assert np.all(np.abs(out[r] - ref) <= 1e-12 * (np.abs(ref) + np.abs(ref).max()))
+        assert np.all(np.abs(out[r] - ref) <= TOL.SINGLE * (np.abs(ref) + np.abs(ref).max()))
 
 
 # ------------------------------------------------------------------ K5
@@ -110,7 +103,7 @@ def test_total_energy_matches_oracle(S, O, Na, Nz):
     eng, p = make_engine(S, O, R0, 3)
     E = eng.total_energy()
     ref = O.total_energy(sys_of(O, p), R0, O.W_FIXTURE)
-    assert np.all(rel(E, ref) < 1e-12)
+    assert np.all(rel(E, ref) < TOL.SINGLE)
     eng.close()
 
 
@@ -118,7 +111,7 @@ def test_total_energy_dense_state(S, O):
     R = dense_state(O)
     eng, p = make_engine(S, O, R, 2)
     ref = O.total_energy(sys_of(O, p), R, O.W_FIXTURE)
-    assert np.all(rel(eng.total_energy(), ref) < 1e-12) and abs(ref) > 1e30  # clamp term dominates
+    assert np.all(rel(eng.total_energy(), ref) < TOL.SINGLE) and abs(ref) > 1e30  # clamp term dominates
     eng.close()
 
 
@@ -147,8 +140,8 @@ def test_single_sweep_matches_oracle(S, O, case):
         E0 = O.total_energy(s, R, O.W_FIXTURE)
         acc, E1, _ = O.sweep(s, O.Rng(12345 + r), R, O.W_FIXTURE, A, T, E=E0)
         assert int(ob["accepted"][r]) == acc
-        assert rel(ob["E_last"][r], E1) < 1e-10
-        assert np.abs(Rg[r] - R).max() < 1e-9
+        TOL.assert_energy(ob["E_last"][r], E1, 1, case)
+        TOL.assert_positions(Rg[r], R, 1, case)
         assert ob["zhist"][r].sum() == p.N  # gather_lapse 1: one histogram of the initial state
     eng.close()
 
@@ -164,12 +157,14 @@ def test_compat_shim_one_particle_moves(S, O):
     Rn = np.zeros_like(Rg)
     j, U = 5, 1.25
     jc, Uc = 5, 1.25
-    for _ in range(3):
+    for k in range(3):
         j, U = S.one_particle_moves(p, rng_gpu, Rg, Rn, O.W_FIXTURE, 2.2, T, j, U)
         a, Uc, _ = O.sweep(s, rng_cpu, Rc, O.W_FIXTURE, 2.2, T, E=Uc)
         jc += a
-        assert j == jc and abs(U - Uc) < 1e-10 * max(1.0, abs(Uc))
-        assert np.abs(Rg - Rc).max() < 1e-9 and np.array_equal(Rn, Rg)
+        assert j == jc
+        TOL.assert_energy(U, Uc, k + 1)
+        TOL.assert_positions(Rg, Rc, k + 1)
+        assert np.array_equal(Rn, Rg)
     # the explicit RNG handle advanced by exactly 3*(4N+1) draws
     h = [int(v) for v in rng_gpu[:31]]
     left = int(rng_gpu[31])
@@ -195,17 +190,16 @@ def test_free_running_chain_observables(S, O, Na, Nz, nsw, kw):
     s = sys_of(O, p)
     for r in range(nrep):
         ref = O.chain(s, 12345 + r, R0, O.W_FIXTURE, T, A, 0, nsw, 1)
-        assert rel(ob["acceptance_ratio"][r], ref["acceptance_ratio"]) < 1e-6
-        assert rel(ob["meanE"][r], ref["meanE"]) < 1e-6
-        assert rel(ob["dE"][r], ref["dE"]) < 1e-5
+        assert rel(ob["acceptance_ratio"][r], ref["acceptance_ratio"]) < TOL.OBSERVABLE
+        assert rel(ob["meanE"][r], ref["meanE"]) < TOL.OBSERVABLE
+        assert rel(ob["dE"][r], ref["dE"]) < 10 * TOL.OBSERVABLE       # (a standard deviation: a difference of nearby numbers)
         prof_g = ob["zhist"][r] / float(g[r]); prof_c = ref["zhist"] / float(ref["gathers"])
-        assert np.abs(prof_g - prof_c).sum() <= 1e-6 * prof_c.sum() + 2.0 / ref["gathers"]
+        assert np.abs(prof_g - prof_c).sum() <= TOL.OBSERVABLE * prof_c.sum() + 2.0 / ref["gathers"]
         assert int(g[r]) == nsw and int(oob[r]) == 0 and ob["zhist"][r].sum() == nsw * p.N
-        # pointwise the trajectories separate exponentially (chaos): tight
-        # over the first sweeps, loose at the end of the window; the averaged observables
-        # above stay within the north-star 1e-6
-        assert np.all(rel(Es[r][:9], ref["E"][:9], scale=1.0) < 1e-9)
-        assert np.all(rel(Es[r], ref["E"], scale=1.0) < 1e-3)
+        # pointwise the trajectories separate exponentially (chaos): the schedule of
+        # tests/tolerances.py is tight over the first sweeps and at its cap ("no pair dropped") from the fourth;
+        # the averaged observables above stay within the north-star 1e-6
+        TOL.assert_series(Es[r], ref["E"], what="replica %d" % r)
         assert np.array_equal(jj[r][:8], ref["jj"][:8])
     eng.close()
 
@@ -224,8 +218,9 @@ def test_benchmark_kernel_against_oracle_N4096(S, O):
     for r in range(nrep):
         ref = O.chain(s, 12345 + r, R0, O.W_FIXTURE, T, A, 0, nsw, 1)
         assert np.array_equal(jj[r], ref["jj"])
-        assert np.all(rel(Es[r], ref["E"], scale=1.0) < 1e-9), (Es[r], ref["E"])
-        assert rel(ob["meanE"][r], ref["meanE"]) < 1e-9 and rel(ob["acceptance_ratio"][r], ref["acceptance_ratio"]) < 1e-12
+        TOL.assert_series(Es[r], ref["E"], what="replica %d" % r)
+        TOL.assert_mean_energy(ob["meanE"][r], ref["meanE"], nsw)
+        assert rel(ob["acceptance_ratio"][r], ref["acceptance_ratio"]) < TOL.RATIO
         assert np.array_equal(ob["zhist"][r], ref["zhist"])
     eng.close()
 
@@ -242,10 +237,11 @@ def test_thermalisation_and_E0_restart(S, O):
         ta = eng.therm_acceptance()
         for r in range(2):
             ref = O.chain(s, 12345 + r, R0, O.W_FIXTURE, T, A, 4, 6, 2, e0_restart=restart)
-            assert rel(Es[r][0], ref["E"][0], 1.0) < 1e-12
-            assert np.all(rel(Es[r], ref["E"], 1.0) < 1e-8)
-            assert rel(ob["meanE"][r], ref["meanE"]) < 1e-8
-            assert abs(ta[r] - ref["therm_acceptance"]) < 1e-12
+            if restart:                                      # entry 0 is the energy of the START (SMC.c:194)
+                TOL.assert_energy(Es[r][0], ref["E"][0], 0)
+            TOL.assert_series(Es[r], ref["E"], k0=4, what="replica %d" % r)     # production entry j: 4 + j sweeps from the start
+            TOL.assert_mean_energy(ob["meanE"][r], ref["meanE"], 10)
+            assert abs(ta[r] - ref["therm_acceptance"]) < TOL.RATIO
             assert np.array_equal(jj[r], ref["jj"])
             assert np.array_equal(ob["zhist"][r], ref["zhist"]) and ref["gathers"] == 3
         eng.close()
@@ -269,9 +265,9 @@ def test_thermalisation_at_the_benchmark_geometry(S, O):
     for r in range(2):
         ref = O.chain(s, int(seeds[r]), R0[r], O.W_FIXTURE, T, A, 2, 3, 2, e0_restart=True)
         assert np.array_equal(jj[r], ref["jj"]) and ref["jj"].sum() > 0
-        assert np.all(rel(Es[r], ref["E"], 1.0) < 1e-9)
-        assert abs(ta[r] - ref["therm_acceptance"]) < 1e-12
-        assert rel(ob["meanE"][r], ref["meanE"]) < 1e-9
+        TOL.assert_series(Es[r], ref["E"], k0=2, what="replica %d" % r)
+        assert abs(ta[r] - ref["therm_acceptance"]) < TOL.RATIO
+        TOL.assert_mean_energy(ob["meanE"][r], ref["meanE"], 5)
         assert np.array_equal(ob["zhist"][r], ref["zhist"])
 
 
@@ -290,7 +286,7 @@ def test_explicit_seeds_and_per_replica_positions(S, O):
     for r in range(3):
         ref = O.chain(s, int(seeds[r]), R0[r], O.W_FIXTURE, T, A, 0, 3, 1)
         assert int(ob["accepted"][r]) == ref["accepted"]
-        assert rel(ob["E_last"][r], ref["Efinal"]) < 1e-10
+        TOL.assert_energy(ob["E_last"][r], ref["Efinal"], 3)
     eng.close()
 
 
@@ -325,7 +321,8 @@ def test_zero_uniform_follows_exp_underflow(S, O):
         for m in tr:
             kinds["underflow" if m["ap"] == 0.0 else "tiny" if m["ap"] < 1e-200 else "plain"] += 1
         assert int(ob["accepted"][r]) == acc, (r, tr["ap"], tr["accepted"])
-        assert rel(ob["E_last"][r], E1, 1e-6) < 1e-9 and np.abs(Rg[r] - R).max() < 1e-9
+        TOL.assert_energy(ob["E_last"][r], E1, 1)
+        TOL.assert_positions(Rg[r], R, 1)
     assert kinds["underflow"] > 100 and kinds["tiny"] > 10 and kinds["plain"] > 50, kinds
 
 
@@ -374,8 +371,8 @@ def test_all_geometries_agree(S, O):
         eng.run(0, 3, 1)
         ob = eng.observables()
         assert int(ob["accepted"][0]) == ref["accepted"], (slots, waves)
-        assert rel(ob["E_last"][0], ref["Efinal"]) < 1e-9, (slots, waves)
-        assert np.abs(eng.positions()[0] - ref["R"]).max() < 1e-8, (slots, waves)
+        TOL.assert_energy(ob["E_last"][0], ref["Efinal"], 3, "%d x %d" % (slots, waves))
+        TOL.assert_positions(eng.positions()[0], ref["R"], 3, "%d x %d" % (slots, waves))
         eng.close()
 
 
@@ -395,13 +392,14 @@ def test_full_size_invariants_N4096(S, O):
     eng2, _ = make_engine(S, O, R0, nrep, flags=S.FLAG_WALLS)
     eng2.run(1, 3, 2)
     ob2 = eng2.observables()
-    assert np.all(rel(ob2["E_last"], eng2.total_energy()) < 1e-9)
+    assert np.all(rel(ob2["E_last"], eng2.total_energy(), 1.0) < TOL.INCREMENTAL)
     assert np.array_equal(ob2["accepted"], ob["accepted"])
     assert np.all(g == 1) and np.all(oob == 0) and np.all(ob["zhist"].sum(axis=1) == 4096)
     assert np.all(np.isfinite(Erec))
     s = sys_of(O, p)
     ref = O.chain(s, 12345, R0, O.W_FIXTURE, T, A, 1, 3, 2)
-    assert int(ob["accepted"][0]) == ref["accepted"] and rel(ob["meanE"][0], ref["meanE"]) < 1e-9
+    assert int(ob["accepted"][0]) == ref["accepted"]
+    TOL.assert_mean_energy(ob["meanE"][0], ref["meanE"], 4)
     # distinct seeds really give distinct chains
     assert len(np.unique(ob["E_last"])) > nrep // 2
     eng.close(); eng2.close()
@@ -416,7 +414,8 @@ def test_edge_cases(S, O):
     eng.run(0, 4, 2)
     ob = eng.observables()
     ref = O.chain(sys_of(O, p), 12345, R0, O.W_FIXTURE, T, A, 0, 4, 2)
-    assert int(ob["accepted"][0]) == ref["accepted"] and rel(ob["E_last"][0], ref["Efinal"], 1e-12) < 1e-9
+    assert int(ob["accepted"][0]) == ref["accepted"]
+    TOL.assert_energy(ob["E_last"][0], ref["Efinal"], 4)
     assert np.array_equal(ob["zhist"][0], ref["zhist"])
     eng.close()
     # zero sweeps: observables are those of the initial state
@@ -453,7 +452,8 @@ def test_observable_export_to_device_memory(S, O):
     assert np.array_equal(got["accepted"], ob["accepted"].astype(np.float64))
     assert np.array_equal(got["zhist"], ob["zhist"].astype(np.float64))
     sm = D.summarise(got, p.N, 4)
-    assert np.allclose(sm["meanE"], ob["meanE"], rtol=1e-15) and np.allclose(sm["acceptance_ratio"], ob["acceptance_ratio"])
+    assert np.allclose(sm["meanE"], ob["meanE"], rtol=TOL.EXACT_SERIES, atol=0)
+    assert np.allclose(sm["acceptance_ratio"], ob["acceptance_ratio"], rtol=TOL.EXACT_SERIES, atol=0)
     eng.close()
 
 
@@ -475,7 +475,7 @@ def test_full_density_mobility_and_pressure(S, O):
         ref = O.chain(s, 12345 + r, R0, O.W_FIXTURE, T, A, 1, 6, 2, full_hist=True, pressure=True)
         assert np.array_equal(D[r], ref["D"]) and np.array_equal(Mu[r], ref["Mu"])
         assert D[r].sum() == 3 * 1024 and np.array_equal(D[r].reshape(33, 33, 33).sum(axis=(0, 1)), ob["zhist"][r])
-        assert np.all(rel(P[r], ref["P"]) < 1e-9), (P[r], ref["P"])
+        TOL.assert_virial(P[r], ref["P"], 1 + 2 * np.arange(1, 4) - 1, "replica %d" % r)   # gather g before sweep 2 g - 1 of production
     eng.close()
 
 
@@ -501,12 +501,16 @@ def test_host_sMC_driver(S, O):
         a = O.fft_acf(ref["E"] + 3 * 256 * T / 2, 2500000)
         tau.append(a.sum()); cv.append(np.var(ref["E"]) / T ** 2)
         l1.append(ref["lca"]["n1"] / ref["lca"]["analyses"])
-        assert rel(sim["rep_E"][r], ref["meanE"]) < 1e-9 and rel(sim["rep_acceptance"][r], ref["acceptance_ratio"]) < 1e-12
-        assert np.abs(sim["Rfinal"][r] - ref["R"]).max() < 1e-8
-    assert rel(sim["E"], np.mean(E)) < 1e-9 and rel(sim["acceptance_ratio"], np.mean(acc)) < 1e-12
-    assert rel(sim["P"], np.mean(Pm)) < 1e-9 and rel(sim["dP"], np.mean(dP), scale=1e-12) < 1e-6
-    assert rel(sim["tau"], np.mean(tau)) < 1e-6 and rel(sim["cv"], np.mean(cv)) < 1e-6
-    assert sim["lca_analyses"] == 2 and rel(sim["l1"], np.mean(l1)) < 1e-12 and abs(sim["l2"].sum() - sim["l1"]) < 1e-9
+        TOL.assert_mean_energy(sim["rep_E"][r], ref["meanE"], eq + maxsteps)
+        assert rel(sim["rep_acceptance"][r], ref["acceptance_ratio"]) < TOL.RATIO
+        TOL.assert_positions(sim["Rfinal"][r], ref["R"], eq + maxsteps)
+    TOL.assert_mean_energy(sim["E"], np.mean(E), eq + maxsteps)
+    assert rel(sim["acceptance_ratio"], np.mean(acc)) < TOL.RATIO
+    TOL.assert_virial(sim["P"], np.mean(Pm), eq + maxsteps)
+    assert rel(sim["dP"], np.mean(dP), scale=TOL.EXACT_SERIES) < TOL.OBSERVABLE
+    assert rel(sim["tau"], np.mean(tau)) < TOL.OBSERVABLE and rel(sim["cv"], np.mean(cv)) < TOL.OBSERVABLE
+    assert sim["lca_analyses"] == 2 and rel(sim["l1"], np.mean(l1)) < TOL.RATIO
+    assert abs(sim["l2"].sum() - sim["l1"]) < TOL.EXACT_SERIES * max(1.0, sim["l1"])
 
 
 def test_multi_gpu_c_host_gathers_through_rccl(S, O):
@@ -523,15 +527,16 @@ def test_multi_gpu_c_host_gathers_through_rccl(S, O):
     one = S.host_sMC(p, O.W_FIXTURE, R0, maxsteps, gl, eq)
     multi = S.host_sMC(p, O.W_FIXTURE, R0, maxsteps, gl, eq, gpus=1)            # RCCL path, one-rank communicator
     for k in ("E", "dE", "acceptance_ratio", "therm_acceptance", "P", "dP", "tau", "cv", "l1"):
-        assert multi[k] == one[k] or rel(multi[k], one[k]) < 1e-14, k
+        assert multi[k] == one[k] or rel(multi[k], one[k]) < TOL.EXACT_SERIES, k
     for k in ("rep_E", "rep_acceptance", "zprofile", "Rfinal"):
         assert np.array_equal(multi[k], one[k]), k
     for k in ("l2", "l3"):
-        assert np.allclose(multi[k], one[k], rtol=1e-13, atol=0), k
+        assert np.allclose(multi[k], one[k], rtol=TOL.EXACT_SERIES, atol=0), k
     s = sys_of(O, p)
     for r in (0, nrep - 1):
         ref = O.chain(s, 12345 + r, R0, O.W_FIXTURE, T, A, eq, maxsteps, gl)
-        assert rel(multi["rep_E"][r], ref["meanE"]) < 1e-9 and rel(multi["rep_acceptance"][r], ref["acceptance_ratio"]) < 1e-12
+        TOL.assert_mean_energy(multi["rep_E"][r], ref["meanE"], eq + maxsteps)
+        assert rel(multi["rep_acceptance"][r], ref["acceptance_ratio"]) < TOL.RATIO
     # two shards (3 + 2 replicas) on the same GPU through the host-concatenation fallback: same numbers, global order
     os.environ["SMCX_HOST_GATHER"] = "host"
     try:
@@ -540,8 +545,8 @@ def test_multi_gpu_c_host_gathers_through_rccl(S, O):
         del os.environ["SMCX_HOST_GATHER"]
     for k in ("rep_E", "rep_acceptance", "Rfinal"):
         assert np.array_equal(two[k], one[k]), k
-    assert rel(two["E"], one["E"]) < 1e-14 and np.allclose(two["zprofile"], one["zprofile"], rtol=1e-14, atol=0)
-    assert rel(two["P"], one["P"]) < 1e-13 and rel(two["l1"], one["l1"]) < 1e-13
+    assert rel(two["E"], one["E"]) < TOL.EXACT_SERIES and np.allclose(two["zprofile"], one["zprofile"], rtol=TOL.EXACT_SERIES, atol=0)
+    assert rel(two["P"], one["P"]) < TOL.EXACT_SERIES and rel(two["l1"], one["l1"]) < TOL.EXACT_SERIES
     # bad requests: more devices than the box has, more devices than replicas
     with pytest.raises(S.SmcxError) as e:
         S.host_sMC(p, O.W_FIXTURE, R0, maxsteps, gl, eq, gpus=S.device_count() + 1)
@@ -580,16 +585,17 @@ def test_csv_outputs_and_restart(S, O, tmp_path):
         assert rows[0] == "E, P, jj" and len(rows) == 1 + 4
         for k in range(4):
             e, pk, j = rows[1 + k].split(",")
-            assert abs(float(e) - (ref["E"][2 * k] + 3 * 256 * 1.1 / 2)) < 1e-6
+            eref = ref["E"][2 * k] + 3 * 256 * 1.1 / 2
+            assert abs(float(e) - eref) < TOL.printed(9) + TOL.energy(2 * k, eref)          # %0.9lf
             pref = (ref["P"][k - 1] if k >= 1 else 0.0) + rho * 1.1
-            assert abs(float(pk) - pref) < 1e-9
+            assert abs(float(pk) - pref) < TOL.printed(9) + TOL.virial(2 * k, pref)
             assert int(j) == ref["jj"][k]
         loc = np.loadtxt(tmp_path / ("local_%s_rank%d.csv" % (tag, r)), delimiter=",", skiprows=1)
         assert loc.shape == (33 ** 3, 5)
         assert np.array_equal(loc[:, 3].astype(np.uint64), ref["D"]) and np.array_equal(loc[:, 4].astype(np.uint64), ref["Mu"])
         assert np.array_equal(loc[34, :3], [0, 1, 1])  # nx, ny, nz order: k fastest
         last = S.read_last_state(str(tmp_path / ("last_state_%s_rank%d.csv" % (tag, r))), 256)
-        assert np.abs(last - Rfin[r]).max() < 1e-12 + 5e-13  # %0.12f
+        assert np.abs(last - Rfin[r]).max() < 3 * TOL.printed(12)  # %0.12f
     # restart replica 0 from its file: the chain continues from the stored (rounded) positions
     eng2 = S.Engine(S.default_params(256, 1))
     eng2.upload(S.read_last_state(str(tmp_path / ("last_state_%s_rank0.csv" % tag)), 256), O.W_FIXTURE)
@@ -611,11 +617,11 @@ def test_energy_autocorrelation(S, O):
         assert acf.shape == (3, k)
         for r in range(3):
             ref = O.fft_acf(Es[r], 2500000)   # same series in, restated transform out
-            assert np.abs(acf[r] - ref).max() < 1e-9
-            assert abs(tau[r] - ref.sum()) < 1e-9 * max(1.0, abs(ref.sum()))
-            assert abs(cv[r] - ob["dE"][r] ** 2 / 1.1 ** 2) < 1e-12 * max(1.0, cv[r])
+            assert np.abs(acf[r] - ref).max() < TOL.FFT
+            assert abs(tau[r] - ref.sum()) < TOL.FFT * max(1.0, abs(ref.sum()))
+            assert abs(cv[r] - ob["dE"][r] ** 2 / 1.1 ** 2) < TOL.EXACT_SERIES * max(1.0, cv[r])
         acf5, _, _ = eng.acf(k_max=5)
-        assert acf5.shape == (3, 5) and np.abs(acf5 - acf[:, :5]).max() < 1e-12
+        assert acf5.shape == (3, 5) and np.abs(acf5 - acf[:, :5]).max() < TOL.EXACT_SERIES
         eng.close()
 
 
@@ -668,8 +674,8 @@ def test_screened_kernel_matches_fp64_kernel(S, O, N, lat, L, slots, waves, nsw,
         eng.close()
     (Ra, Ea, ja, za), (Rb, Eb, jb, zb) = out
     assert np.array_equal(ja, jb) and ja.sum() > 0
-    assert np.all(np.abs(Ea - Eb) <= 1e-9 * (1.0 + np.abs(Ea))), np.abs(Ea - Eb).max()
-    assert np.abs(Ra - Rb).max() < 1e-8
+    TOL.assert_series(Ea, Eb, k0=1, what="screened against fp64 kernel")      # (one thermalisation sweep in front)
+    TOL.assert_positions(Ra, Rb, 1 + nsw)
     assert np.array_equal(za, zb)
 
 
@@ -712,8 +718,8 @@ def test_byte_screen_kernel_corner_cases_against_fp64_kernel(S, O, case):
             out.append((eng.positions().copy(), E.copy(), jj.copy(), eng.observables()["zhist"].copy()))
     (Ra, Ea, ja, za), (Rb, Eb, jb, zb) = out
     assert np.array_equal(ja, jb) and ja.sum() > 0
-    assert np.all(np.abs(Ea - Eb) <= 1e-9 * (1.0 + np.abs(Ea))), np.abs(Ea - Eb).max()
-    assert np.abs(Ra - Rb).max() < 1e-8
+    TOL.assert_series(Ea, Eb, k0=1, what="screened against fp64 kernel")      # (one thermalisation sweep in front)
+    TOL.assert_positions(Ra, Rb, 1 + nsw)
     assert np.array_equal(za, zb)
 
 
@@ -744,8 +750,8 @@ def test_wall_grids_other_than_3x3_against_oracle(S, O, M, N, lat, slots, waves)
     for r in range(nrep):
         ref = O.chain(s, 12345 + r, R0.ravel(), W, T, A, 0, nsw, 1)
         assert np.array_equal(jj[r], ref["jj"]) and ref["jj"].sum() > 0
-        assert np.all(rel(Es[r], ref["E"], scale=1.0) < 1e-9), (Es[r], ref["E"])
-        assert np.abs(Rg[r] - ref["R"]).max() < 1e-8
+        TOL.assert_series(Es[r], ref["E"], what="replica %d" % r)
+        TOL.assert_positions(Rg[r], ref["R"], nsw)
     # the walls matter in this state: without them the first sweep's energy differs
     assert abs(ref["E"][0]) > 0
 
@@ -775,8 +781,8 @@ def test_int16_z_ordered_kernel_unsafe_particles_against_fp64_kernel(S, O):
             out.append((eng.positions().copy(), E.copy(), jj.copy()))
     (Ra, Ea, ja), (Rb, Eb, jb) = out
     assert np.array_equal(ja, jb) and ja.sum() > 0
-    assert np.all(np.abs(Ea - Eb) <= 1e-9 * (1.0 + np.abs(Ea))), np.abs(Ea - Eb).max()
-    assert np.abs(Ra - Rb).max() < 1e-8
+    TOL.assert_series(Ea, Eb, k0=1, what="mb64 against fp64 kernel")
+    TOL.assert_positions(Ra, Rb, 1 + nsw)
 
 
 def film_state(O, Na, Nz, L, jitter, seed):
@@ -862,8 +868,8 @@ def test_ragged_sizes_with_padding(S, O, N):
     for r in range(nrep):
         ref = O.chain(s, 12345 + r, R0, O.W_FIXTURE, T, A, 0, 2, 1)
         assert int(ob["accepted"][r]) == ref["accepted"], (N, r)
-        assert rel(ob["E_last"][r], ref["Efinal"], 1e-9) < 1e-9
-        assert np.abs(Rg[r] - ref["R"]).max() < 1e-8
+        TOL.assert_energy(ob["E_last"][r], ref["Efinal"], 2, "N=%d replica %d" % (N, r))
+        TOL.assert_positions(Rg[r], ref["R"], 2, "N=%d replica %d" % (N, r))
         assert np.array_equal(ob["zhist"][r], ref["zhist"])
     eng.close()
 

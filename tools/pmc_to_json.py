@@ -1,8 +1,10 @@
 #!/usr/bin/env python3
 """pmc_to_json.py PROF_DIR OUT_JSON [N nrep sweeps [waves_per_replica]] -- turn the rocprofv3 --pmc csv files of
-tools/profile_valu.sh into per-kernel counters of the LARGEST launch of every sweep kernel (the
-9-sweep launch of the default profile command) and per-wave-move figures.  bench.py reads the JSON
-(profiles/kernel_counters.json) for the instruction mix behind its roofline line."""
+tools/profile_valu.sh into per-kernel counters of ONE full launch of every sweep kernel and per-wave-move figures:
+the LARGEST launch (default: the 2-sweep launch between two z sorts of the default profile command, or the one launch per
+sweep of the several-wavefront kernels), or with PMC_PICK=last the LAST full launch (within 25 % of the largest) -- for profiles
+of `bench.py --equilibrate E`, where the launches in front of the timed ones belong to other states of the system.
+bench.py reads the JSON (profiles/kernel_counters.json) for the instruction mix behind its roofline line."""
 import csv, glob, json, os, sys
 
 d, out = sys.argv[1], sys.argv[2]
@@ -10,7 +12,7 @@ N, nrep, sweeps = (int(v) for v in sys.argv[3:6]) if len(sys.argv) > 5 else (409
 wpr = int(sys.argv[6]) if len(sys.argv) > 6 else 1
 res = {}
 for f in glob.glob(os.path.join(d, "*", "*", "*_counter_collection.csv")):
-    best = {}
+    best, allv = {}, {}
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
         if "sweep_kernel" not in k:
@@ -18,9 +20,15 @@ for f in glob.glob(os.path.join(d, "*", "*", "*_counter_collection.csv")):
         name = k.split("(")[0].replace("void ", "").strip()
         key = (name, r["Counter_Name"])
         v = float(r["Counter_Value"])
+        row = (v, int(r["VGPR_Count"]), int(r["SGPR_Count"]), int(r["Scratch_Size"]), int(r["LDS_Block_Size"]),
+               int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+        allv.setdefault(key, []).append((int(r["Start_Timestamp"]), row))
         if v >= best.get(key, (-1,))[0]:
-            best[key] = (v, int(r["VGPR_Count"]), int(r["SGPR_Count"]), int(r["Scratch_Size"]), int(r["LDS_Block_Size"]),
-                         int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+            best[key] = row
+    if os.environ.get("PMC_PICK") == "last":
+        for key, rows in allv.items():
+            full = [row for _, row in sorted(rows) if row[5] >= 0.75 * best[key][5]]     # by duration: a full (2-sweep) launch
+            best[key] = full[-1]
     for (name, cnt), (v, vg, sg, scr, lds, ns) in best.items():
         e = res.setdefault(name, {"counters": {}, "launch_ns": {}})
         e["counters"][cnt] = v
@@ -39,6 +47,9 @@ for name, e in res.items():
         # cycles summed (guide).  Reported against the launch time at the clock bench.py measures, see DESIGN section 6
         e["active_inst_valu_quadcycles"] = c["SQ_ACTIVE_INST_VALU"]
     e["per_wave_move"] = {k: v / moves for k, v in c.items() if k.startswith("SQ_INSTS")}
+    if c.get("SQ_WAVE_CYCLES"):
+        e["wait_any_frac"] = c.get("SQ_WAIT_ANY", 0.0) / c["SQ_WAVE_CYCLES"]
+        e["wait_inst_any_frac"] = c.get("SQ_WAIT_INST_ANY", 0.0) / c["SQ_WAVE_CYCLES"]
     if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
         # gfx950: FETCH_SIZE counts 64 B per 128-B request of wide coalesced reads (guide, section HBM); these
         # are 8/16-byte scattered and scalar reads, for which the factor is uncalibrated: both readings kept
