@@ -25,10 +25,13 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-# bytes of HBM traffic per byte of FETCH_SIZE for THIS path's reads (24-byte gathers of candidate positions, scalar loads, row
-# fills): calibrated by tools/ubench/gather24.hip on a known record count (profiles/r05_fetch_size_24B_gather.txt).  WRITE_SIZE is
-# exact (guide).  bytes = HBM_FETCH_FACTOR * FETCH_SIZE + WRITE_SIZE.
-HBM_FETCH_FACTOR = 1.0
+# bytes of HBM traffic per byte of FETCH_SIZE for THIS path's reads (24-byte gathers of candidate positions, row fills of 64
+# consecutive 24-byte records): calibrated by tools/ubench/gather24.hip on known record counts
+# (profiles/r05_fetch_size_24B_gather.txt): a random 24-byte gather from a 3 GiB table reads FETCH_SIZE = 73.7 B per record.
+# 64-byte requests counted in full could not give less than 80 (1.25 sectors per record); 128-byte requests tallied at 64 give 72
+# (1.125 lines): the counter halves this pattern like the guide's streamed read; rows of consecutive records read 12.0 B per
+# 24-byte record.  So x 2 throughout.  WRITE_SIZE is exact (guide).  bytes = 2 FETCH_SIZE + WRITE_SIZE.
+HBM_FETCH_FACTOR = 2.0
 BYTES_PER_PAIR_EVAL = 24  # one neighbour position = 3 fp64 per pair-eval
 N_SIMD = 256 * 4          # MI355X_MICROARCH.md: 256 CUs x 4 SIMD-32
 # issue cost of one wave64 VALU instruction on a SIMD-32, MI355X_MICROARCH.md ("v_fma_f32 (wave64) 2 cyc",
@@ -187,6 +190,14 @@ def executed_work(kname, N, lattice, slots, waves, device, nrep=64, sweeps=2, st
             "sample": "%d replicas x %d sweeps" % (nrep, sweeps)}
 
 
+def progress(msg):
+    """one line per stage on stderr (a long silent run looks hung to the job runner; stdout carries only the JSON line)"""
+    print("[bench %.0fs] %s" % (time.perf_counter() - _T0, msg), file=sys.stderr, flush=True)
+
+
+_T0 = time.perf_counter()
+
+
 def cpu_model():
     try:
         for ln in open("/proc/cpuinfo"):
@@ -300,6 +311,7 @@ def side_config(S, label, N, nrep, lattice, sweeps, device, kernel=0, executed=T
     sweeps of the chain: the state a production run sits in), run briefly AFTER the timed region (not the headline)"""
     p = S.default_params(N, nrep, device=device, tune_kernel=kernel)
     state = None
+    progress("side config: %s" % label)
     with S.Engine(p) as e:
         e.upload(S.fcc_init(*lattice), S.W_REFERENCE)
         e.run(0, max(1, equilibrate), 10)
@@ -398,6 +410,7 @@ def main():
 
     if a.equilibrate > 0:
         eng.run(0, a.equilibrate, gather_lapse)
+    progress("warm-up and timed region")
     warm_ms, warm_launches = 0.0, 0
     if a.warmup > 0:
         eng.run(0, a.warmup, gather_lapse)
@@ -492,6 +505,7 @@ def main():
         out["roofline"] = rl
         if world == 1 and kform == 2 and not a.no_cpu:
             # for reference, outside the timed region: the same workload through the all-fp64 sweep kernels
+            progress("timed region done: %.3f ms per step; all-fp64 kernels" % (dt * 1e3 / a.steps))
             try:
                 eng.close()
                 p64 = S.default_params(N, nrep, device=local_rank, first_replica=first, tune_kernel=1)
@@ -509,6 +523,7 @@ def main():
         if world == 1 and not a.no_cpu and zipped:
             # what the timed kernel executed per probe (diagnostic build, sample of the same start)
             eng.close()
+            progress("executed-work counters (diagnostic build)")
             out["executed"] = executed_work(kname, N, lattice, S_, W_, local_rank, nrep=64 if N <= 4096 else 8)
         if world == 1 and not a.no_cpu and N == 4096:
             # the like-for-like kernel: the same workload through sweep_kernel_ma64, whose screen visits EVERY cell for
@@ -537,6 +552,7 @@ def main():
             try:
                 # the reference itself where its prebuilt library is at hand (kind "reference"), with the oracle's rate on
                 # the same cores beside it; the oracle alone (kind "port") otherwise
+                progress("cpu baseline (reference, then oracle port)")
                 ref = cpu_baseline_reference(N, *lattice)
                 port = cpu_baseline(N, *lattice, seconds_target=6.0 if ref else 12.0)
                 if ref:

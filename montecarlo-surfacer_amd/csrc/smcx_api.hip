@@ -201,7 +201,7 @@ static int validate(const smcx_params *p)
 // libsmcx_x.so, loaded by name for an A/B session) and there only under SMCX_ALLOW_ENV_TUNING=1.  The product library and the
 // diagnostic build never read them: a set variable makes smcx_create fail instead of silently changing the kernel a caller gets.
 static const char *const k_tune_env[] = {"SMCX_MX", "SMCX_MI", "SMCX_MA", "SMCX_MB", "SMCX_MC", "SMCX_MCW", "SMCX_MZ",
-                                         "SMCX_RESORT", "SMCX_ZSORT_TPB", "SMCX_LEAD", "SMCX_NO_LEAD"};
+                                         "SMCX_RESORT", "SMCX_ZSORT_TPB", "SMCX_LEAD", "SMCX_NO_LEAD", "SMCX_NO_WINDOWS"};
 
 static int make_tune(const smcx_params *p, Tune *t)
 {
@@ -243,6 +243,7 @@ static int make_tune(const smcx_params *p, Tune *t)
     if (getenv("SMCX_LEAD")) t->lead = 1;
     if (const char *e = getenv("SMCX_MZ")) t->mz = (e[0] != '0');
     if (const char *e = getenv("SMCX_RESORT")) { const int v = atoi(e); if (v > 0) t->resort = v; }
+    if (getenv("SMCX_NO_WINDOWS")) t->windows = 0;
     if (const char *e = getenv("SMCX_ZSORT_TPB")) { const int v = atoi(e); if (v == 128 || v == 256 || v == 512 || v == 1024) t->zsort_tpb = v; }
 #endif
     return SMCX_OK;
@@ -415,6 +416,9 @@ extern "C" int smcx_create(const smcx_params *p, smcx_handle **out)
     DevCtx &c = h.c;
     const size_t nrep = p->nrep, N = p->N;
     CRT(hipSetDevice(p->device));
+    // a replica count that is no multiple of what the device holds at once: launch groups run as windows of units (MaArgs2)
+    c.granule = h.plan.zordered() ? ma_resident_replicas(h.plan, p->device) : 0;
+    c.windows = (h.plan.tune.windows && c.granule > 0 && p->nrep > c.granule && p->nrep % c.granule != 0) ? 1 : 0;
     CRT(hipStreamCreate(&h.stream));
     CRT(hipEventCreate(&h.ev0));
     CRT(hipEventCreate(&h.ev1));
@@ -536,7 +540,18 @@ extern "C" int smcx_replica_granule(smcx_handle *hh, int *granule, char *note, i
                               "so fewer replicas do not make it proportionally shorter (half of them: about 80 %% of the time).  "
                               "%d replicas per GPU use the device fully.",
                               h.p.nrep, h.plan.name, g, g);
-            else
+            else if (h.c.windows) {
+                // (round 5) the sweeps between two gathers run as windows of g (replica, block) units: full launches
+                const int every = h.plan.WPR == 1 ? (h.plan.tune.resort > 0 ? h.plan.tune.resort : 1) : 1;
+                const int nb = (10 + every - 1) / every;   // a group of 10 sweeps, the throughput runs' gather_lapse
+                const long launches = ((long)h.p.nrep * nb + g - 1) / g;
+                std::snprintf(note, (size_t)len,
+                              "%d replicas with %s: the device runs %d of them at once and a sweep is sequential inside a replica.  The "
+                              "sweeps between two gathers are cut into blocks of %d sweep(s) and launched as windows of %d (replica, "
+                              "block) units, so that every launch but the last of a group is full: 10 sweeps cost %ld launches "
+                              "(%d rounds of all replicas would be %d); a multiple of %d replicas per GPU has no partial launch at all.",
+                              h.p.nrep, h.plan.name, g, every, g, launches, nb, nb * rounds, g);
+            } else
                 std::snprintf(note, (size_t)len,
                               "%d replicas with %s: the device runs %d of them at once and a sweep is sequential inside a replica, so "
                               "a sweep takes %d rounds, the last with %d replica(s) on a nearly empty chip (a lone wavefront still "

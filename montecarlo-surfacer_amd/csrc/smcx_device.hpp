@@ -78,6 +78,8 @@ struct DevCtx {
     double *Rs;                   // [nrep][4096][3] sweep_kernel_mb: positions in cell (z-sorted) order, or null
     unsigned short *loc;          // [nrep][N] sweep_kernel_mb: cell of each particle, or null
     unsigned *prio;               // [16384] sweep_kernel_mb/mc: progress of the wavefronts of each SIMD (issue priorities)
+    int granule;                  // replicas the device runs at once with the plan's z-ordered kernel (0: unknown / not one of them)
+    int windows;                  // 1: nrep is no multiple of granule -- launch groups run as windows of `granule` units (MaArgs2)
 #ifdef SMCX_CHECK
     unsigned long long *dbg;      // [4] diagnostic build only (see SweepArgs)
 #endif

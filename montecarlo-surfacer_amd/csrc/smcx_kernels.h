@@ -61,6 +61,7 @@ struct Tune {
     int resort = 1;      // sweeps per z sort of the z-ordered kernels (smcx_params.tune_resort)
     int zsort_tpb = 512; // threads of zsort_kernel for 4096 cells (128, 256, 512, 1024)
     int check_mb = 0;    // diagnostic build only: 1 = sweep_kernel_mb64, 2 = sweep_kernel_mc64 with the fp64 test beside
+    int windows = 1;     // launch groups as windows of units when nrep is no multiple of the resident count (VARIANT: SMCX_NO_WINDOWS)
 };
 struct KernelPlan {
     int form = FORM_NONE, S = 0, WPR = 0;

@@ -6,7 +6,9 @@
 #include "smcx_kernels.h"
 
 #include <cmath>
+#include <cstddef>
 #include <cstdlib>
+#include <vector>
 
 namespace smcx {
 
@@ -32,6 +34,23 @@ struct MaArgs {
     double znear;                                             // 0xe0  mg: |z| from which a wall's sites can be inside the cutoff
 };
 static_assert(sizeof(MaArgs) == 0xe8, "offsets are hard-wired in gen_sweep_ma.py");
+
+// What a launch of a z-ordered sweep kernel really takes (round 5).  A plain launch: workgroup b runs replica b with the
+// arguments `a` (use = 0).  A WINDOW of units (use = 1): the `nsweeps` of a launch group are cut into blocks of `every` sweeps
+// (one z sort each) and unit u = block * nmod + replica; workgroup b of the launch that starts at unit u0 runs replica
+// (u0 + b) % nmod in block (u0 + b) / nmod, with the arguments `a` if that is block blk0 and `b` if it is blk0 + 1 (a launch of
+// at most nmod units spans two blocks at most; a and b differ in sw0 and nsweeps only).  The body reads its arguments through
+// the kernarg pointer it is handed, so the wrapper hands it the address of `a` or of `b` inside the kernarg segment.
+// Why: a sweep is sequential inside a replica and the device holds G replicas at once (smcx_replica_granule), so a launch of
+// nrep = q G + r replicas costs q + 1 rounds, the last one nearly empty (4097 replicas of N = 4096: 1.55 x the time of 4096,
+// 6144: the price of 8192, profiles/r04_replica_cliff.txt).  Launches of G consecutive UNITS keep every round full: the
+// replicas of a launch sit in different blocks of the group, which is legal because replicas are independent chains
+// (SMC.c:40, 66-95: the reference's ranks) and the random numbers of the whole group are generated before it starts; unit
+// (replica, block + 1) lies nmod >= G units behind (replica, block), i.e. in a LATER launch of the same stream.
+struct MaArgs2 {
+    MaArgs a, b;
+    unsigned u0, nmod, blk0, use;
+};
 
 // |z| below which no wall SITE can be within the cutoff of a probe and the clamp of SMC.c:736-739 cannot apply: the wall is
 // Lz/2 - |z| away and a site at least that far; a relative margin covers the roundings of the kernel's own wall distance.
@@ -60,12 +79,24 @@ constexpr unsigned mb_lds_bytes(int S) { return ma_lds_bytes(S); }
 #define SMCX_MA_V95 SMCX_MA_V79, "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95"
 #define SMCX_MA_V127 SMCX_MA_V95, "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127"
 
+// kernarg pointer and replica of this workgroup (see MaArgs2); all uniform: scalar registers.  (kp is left as the compiler has
+// it: rebuilding it from two v_readfirstlane halves SIGN-EXTENDED the low word -- the builtin returns int -- and faulted
+// whenever the kernarg buffer's address had bit 31 set)
+#define SMCX_UNIT(p)                                                                                          \
+    unsigned long long kp = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();                       \
+    unsigned rep = blockIdx.x;                                                                                \
+    if (p.use) {                                                                                              \
+        const unsigned u = p.u0 + blockIdx.x;                                                                 \
+        rep = u % p.nmod;                                                                                     \
+        if (u / p.nmod != p.blk0) kp += (unsigned long long)offsetof(MaArgs2, b);                             \
+    }                                                                                                         \
+    rep = (unsigned)__builtin_amdgcn_readfirstlane((int)rep);
+
 // one kernel per particles-per-lane count; launch bounds = the waves per SIMD 64 + S VGPRs allow
-__global__ void __launch_bounds__(64, 4) sweep_kernel_ma64(MaArgs a)
+__global__ void __launch_bounds__(64, 4) sweep_kernel_ma64(MaArgs2 p)
 {
     unsigned lane = threadIdx.x;
-    unsigned long long kp = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
-    unsigned rep = blockIdx.x;
+    SMCX_UNIT(p)
     asm volatile(
 #include "smcx_sweep_ma_body64.inc"
         : "+v"(lane), "+s"(kp), "+s"(rep)
@@ -73,11 +104,10 @@ __global__ void __launch_bounds__(64, 4) sweep_kernel_ma64(MaArgs a)
         : "memory", "vcc", "scc", SMCX_MA_SGPRS, SMCX_MA_V127);
 }
 
-__global__ void __launch_bounds__(64, 5) sweep_kernel_ma32(MaArgs a)
+__global__ void __launch_bounds__(64, 5) sweep_kernel_ma32(MaArgs2 p)
 {
     unsigned lane = threadIdx.x;
-    unsigned long long kp = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
-    unsigned rep = blockIdx.x;
+    SMCX_UNIT(p)
     asm volatile(
 #include "smcx_sweep_ma_body32.inc"
         : "+v"(lane), "+s"(kp), "+s"(rep)
@@ -85,11 +115,10 @@ __global__ void __launch_bounds__(64, 5) sweep_kernel_ma32(MaArgs a)
         : "memory", "vcc", "scc", SMCX_MA_SGPRS, SMCX_MA_V95);
 }
 
-__global__ void __launch_bounds__(64, 6) sweep_kernel_ma16(MaArgs a)
+__global__ void __launch_bounds__(64, 6) sweep_kernel_ma16(MaArgs2 p)
 {
     unsigned lane = threadIdx.x;
-    unsigned long long kp = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
-    unsigned rep = blockIdx.x;
+    SMCX_UNIT(p)
     asm volatile(
 #include "smcx_sweep_ma_body16.inc"
         : "+v"(lane), "+s"(kp), "+s"(rep)
@@ -99,11 +128,10 @@ __global__ void __launch_bounds__(64, 6) sweep_kernel_ma16(MaArgs a)
 
 // z-binned form (gen_sweep_ma.py ... zb): the cells hold the particles in z order (zsort_kernel below), a probe
 // screens only the 4-slot groups whose z range can reach it
-__global__ void __launch_bounds__(64, 4) sweep_kernel_mb64(MaArgs a)
+__global__ void __launch_bounds__(64, 4) sweep_kernel_mb64(MaArgs2 p)
 {
     unsigned lane = threadIdx.x;
-    unsigned long long kp = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
-    unsigned rep = blockIdx.x;
+    SMCX_UNIT(p)
     asm volatile(
 #ifdef SMCX_CHECK
 #include "smcx_sweep_mbc_body64.inc" // + the full screen beside every ranged pass, counting what the latter lacks
@@ -116,11 +144,10 @@ __global__ void __launch_bounds__(64, 4) sweep_kernel_mb64(MaArgs a)
 }
 
 // byte form (gen_sweep_ma.py ... z8): one word per cell, three instructions per slot and probe, no z words in LDS
-__global__ void __launch_bounds__(64, 4) sweep_kernel_mc64(MaArgs a)
+__global__ void __launch_bounds__(64, 4) sweep_kernel_mc64(MaArgs2 p)
 {
     unsigned lane = threadIdx.x;
-    unsigned long long kp = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
-    unsigned rep = blockIdx.x;
+    SMCX_UNIT(p)
     asm volatile(
 #ifdef SMCX_CHECK
 #include "smcx_sweep_mcc_body64.inc" // + the fp64 cutoff test of every cell beside every pass, counting unflagged pairs
@@ -132,11 +159,10 @@ __global__ void __launch_bounds__(64, 4) sweep_kernel_mc64(MaArgs a)
         : "memory", "vcc", "scc", "m0", SMCX_MA_SGPRS, SMCX_MA_V127);
 }
 // 32 and 16 particles per lane (1024 < N <= 2048, 512 < N <= 1024): 8 and 4 groups
-__global__ void __launch_bounds__(64, 5) sweep_kernel_mc32(MaArgs a)
+__global__ void __launch_bounds__(64, 5) sweep_kernel_mc32(MaArgs2 p)
 {
     unsigned lane = threadIdx.x;
-    unsigned long long kp = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
-    unsigned rep = blockIdx.x;
+    SMCX_UNIT(p)
     asm volatile(
 #ifdef SMCX_CHECK
 #include "smcx_sweep_mcc_body32.inc"
@@ -147,11 +173,10 @@ __global__ void __launch_bounds__(64, 5) sweep_kernel_mc32(MaArgs a)
         :
         : "memory", "vcc", "scc", "m0", SMCX_MA_SGPRS, SMCX_MA_V95);
 }
-__global__ void __launch_bounds__(64, 6) sweep_kernel_mc16(MaArgs a)
+__global__ void __launch_bounds__(64, 6) sweep_kernel_mc16(MaArgs2 p)
 {
     unsigned lane = threadIdx.x;
-    unsigned long long kp = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
-    unsigned rep = blockIdx.x;
+    SMCX_UNIT(p)
     asm volatile(
 #ifdef SMCX_CHECK
 #include "smcx_sweep_mcc_body16.inc"
@@ -164,11 +189,10 @@ __global__ void __launch_bounds__(64, 6) sweep_kernel_mc16(MaArgs a)
 }
 // sweep_kernel_mc16 with the fp64 positions of all 1024 cells in LDS (gen_sweep_ma.py ... z8l): the few-replica form of
 // N <= 1024 -- with one wavefront per SIMD nothing hides a candidate fetch's round trip to L2, so the candidates come from LDS
-__global__ void __launch_bounds__(64, 2) sweep_kernel_ml16(MaArgs a)
+__global__ void __launch_bounds__(64, 2) sweep_kernel_ml16(MaArgs2 p)
 {
     unsigned lane = threadIdx.x;
-    unsigned long long kp = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
-    unsigned rep = blockIdx.x;
+    SMCX_UNIT(p)
     asm volatile(
 #ifdef SMCX_CHECK
 #include "smcx_sweep_mlc_body16.inc"
@@ -181,11 +205,10 @@ __global__ void __launch_bounds__(64, 2) sweep_kernel_ml16(MaArgs a)
 }
 // four wavefronts per replica (8192 < N <= 16384; gen_sweep_ma.py ... z8w): wave w owns the cells 4096 w .. of the
 // z order; LDS = four copies of the row cache (2048 B apart) + the exchange area of the reductions (2 x 2048 B)
-__global__ void __launch_bounds__(256, 1) sweep_kernel_mc64x4(MaArgs a)
+__global__ void __launch_bounds__(256, 1) sweep_kernel_mc64x4(MaArgs2 p)
 {
     unsigned lane = threadIdx.x & 63;
-    unsigned long long kp = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
-    unsigned rep = blockIdx.x;
+    SMCX_UNIT(p)
     unsigned wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     asm volatile(
 #ifdef SMCX_CHECK
@@ -198,11 +221,10 @@ __global__ void __launch_bounds__(256, 1) sweep_kernel_mc64x4(MaArgs a)
         : "memory", "vcc", "scc", "m0", SMCX_MA_SGPRS, SMCX_MA_V127);
 }
 // eight wavefronts per replica with 32 cells per lane each (the same generator output with NS = 32)
-__global__ void __launch_bounds__(512, 1) sweep_kernel_mc32x8(MaArgs a)
+__global__ void __launch_bounds__(512, 1) sweep_kernel_mc32x8(MaArgs2 p)
 {
     unsigned lane = threadIdx.x & 63;
-    unsigned long long kp = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
-    unsigned rep = blockIdx.x;
+    SMCX_UNIT(p)
     unsigned wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     asm volatile(
 #ifdef SMCX_CHECK
@@ -215,11 +237,10 @@ __global__ void __launch_bounds__(512, 1) sweep_kernel_mc32x8(MaArgs a)
         : "memory", "vcc", "scc", "m0", SMCX_MA_SGPRS, SMCX_MA_V95);
 }
 // four wavefronts per replica with 32 cells per lane each: 4096 < N <= 8192 (NS = 32 with WPR = 4)
-__global__ void __launch_bounds__(256, 1) sweep_kernel_mc32x4(MaArgs a)
+__global__ void __launch_bounds__(256, 1) sweep_kernel_mc32x4(MaArgs2 p)
 {
     unsigned lane = threadIdx.x & 63;
-    unsigned long long kp = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
-    unsigned rep = blockIdx.x;
+    SMCX_UNIT(p)
     unsigned wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     asm volatile(
 #ifdef SMCX_CHECK
@@ -236,11 +257,10 @@ __global__ void __launch_bounds__(256, 1) sweep_kernel_mc32x4(MaArgs a)
 // Built: 64 cells per lane x 8 wavefronts (8192 < N <= 16384 with at most 256 replicas per GPU: BASELINE config 5).  Round 3
 // also built 16 x 2 (N <= 1024; slower than sweep_kernel_ml16 since round 4) and 32 x 16 (never the fastest): retired; the
 // generator still writes them (gen_sweep_ma.py ... 16 z8t 2 / 32 z8t 16).
-__global__ void __launch_bounds__(512, 1) sweep_kernel_mt64x8(MaArgs a)
+__global__ void __launch_bounds__(512, 1) sweep_kernel_mt64x8(MaArgs2 p)
 {
     unsigned lane = threadIdx.x & 63;
-    unsigned long long kp = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
-    unsigned rep = blockIdx.x;
+    SMCX_UNIT(p)
     unsigned wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     asm volatile(
 #ifdef SMCX_CHECK
@@ -341,19 +361,21 @@ __device__ inline void bitonic_lds(unsigned *key, int kmax)
 #endif
 template <int CELLS, int TPB>
 __global__ void __launch_bounds__(TPB) zsort_kernel(const double *__restrict__ R, double *__restrict__ Rs,
-                                                    unsigned short *__restrict__ loc, int N, double toFix, int K = 1)
+                                                    unsigned short *__restrict__ loc, int N, double toFix, int K, unsigned u0,
+                                                    unsigned nmod)
 {
+    const unsigned rpl = nmod ? (u0 + blockIdx.x) % nmod : blockIdx.x; // the replica of this workgroup (a window of units: MaArgs2)
     // bits of the particle index in the keys; second keys: 32 - NB - (bits of the group) are left for the Morton code
     constexpr int NB = CELLS <= 4096 ? 12 : 14, GB = CELLS <= 4096 ? 4 : 6, MB = 32 - NB - GB;
     static_assert(CELLS <= 16384 && MB >= 12, "key layout");
     __shared__ unsigned key[CELLS];
-    const double *Rr = R + (size_t)blockIdx.x * 3 * N;
+    const double *Rr = R + (size_t)rpl * 3 * N;
     const double zFix = toFix * (1.0 / 256.0); // 256 / L
     for (int n = threadIdx.x; n < CELLS; n += TPB) {
         unsigned k = ~0u;
         if (n < N) {
             int zq = (int)rint(Rr[3 * n + 2] * zFix);
-            zq = zq < -32767 ? -32767 : zq > 32767 ? 32767 : zq;
+            zq = zq < -32767 ? -32767 : zq > 32766 ? 32766 : zq;   // (32766: a particle's key is never the all-ones key of an empty cell)
             k = ((unsigned)(zq + 32768) << NB) | (unsigned)n;
         }
         key[n] = k;
@@ -362,10 +384,18 @@ __global__ void __launch_bounds__(TPB) zsort_kernel(const double *__restrict__ R
 #ifndef SMCX_ZSORT_NOSORT
     bitonic_lds<CELLS, TPB, false>(key, CELLS);
 #endif
+    // After the sort the N particles occupy the ranks p < N (an empty cell's key ~0u is larger than any particle's).  From here on
+    // a rank is a particle IF p < N -- never "its key is not ~0u": the second key of the LAST particle (n = CELLS - 1) in the
+    // last group with the highest Morton code IS all ones.  Rounds 2-4 tested the key: at N = 4096 and N = 16384 that particle,
+    // whenever it sat in the top z group and in the (+L/2, +L/2) corner cell of the x,y grid, was taken for an empty cell -- its
+    // Rs entry zeroed (a phantom particle at the origin for every probe nearby, the real one invisible) and its `loc` left
+    // stale until the next sort.  Found in round 5 by comparing the energy carried along 500 sweeps with the recomputed one
+    // (one replica in a thousand off by 0.2); the fcc start puts the last particle next to that corner
+    // (tests/test_gpu_configs.py::test_last_particle_in_the_top_corner_cell, profiles/r05_zsort_sentinel_bug.txt).
     const int full = N >> 8; // groups with 256 particles
     for (int p = threadIdx.x; p < CELLS; p += TPB) {
         const unsigned k = key[p];
-        if (k == ~0u) continue;
+        if (p >= N) continue;
         const unsigned n = k & ((1u << NB) - 1u);
         unsigned sub = (unsigned)(p & 255) << (MB - 8); // a partial group keeps z order
 #ifndef SMCX_ZSORT_NOMORTON // (measurement builds: make VARIANT=x EXTRA=-DSMCX_ZSORT_NOMORTON, likewise _NOGATHER, _NOSORT)
@@ -388,10 +418,10 @@ __global__ void __launch_bounds__(TPB) zsort_kernel(const double *__restrict__ R
         if (K > 1) // K wavefronts share the cells: group g is local group g / K of wave g % K (its cells start at
             c = (g % K) * (CELLS / K) + (g / K) * 256 + (c & 255); // (g % K) CELLS / K) -- a probe's 3-4 groups in reach
                                                                     // then lie on different wavefronts
-        double *d = Rs + ((size_t)blockIdx.x * CELLS + c) * 3;
-        if (k != ~0u) {
+        double *d = Rs + ((size_t)rpl * CELLS + c) * 3;
+        if (p < N) { // (a partial last group keeps its particles in front: their keys are smaller than ~0u, see above)
             const unsigned n = k & ((1u << NB) - 1u);
-            loc[(size_t)blockIdx.x * N + n] = (unsigned short)c;
+            loc[(size_t)rpl * N + n] = (unsigned short)c;
 #ifdef SMCX_ZSORT_NOGATHER
             d[0] = d[1] = d[2] = 1.0;
 #else
@@ -441,6 +471,46 @@ bool mt_built(int S, int WPR, int N, int M2, double L, double Lz, double cutoff2
     return big && M2 + 2 <= 30 && mc_box_supported(L, Lz, cutoff2);
 }
 
+// The launches of one launch group of `nsweeps` sweeps, cut into blocks of `every` sweeps (one z sort + one kernel launch
+// each): plain -- one launch per block over all replicas -- or, when the replica count is not a multiple of what the device
+// holds at once (c.windows, MaArgs2), windows of c.granule consecutive units.
+struct UnitLaunch {
+    unsigned grid, u0, nmod, blk0, use;
+    int sw0[2], nsw[2];
+};
+static std::vector<UnitLaunch> unit_launches(const DevCtx &c, int nsweeps, int every)
+{
+    std::vector<UnitLaunch> v;
+    const int nb = (nsweeps + every - 1) / every;
+    auto block = [&](UnitLaunch &l, int k, int blk) { l.sw0[k] = blk * every; l.nsw[k] = nsweeps - blk * every < every ? nsweeps - blk * every : every; };
+    if (!c.windows) {
+        for (int b = 0; b < nb; b++) {
+            UnitLaunch l{(unsigned)c.nrep, 0u, 0u, (unsigned)b, 0u, {0, 0}, {0, 0}};
+            block(l, 0, b); block(l, 1, b);
+            v.push_back(l);
+        }
+        return v;
+    }
+    const long total = (long)c.nrep * nb, G = c.granule;
+    for (long u0 = 0; u0 < total; u0 += G) {
+        const long cnt = total - u0 < G ? total - u0 : G;
+        const int b0 = (int)(u0 / c.nrep), b1 = (int)((u0 + cnt - 1) / c.nrep);
+        UnitLaunch l{(unsigned)cnt, (unsigned)u0, (unsigned)c.nrep, (unsigned)b0, 1u, {0, 0}, {0, 0}};
+        block(l, 0, b0); block(l, 1, b1);
+        v.push_back(l);
+    }
+    return v;
+}
+static MaArgs2 unit_args(const MaArgs &a, const UnitLaunch &l)
+{
+    MaArgs2 p;
+    p.a = a; p.b = a;
+    p.a.sw0 = l.sw0[0]; p.a.nsweeps = l.nsw[0];
+    p.b.sw0 = l.sw0[1]; p.b.nsweeps = l.nsw[1];
+    p.u0 = l.u0; p.nmod = l.nmod; p.blk0 = l.blk0; p.use = l.use;
+    return p;
+}
+
 hipError_t launch_sweeps_mt(const SweepArgs &s, const DevCtx &c, const KernelPlan &pl, int nsweeps, double A, hipStream_t st,
                             SweepTimer *tm)
 {
@@ -461,13 +531,12 @@ hipError_t launch_sweeps_mt(const SweepArgs &s, const DevCtx &c, const KernelPla
     a.dbg = s.dbg;
 #endif
     const double toFix16 = 65536.0 / c.L;
-    for (int sw = 0; sw < nsweeps; sw++) {
-        hipLaunchKernelGGL((zsort_kernel<4 * 64 * 64, 1024>), dim3(c.nrep), dim3(1024), 0, st, (const double *)s.R, c.Rs, c.loc, s.N, toFix16,
-                               pl.WPR / 2);
-        a.sw0 = sw;
+    for (const UnitLaunch &l : unit_launches(c, nsweeps, 1)) {
+        hipLaunchKernelGGL((zsort_kernel<4 * 64 * 64, 1024>), dim3(l.grid), dim3(1024), 0, st, (const double *)s.R, c.Rs, c.loc, s.N, toFix16,
+                           pl.WPR / 2, l.u0, l.nmod);
         hipError_t rc = tm ? tm->mark(st) : hipSuccess;
         if (rc != hipSuccess) return rc;
-        hipLaunchKernelGGL(sweep_kernel_mt64x8, dim3(c.nrep), dim3(512), mt_lds_bytes(8), st, a);
+        hipLaunchKernelGGL(sweep_kernel_mt64x8, dim3(l.grid), dim3(512), mt_lds_bytes(8), st, unit_args(a, l));
         rc = hipGetLastError();
         if (rc == hipSuccess && tm) rc = tm->mark(st);
         if (rc != hipSuccess) return rc;
@@ -496,22 +565,22 @@ hipError_t launch_sweeps_mcw(const SweepArgs &s, const DevCtx &c, int WPR, int n
 #endif
     const double toFix16 = 65536.0 / c.L; // the Morton code of the z sort takes x, y in units of L/65536
     const bool mid = s.N <= 8192; // 32 cells per lane x 4 wavefronts: 8192 cells
-    for (int sw = 0; sw < nsweeps; sw++) {
+    for (const UnitLaunch &l : unit_launches(c, nsweeps, 1)) {
         if (mid)
-            hipLaunchKernelGGL((zsort_kernel<2 * 64 * 64, 1024>), dim3(c.nrep), dim3(1024), 0, st, (const double *)s.R, c.Rs, c.loc,
-                               s.N, toFix16, WPR);
+            hipLaunchKernelGGL((zsort_kernel<2 * 64 * 64, 1024>), dim3(l.grid), dim3(1024), 0, st, (const double *)s.R, c.Rs, c.loc,
+                               s.N, toFix16, WPR, l.u0, l.nmod);
         else
-            hipLaunchKernelGGL((zsort_kernel<4 * 64 * 64, 1024>), dim3(c.nrep), dim3(1024), 0, st, (const double *)s.R, c.Rs, c.loc,
-                               s.N, toFix16, WPR);
-        a.sw0 = sw;
+            hipLaunchKernelGGL((zsort_kernel<4 * 64 * 64, 1024>), dim3(l.grid), dim3(1024), 0, st, (const double *)s.R, c.Rs, c.loc,
+                               s.N, toFix16, WPR, l.u0, l.nmod);
+        const MaArgs2 p2 = unit_args(a, l);
         hipError_t rc = tm ? tm->mark(st) : hipSuccess;
         if (rc != hipSuccess) return rc;
         if (mid)
-            hipLaunchKernelGGL(sweep_kernel_mc32x4, dim3(c.nrep), dim3(256), mcw_lds_bytes(4), st, a);
+            hipLaunchKernelGGL(sweep_kernel_mc32x4, dim3(l.grid), dim3(256), mcw_lds_bytes(4), st, p2);
         else if (WPR == 4)
-            hipLaunchKernelGGL(sweep_kernel_mc64x4, dim3(c.nrep), dim3(256), mcw_lds_bytes(4), st, a);
+            hipLaunchKernelGGL(sweep_kernel_mc64x4, dim3(l.grid), dim3(256), mcw_lds_bytes(4), st, p2);
         else
-            hipLaunchKernelGGL(sweep_kernel_mc32x8, dim3(c.nrep), dim3(512), mcw_lds_bytes(8), st, a);
+            hipLaunchKernelGGL(sweep_kernel_mc32x8, dim3(l.grid), dim3(512), mcw_lds_bytes(8), st, p2);
         rc = hipGetLastError();
         if (rc == hipSuccess && tm) rc = tm->mark(st);
         if (rc != hipSuccess) return rc;
@@ -586,9 +655,9 @@ hipError_t launch_sweeps_ma(const SweepArgs &s, const DevCtx &c, const KernelPla
             a.zFix = a.toFix;
         }
         const int every = pl.tune.resort > 0 ? pl.tune.resort : 1;
-        for (int sw = 0; sw < nsweeps; sw += every) {
+        for (const UnitLaunch &l : unit_launches(c, nsweeps, every)) {
             const int tpb = pl.tune.zsort_tpb; // 512 threads (8 keys each) measured best of 128..1024 for 4096 cells
-#define SMCX_ZSORT(C, T) hipLaunchKernelGGL((zsort_kernel<C, T>), dim3(c.nrep), dim3(T), 0, st, (const double *)s.R, c.Rs, c.loc, s.N, toFix)
+#define SMCX_ZSORT(C, T) hipLaunchKernelGGL((zsort_kernel<C, T>), dim3(l.grid), dim3(T), 0, st, (const double *)s.R, c.Rs, c.loc, s.N, toFix, 1, l.u0, l.nmod)
             if (S == 64 && tpb == 128) SMCX_ZSORT(64 * 64, 128);
             else if (S == 64 && tpb == 256) SMCX_ZSORT(64 * 64, 256);
             else if (S == 64 && tpb == 1024) SMCX_ZSORT(64 * 64, 1024);
@@ -596,30 +665,32 @@ hipError_t launch_sweeps_ma(const SweepArgs &s, const DevCtx &c, const KernelPla
             else if (S == 32) SMCX_ZSORT(32 * 64, 256);
             else SMCX_ZSORT(16 * 64, 256);
 #undef SMCX_ZSORT
-            a.sw0 = sw; a.nsweeps = nsweeps - sw < every ? nsweeps - sw : every;
+            const MaArgs2 p2 = unit_args(a, l);
             hipError_t rc = tm ? tm->mark(st) : hipSuccess;
             if (rc != hipSuccess) return rc;
             if (mc && S == 64)
-                hipLaunchKernelGGL(sweep_kernel_mc64, dim3(c.nrep), dim3(64), mc_lds_bytes(), st, a);
+                hipLaunchKernelGGL(sweep_kernel_mc64, dim3(l.grid), dim3(64), mc_lds_bytes(), st, p2);
             else if (mc && S == 32)
-                hipLaunchKernelGGL(sweep_kernel_mc32, dim3(c.nrep), dim3(64), mc_lds_bytes(), st, a);
+                hipLaunchKernelGGL(sweep_kernel_mc32, dim3(l.grid), dim3(64), mc_lds_bytes(), st, p2);
             else if (mc)
                 if (pl.lpos)
-                    hipLaunchKernelGGL(sweep_kernel_ml16, dim3(c.nrep), dim3(64), ml_lds_bytes(), st, a);
+                    hipLaunchKernelGGL(sweep_kernel_ml16, dim3(l.grid), dim3(64), ml_lds_bytes(), st, p2);
                 else
-                    hipLaunchKernelGGL(sweep_kernel_mc16, dim3(c.nrep), dim3(64), mc_lds_bytes(), st, a);
+                    hipLaunchKernelGGL(sweep_kernel_mc16, dim3(l.grid), dim3(64), mc_lds_bytes(), st, p2);
             else
-                hipLaunchKernelGGL(sweep_kernel_mb64, dim3(c.nrep), dim3(64), mb_lds_bytes(64), st, a);
+                hipLaunchKernelGGL(sweep_kernel_mb64, dim3(l.grid), dim3(64), mb_lds_bytes(64), st, p2);
             rc = hipGetLastError();
             if (rc == hipSuccess && tm) rc = tm->mark(st);
             if (rc != hipSuccess) return rc;
         }
         return hipSuccess;
     }
-    void (*f)(MaArgs) = S == 64 ? sweep_kernel_ma64 : S == 32 ? sweep_kernel_ma32 : sweep_kernel_ma16;
+    void (*f)(MaArgs2) = S == 64 ? sweep_kernel_ma64 : S == 32 ? sweep_kernel_ma32 : sweep_kernel_ma16;
     hipError_t rc = tm ? tm->mark(st) : hipSuccess;
     if (rc != hipSuccess) return rc;
-    hipLaunchKernelGGL(f, dim3(c.nrep), dim3(64), ma_lds_bytes(S), st, a);
+    MaArgs2 p2;
+    p2.a = a; p2.b = a; p2.u0 = p2.nmod = p2.blk0 = p2.use = 0;
+    hipLaunchKernelGGL(f, dim3(c.nrep), dim3(64), ma_lds_bytes(S), st, p2);
     rc = hipGetLastError();
     if (rc == hipSuccess && tm) rc = tm->mark(st);
     return rc;

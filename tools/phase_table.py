@@ -1,0 +1,88 @@
+#!/usr/bin/env python3
+"""phase_table.py BODY.inc -- static instruction count per phase of the STEADY copy of the move of a merged-pass kernel
+(sweep_kernel_mc64: csrc/build/smcx_sweep_mc_body64.inc), by instruction kind.  VERDICT r4 next #4: where the non-vector
+instructions of a move sit.  Static = the main line of the steady copy as written (cold pieces -- near-wall pass, further
+rounds, second hand-over, unsafe probes -- are not on it); the two screens are unrolled over all 16 groups and entered by a
+computed jump, so their group blocks are listed per block and weighted with the executed groups per pass in the last column."""
+import re
+import sys
+
+path = sys.argv[1]
+groups_per_pass = float(sys.argv[2]) if len(sys.argv) > 2 else 3.63      # executed, bench line `executed` (lattice start)
+accept = float(sys.argv[3]) if len(sys.argv) > 3 else 0.46
+lines = [re.sub(r'\\n\\t"$', "", l.strip()[1:]) for l in open(path) if l.startswith('"')]
+pre = re.match(r"(L\d+z8\w*?)_S_move:", next(l for l in lines if "_S_move:" in l)).group(1)
+lab = lambda n: "%s_S_%s:" % (pre, n)
+idx = {l: i for i, l in enumerate(lines)}
+at = lambda n: idx[lab(n)]
+end = next(i for i in range(at("move"), len(lines)) if lines[i].startswith("s_branch %s_G_move" % pre) or lines[i] == "%s_move:" % pre)
+rej_branch = next(i for i in range(at("mgR0"), at("reject")) if lines[i].startswith("s_cbranch_scc0 %s_S_reject" % pre))
+rowtest = next(i for i in range(at("nsr"), end) if lines[i].startswith("s_cmp_eq_u32") and "63" in lines[i])
+
+
+def kind(l):
+    if l.endswith(":"):
+        return None
+    op = l.split()[0]
+    if op in ("s_waitcnt", "s_nop"):
+        return "wait/nop"
+    if op.startswith(("s_cbranch", "s_branch", "s_setpc", "s_swappc")):
+        return "branch"
+    if op.startswith("s_load"):
+        return "smem"
+    if op.startswith("s_"):
+        return "salu"
+    if op.startswith("ds_"):
+        return "lds"
+    if op.startswith(("global_", "buffer_", "flat_")):
+        return "vmem"
+    if op.startswith("v_"):
+        return "valu_f64" if "_f64" in op else "valu"
+    return "other"
+
+
+KINDS = ["valu", "valu_f64", "salu", "branch", "lds", "vmem", "smem", "wait/nop"]
+
+
+def count(a, b):
+    c = dict.fromkeys(KINDS, 0)
+    for l in lines[a:b]:
+        k = kind(l)
+        if k in c:
+            c[k] += 1
+    return c
+
+
+grp = (at("sg14_A") - at("sg15_A"))
+phases = [
+    ("move head, probe B's compact copy", at("move"), at("nob1"), 1.0),
+    ("screen A: range test, computed jump", at("nob1"), at("sg15_A"), 1.0),
+    ("screen A: ONE group of 4 slots (x %.2f executed)" % groups_per_pass, at("sg15_A"), at("sg14_A"), groups_per_pass),
+    ("screen A: exit (flag words to their slots)", at("sfinL_A"), at("sdone_A"), 0.6),
+    ("fix A: unsafe probe test", at("sdone_A"), at("nofa"), 1.0),
+    ("screen B: range test, computed jump", at("nofa"), at("sg15_B"), 1.0),
+    ("screen B: ONE group of 4 slots (x %.2f executed)" % groups_per_pass, at("sg15_B"), at("sg14_B"), groups_per_pass),
+    ("screen B: exit", at("sfinL_B"), at("sdone_B"), 0.6),
+    ("fix B: unsafe probe test", at("sdone_B"), at("nofb"), 1.0),
+    ("pass set-up: log-uniform asked for, near-wall test, two hand-overs through the list, probes, side sources, "
+     "displacement asked for, exclusions by compare, wall dz", at("nofb"), at("wdz_mf"), 1.0),
+    ("fp64 body (both probes, one pass)", at("wdz_mf"), at("nolj_mf"), 1.0),
+    ("side pair captured", at("nolj_mf"), at("mgR0"), 1.0),
+    ("reduction (8 sums) + Metropolis step", at("mgR0"), rej_branch + 1, 1.0),
+    ("accept path (x %.2f accepted)" % accept, rej_branch + 1, at("reject"), accept),
+    ("Fm of particle n+1 (side result), its proposal, fixed-point copies", at("reject"), rowtest, 1.0),
+    ("row test; row fill + issue priority (1 move in 64)", rowtest, at("nocross"), 1.0 / 64),
+    ("loop bookkeeping", at("nocross"), end + 1, 1.0),
+]
+print("%s: steady copy of the move, static instruction counts by phase (lines %d..%d of the body)" % (path.split("/")[-1], at("move"), end))
+print("%-64s" % "phase" + "".join("%9s" % k for k in KINDS) + "%9s%10s" % ("all", "weighted"))
+tot = dict.fromkeys(KINDS, 0.0)
+wsum = 0.0
+for name, a, b, w in phases:
+    c = count(a, b)
+    n = sum(c.values()) - c["wait/nop"]
+    print("%-64s" % name[:64] + "".join("%9d" % c[k] for k in KINDS) + "%9d%10.1f" % (n, n * w))
+    for k in KINDS:
+        tot[k] += c[k] * w
+    wsum += n * w
+print("%-64s" % "per move, weighted with the executed fractions" + "".join("%9.1f" % tot[k] for k in KINDS) + "%9s%10.1f" % ("", wsum))

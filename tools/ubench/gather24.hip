@@ -40,7 +40,7 @@ __global__ void __launch_bounds__(256) gather24(const double *tab, uint64_t nrec
         const double *p = tab + 3 * rec;
         double2 a; double b;
         asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx2 %1, %2, off offset:16\n\ts_waitcnt vmcnt(0)"
-                     : "=v"(a), "=v"(b) : "v"(p) : "memory");
+                     : "=&v"(a), "=&v"(b) : "v"(p) : "memory");   // early clobber: the address is read again by the second load
         acc += a.x + a.y + b;
     }
     if (acc == 1.2345e300) sink[0] = acc;
@@ -57,7 +57,7 @@ __global__ void __launch_bounds__(256) rows24(const double *tab, uint64_t nrec, 
         const double *p = tab + 3 * rec;
         double2 a; double b;
         asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx2 %1, %2, off offset:16\n\ts_waitcnt vmcnt(0)"
-                     : "=v"(a), "=v"(b) : "v"(p) : "memory");
+                     : "=&v"(a), "=&v"(b) : "v"(p) : "memory");   // early clobber: the address is read again by the second load
         acc += a.x + a.y + b;
     }
     if (acc == 1.2345e300) sink[0] = acc;
@@ -70,7 +70,7 @@ __global__ void __launch_bounds__(256) stream16(const double2 *tab, uint64_t n16
     double acc = 0.0;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) {
         double2 a;
-        asm volatile("global_load_dwordx4 %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(a) : "v"(tab + i) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=&v"(a) : "v"(tab + i) : "memory");
         acc += a.x + a.y;
     }
     if (acc == 1.2345e300) sink[0] = acc;
