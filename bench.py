@@ -97,8 +97,6 @@ def issue_roofline(kname, sweep_ms_per_sweep, nrep, N, clock_ghz, start=None):
              (m.get("SQ_INSTS_VMEM_RD") or 0) + (m.get("SQ_INSTS_VMEM_WR") or 0) + (m.get("SQ_INSTS_SMEM") or 0))
     all_lo = b32 * 1.8 + f64 * 3.4 + tr * 8.0 + other * 2.0
     all_hi = b32 * 3.2 + f64 * 3.4 + tr * 8.0 + other * 2.0
-    int32 = (m.get("SQ_INSTS_VALU_INT32") or 0) + (m.get("SQ_INSTS_VALU_INT64") or 0)
-    cvt = m.get("SQ_INSTS_VALU_CVT") or 0
     out = {"bound": "valu_issue", "achieved": achieved, "peak": peak, "unit": "G SIMD-cycles/s of VALU issue",
            "frac": achieved / peak,
            # all executed instructions at the per-kind costs measured inside this kernel, 32-bit VALU all-fast .. all-slow
@@ -107,10 +105,9 @@ def issue_roofline(kname, sweep_ms_per_sweep, nrep, N, clock_ghz, start=None):
            "wave_instr_per_move_all_kinds": m["SQ_INSTS_VALU"] + other,
            "clock_ghz": clock_ghz, "waves_per_replica": wpr,
            "valu_per_move": m["SQ_INSTS_VALU"], "fp64_per_move": f64, "fp64_trans_per_move": tr,
-           "int_per_move": int32 or None, "cvt_per_move": cvt or None,
            "salu_per_move": m.get("SQ_INSTS_SALU"), "branch_per_move": m.get("SQ_INSTS_BRANCH"), "lds_per_move": m.get("SQ_INSTS_LDS"),
            "vmem_per_move": (m.get("SQ_INSTS_VMEM_RD") or 0) + (m.get("SQ_INSTS_VMEM_WR") or 0),
-           "guide_issue_cycles_per_wave_move": need, "simd_cycles_per_wave_move": peak * 1e9 / wave_moves_per_s,
+           "simd_cycles_per_wave_move": peak * 1e9 / wave_moves_per_s,
            "wait_any_frac": kc.get("wait_any_frac"), "wait_inst_any_frac": kc.get("wait_inst_any_frac")}
     hb = kc.get("hbm_bytes_per_sweep")
     if hb:
@@ -242,8 +239,7 @@ def cpu_baseline_reference(N, Na, Nz, seconds_target=12.0):
     pe = cores * sweeps * 2.0 * N * (N - 1.0)
     return {"value": pe / wall, "unit": "pair-evals/s", "cores": cores, "kind": "reference", "cpu_model": cpu_model(),
             "per_core": pe / wall / cores,
-            "sample": "%d chains (one process per core) x %d sweeps of N=%d, fcc(%d,%d), the reference's own oneParticleMoves "
-                      "(gcc -O3), slowest chain %.1f s" % (cores, sweeps, N, Na, Nz, wall)}
+            "sample": "%d chains (one process per core) x %d sweeps, the reference's oneParticleMoves, slowest %.1f s" % (cores, sweeps, wall)}
 
 
 def cpu_baseline(N, Na, Nz, seconds_target=12.0):
@@ -295,6 +291,25 @@ def cpu_baseline(N, Na, Nz, seconds_target=12.0):
                       % (cores, sweeps, N, Na, Nz, flags, wall)}
 
 
+def compact(o, digits=5):
+    """the JSON line in few bytes: floats to `digits` significant digits, None-valued keys dropped"""
+    if isinstance(o, float):
+        return float("%.*g" % (digits, o))
+    if isinstance(o, dict):
+        return {k: compact(v, digits) for k, v in o.items() if v is not None or k in ("vs_baseline", "frac", "traffic", "value")}
+    if isinstance(o, (list, tuple)):
+        return [compact(v, digits) for v in o]
+    return o
+
+
+SIDE_ROOFLINE_KEYS = ("bound", "frac", "frac_all_instruction_kinds_at_measured_costs_range", "clock_ghz", "valu_per_move", "fp64_per_move",
+                      "salu_per_move", "branch_per_move", "wave_instr_per_move_all_kinds", "simd_cycles_per_wave_move", "wait_any_frac",
+                      "wait_inst_any_frac", "note")
+SIDE_EXECUTED_KEYS = ("groups_screened_per_pass", "groups_per_wavefront", "cells_screened_per_move", "candidate_bits_per_probe",
+                      "pairs_inside_cutoff_per_probe", "pairs_inside_cutoff_missed", "handed_over_without_working_lane",
+                      "further_rounds_per_probe", "note")
+
+
 def z_profile_width(ob, p):
     """standard deviation of z over the gathers of the last run (the wall-normal profile's width: identifies the state)"""
     import numpy as np
@@ -331,13 +346,16 @@ def side_config(S, label, N, nrep, lattice, sweeps, device, kernel=0, executed=T
     pe = nrep * sweeps * 2.0 * N * (N - 1.0)
     start = "fcc(%d,%d)" % tuple(lattice) + ("+%d sweeps" % equilibrate if equilibrate else "")
     out = {"workload": label, "N": N, "replicas": nrep, "start": start, "sweeps": sweeps, "value": pe / (run_ms * 1e-3),
-           "ms_per_sweep": ms / sweeps, "device_ms_per_sweep": run_ms / sweeps, "kernel": kname,
-           "geometry": "S=%d x %d" % (s_, w_), "acceptance": float(ob["acceptance_ratio"].mean()),
-           "mean_E_last": float(ob["E_last"].mean()), "z_std": z_profile_width(ob, p)}
-    rl = issue_roofline(kname, ms / sweeps, nrep, N, ghz, start=start)
-    out["roofline"] = rl if rl else {"bound": "valu_issue", "frac": None, "clock_ghz": ghz}
+           "ms_per_sweep": ms / sweeps, "kernel": kname.replace("smcx::sweep_kernel_", ""),
+           "acceptance": float(ob["acceptance_ratio"].mean()), "mean_E_last": float(ob["E_last"].mean()), "z_std": z_profile_width(ob, p)}
+    rl = issue_roofline(kname, ms / sweeps, nrep, N, ghz, start=start) or {"bound": "valu_issue", "frac": None, "clock_ghz": ghz}
+    out["roofline"] = {k: rl[k] for k in SIDE_ROOFLINE_KEYS if k in rl}
+    if rl.get("hbm"):
+        out["roofline"]["hbm_gbs"] = rl["hbm"]["gbs"]
+        out["roofline"]["hbm_frac_of_peak"] = rl["hbm"]["frac_of_peak"]
     if executed and zipped:
-        out["executed"] = executed_work(kname, N, lattice, s_, w_, device, nrep=min(nrep, 64 if N <= 4096 else 8), state=state)
+        ex = executed_work(kname, N, lattice, s_, w_, device, nrep=min(nrep, 64 if N <= 4096 else 8), state=state)
+        out["executed"] = {k: ex[k] for k in SIDE_EXECUTED_KEYS if k in ex}
     return out
 
 
@@ -464,17 +482,16 @@ def main():
             "value": value, "unit": "pair-evals/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": dt * 1e3 / a.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "BASELINE config 3 per GPU: N=%d LJ + wall (M=3), %d replica chains per GPU, %s start, "
-                                   "L=33 Lz=240 T=A=1.1, seeds 12345+replica" % (N, nrep, start),
+            "config": {"workload": "BASELINE config 3 per GPU: N=%d LJ + wall (M=3), %d replicas per GPU, %s, L=33 Lz=240 T=A=1.1"
+                                   % (N, nrep, start),
                        "N": N, "replicas_per_gpu": nrep, "replicas_total": nrep * world, "gather_lapse": gather_lapse,
-                       "replicas_resident_at_once": granule,
-                       "geometry": "S=%d particles/lane, %d wavefront(s)/replica" % (S_, W_),
-                       "parallelism": "replica-sharded x%d, no data-path collective; %s all-gather of observables at the end"
+                       "replicas_resident_at_once": granule, "geometry": "S=%d x %d wavefront(s)" % (S_, W_),
+                       "parallelism": "replicas sharded x%d, %s all-gather of observables at the end"
                                       % (world, "RCCL" if backend == "nccl" else backend)},
             "roofline": None,
             # SURVEY 8d's streaming model (24 B per pair-eval): NOT the binding bound -- positions are register-resident
             "roofline_hbm_model": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                   "frac": achieved / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": algo_bytes_per_launch},
+                                   "frac": achieved / HBM_PEAK_GBS},
             "device_ms": {"sweep_kernels": sweep_ms, "whole_run": run_ms, "helpers": run_ms - sweep_ms},
             "observables": {"mean_acceptance": summ["mean_acceptance"], "mean_energy": summ["mean_of_meanE"],
                             "replicas_gathered": int(len(obs["accepted"]))},
@@ -492,7 +509,6 @@ def main():
         rl = issue_roofline(kname, sweep_ms / a.steps, nrep, N, clock_ghz, start=start)
         base = {"kernel": kname, "launches": launches, "avg_launch_ms": sweep_ms / max(launches, 1),
                 # what `rocprofv3 --stats` averages over: the warm-up launches as well
-                "launches_incl_warmup": launches + warm_launches,
                 "avg_launch_ms_incl_warmup": (sweep_ms + warm_ms) / max(launches + warm_launches, 1),
                 "ms_per_sweep": sweep_ms / a.steps, "traffic": None}
         if rl is None:   # no committed counters for this kernel / workload: the clock and the time are still live
@@ -524,7 +540,8 @@ def main():
             # what the timed kernel executed per probe (diagnostic build, sample of the same start)
             eng.close()
             progress("executed-work counters (diagnostic build)")
-            out["executed"] = executed_work(kname, N, lattice, S_, W_, local_rank, nrep=64 if N <= 4096 else 8)
+            ex = executed_work(kname, N, lattice, S_, W_, local_rank, nrep=64 if N <= 4096 else 8)
+            out["executed"] = {k: ex[k] for k in SIDE_EXECUTED_KEYS + ("fraction_of_all_pairs_screened", "sample") if k in ex}
         if world == 1 and not a.no_cpu and N == 4096:
             # the like-for-like kernel: the same workload through sweep_kernel_ma64, whose screen visits EVERY cell for
             # every probe as the reference's loops do (SMC.c:563-578, 597-612)
@@ -532,18 +549,18 @@ def main():
                 eng.close()
                 apk = side_config(S, "the timed workload through the last kernel that tests every pair", N, nrep, lattice, 5,
                                   local_rank, kernel=S.KERNEL_MA, executed=False)
-                out["all_pairs_kernel"] = {k: apk[k] for k in ("kernel", "value", "ms_per_sweep", "sweeps")}
+                out["all_pairs_kernel"] = {k: apk[k] for k in ("kernel", "value", "ms_per_sweep")}
             except Exception as e:
                 out["all_pairs_kernel"] = {"value": None, "note": "failed: %r" % (e,)}
             # the other single-GPU BASELINE configurations, one adverse state, and the states a PRODUCTION run sits in (the
             # reference thermalises for ~4e6 sweeps, main.c:15-18, SMC.c:110-126): briefly, after the timed region
             out["other_configs"] = []
             for label, n_, r_, lat_, sw_, eq_ in (
-                    ("config 3 equilibrated: the timed workload after 2000 sweeps", 4096, 4096, (8, 16), 20, 2000),
-                    ("config 2: N=1024 + wall, 1024 replicas", 1024, 1024, (8, 4), 40, 0),
-                    ("config 5 per GPU: N=16384 + wall, 256 of 2048 replicas", 16384, 256, (16, 16), 4, 0),
-                    ("config 5 per GPU after 200 sweeps", 16384, 256, (16, 16), 4, 200),
-                    ("adverse for the z-ordered screen: N=4096, 4096 replicas, dense film", 4096, 4096, (16, 4), 5, 0)):
+                    ("config 3 equilibrated", 4096, 4096, (8, 16), 20, 2000),
+                    ("config 2", 1024, 1024, (8, 4), 40, 0),
+                    ("config 5 per GPU", 16384, 256, (16, 16), 4, 0),
+                    ("config 5 per GPU equilibrating", 16384, 256, (16, 16), 4, 200),
+                    ("dense film (adverse)", 4096, 4096, (16, 4), 5, 0)):
                 try:
                     out["other_configs"].append(side_config(S, label, n_, r_, lat_, sw_, local_rank, equilibrate=eq_))
                 except Exception as e:
@@ -561,7 +578,10 @@ def main():
             except Exception as e:  # the baseline leg must never take the GPU number down
                 out["cpu_baseline"] = {"value": None, "unit": "pair-evals/s", "cores": 0, "kind": "port",
                                        "sample": "failed: %r" % (e,)}
-        print(json.dumps(out), flush=True)
+        value_full = out["value"]
+        out = compact(out)
+        out["value"] = value_full
+        print(json.dumps(out, separators=(",", ":")), flush=True)
     eng.close()
     if world > 1:
         dist.barrier()

@@ -226,11 +226,14 @@ int smcx_geometry(const smcx_handle *h, int *slots, int *waves_per_replica, int 
  * if not NULL, receives the kernel's name (at most len bytes) */
 int smcx_kernel_form(const smcx_handle *h, int *form, char *name, int len);
 /* how many replicas the device runs at once with this handle's sweep kernel (workgroups resident per CU x CUs; 0 if unknown
- * for this kernel form).  One launch runs one sweep of every replica and a sweep is sequential inside a replica, so the time
- * per sweep is a step function of nrep / granule: 4097 replicas of N = 4096 cost one full round plus a round of ONE replica
- * on an empty chip (profiles/r04_replica_cliff.txt).  note (optional, len bytes) receives a one-paragraph advisory when nrep
- * is not a multiple of the granule, "" otherwise.  The reference has no counterpart: its MPI ranks are independent processes
- * (SMC.c:40, 66-95); this is the sizing rule of the batched replacement. */
+ * for this kernel form).  A sweep is sequential inside a replica, so a launch of more replicas than that runs in rounds.  Since
+ * round 5 a replica count that is no multiple of the granule no longer costs a nearly empty last round per launch: the sweeps
+ * between two gathers are cut into blocks (one z sort each) and launched as WINDOWS of `granule` (replica, block) units -- the
+ * replicas of a launch sit in different blocks, legal because the chains are independent (the reference's MPI ranks,
+ * SMC.c:40, 66-95) -- so 4097 replicas of N = 4096 cost 1.16 x the time of 4096 (was 1.55 x), 6144 cost 1.63 x (was 1.95 x) at a
+ * gather every 10 sweeps, less with rarer gathers (profiles/r05_replica_cliff.txt).  Results are bit-identical to plain
+ * launches.  note (optional, len bytes) receives a one-paragraph advisory when nrep is not a multiple of the granule, ""
+ * otherwise.  Multiples of the granule remain the most efficient sizes. */
 int smcx_replica_granule(smcx_handle *h, int *granule, char *note, int len);
 /* source identity of a sweep kernel of THIS library (host only, no GPU needed): 16 hex digits, the sha256 of the generated
  * body (hand-scheduled kernels) or of the source files (compiled ones) it was built from.  kernel = a name as

@@ -175,6 +175,11 @@ MG = Z8 and not TT and os.environ.get("SMCX_GEN_NOMERGE") != "1"      # (switch 
 # merged pass (all 64 lanes work for the ONE probe of the wave; wall lanes and side lanes on fixed lanes in front), so a lane
 # with two candidates costs a second hand-over instead of a second pass of the fp64 body (round 3's PF2)
 TL = TT and os.environ.get("SMCX_GEN_TTLIST", "1") != "0"
+# z8t: which slab's wave of team B carries probe B's wall lanes / the side pair (team A's wall lanes: its slab-0 wave).  Round 4's
+# stamps (profiles/r04_two_team_phases.txt) have team B's slab-0 wave, which carried both, the last at the barrier by 280 cycles over
+# its team mates; on separate waves each fits into that slack.
+TT_WALLB = int(os.environ.get("SMCX_GEN_TT_WALLB_SLAB", "0"))
+TT_SIDE = int(os.environ.get("SMCX_GEN_TT_SIDE_SLAB", "0"))
 TTCAP = int(os.environ.get("SMCX_GEN_TTCAP", "63"))       # working lanes of a two-team wave's list (64 = round 4's value: drops items, see tt_assign)
 # "XC" (merged pass, steady copy of the move): the cells that are no neighbours of a probe -- the moving particle n
 # for both, particle n+1 itself for probe B -- keep their candidate bits and travel through the hand-over list like any other; the
@@ -368,7 +373,9 @@ else:
         s_add_u32 {s('Nw')}, {st(6)}, {st(5)}
         s_min_i32 {s('Nw')}, {s('Nw')}, {NS * 64}
         {f"s_and_b32 {st(0)}, {WAVE}, {KS - 1}" if TT else ""}
-        {"" if MG else f"s_cmp_eq_u32 {st(0) if TT else WAVE}, 0"}
+        {f"s_cmp_ge_u32 {WAVE}, {KS}" if TT else ""}
+        {f"s_cselect_b32 {st(4)}, {TT_WALLB}, 0" if TT else ""}
+        {"" if MG else f"s_cmp_eq_u32 {st(0) if TT else WAVE}, {st(4) if TT else 0}"}
         {"" if MG else f"s_cselect_b32 {s('M2w')}, {s('M2')}, -1"}
         s_mul_i32 {st(0)}, {WAVE}, {LDS_WAVE}
         v_mov_b32 v1, {st(0)}
@@ -3585,7 +3592,7 @@ if TL:
 G(f"""
 s_mov_b32 {s('hasA')}, 1
 {f"s_and_b32 {st(0)}, {WAVE}, {KS - 1}" if TT else ""}
-{f"s_cmp_eq_u32 {st(0) if TT else WAVE}, 0" if (W4 and not MG) else ""}
+{f"s_cmp_eq_u32 {st(0) if TT else WAVE}, {TT_SIDE if TT else 0}" if (W4 and not MG) else ""}
 {f"s_cselect_b32 {s('hasAw')}, 1, 0" if (W4 and not MG) else ""}
 """)
 E(f"""

@@ -42,6 +42,32 @@ def kind(l):
 
 
 KINDS = ["valu", "valu_f64", "salu", "branch", "lds", "vmem", "smem", "wait/nop"]
+# issue cost per wave-instruction at four wavefronts per SIMD, measured INSIDE this kernel (profiles/r04_instruction_costs_in_kernel.txt:
+# scalar 2.0, fast 32-bit VALU 1.8, slow 32-bit VALU 3.2, fp64 3.4, s_nop 0.44) and, for v_rcp_f64, in isolation (r02_issue_costs.txt: 8).
+# Fast 32-bit forms (r02_issue_costs.txt): add/sub/mul/fma(c)_f32, mov, and/or/xor, add/sub_u32, lshr/ashr -- with VGPR or inline
+# sources only; any SGPR or literal source, and every other opcode (dot4, alignbit, mad, bfe, perm, cvt, cmp, cndmask with an
+# SGPR mask, DPP, lane reads, ffbl, mbcnt, med3, min/max ...) is a slow form.
+FAST = ("v_add_f32", "v_sub_f32", "v_mul_f32", "v_fma_f32", "v_fmac_f32", "v_mov_b32", "v_and_b32", "v_or_b32", "v_xor_b32",
+        "v_add_u32", "v_sub_u32", "v_subrev_u32", "v_lshrrev_b32", "v_ashrrev_i32")
+COST = {"fast": 1.8, "slow": 3.2, "valu_f64": 3.4, "rcp_f64": 8.0, "salu": 2.0, "branch": 2.0, "lds": 2.0, "vmem": 2.0, "smem": 2.0, "nop": 0.44}
+
+
+def cost(l):
+    k = kind(l)
+    if k is None:
+        return 0.0, None
+    op = l.split()[0]
+    if k == "valu":
+        ops = l[len(op):]
+        sgpr = re.search(r"(?<![\w\[])s\d+|s\[\d+:\d+\]|vcc|exec|0x[0-9a-f]{3,}", ops) is not None
+        dpp = "row_" in l or "quad_perm" in l
+        c = "fast" if (op in FAST and not sgpr and not dpp) else "slow"
+        return COST[c], c
+    if k == "valu_f64":
+        return (COST["rcp_f64"], "rcp_f64") if op == "v_rcp_f64" else (COST["valu_f64"], "valu_f64")
+    if k == "wait/nop":
+        return COST["nop"], "nop"
+    return COST[k], k
 
 
 def count(a, b):
@@ -86,3 +112,20 @@ for name, a, b, w in phases:
         tot[k] += c[k] * w
     wsum += n * w
 print("%-64s" % "per move, weighted with the executed fractions" + "".join("%9.1f" % tot[k] for k in KINDS) + "%9s%10.1f" % ("", wsum))
+# the same main line priced at the measured issue costs: SIMD cycles per move, by cost class
+cyc = {}
+cnt = {}
+for name, a, b, w in phases:
+    for l in lines[a:b]:
+        c, cl = cost(l)
+        if cl:
+            cyc[cl] = cyc.get(cl, 0.0) + c * w
+            cnt[cl] = cnt.get(cl, 0.0) + w
+print()
+print("priced at the issue costs measured in this kernel (SIMD cycles per wave-instruction; four wavefronts per SIMD issue ONE instruction at a time):")
+for cl in ("fast", "slow", "valu_f64", "rcp_f64", "salu", "branch", "lds", "vmem", "smem", "nop"):
+    if cl in cnt:
+        print("   %-10s %7.1f instructions x %4.2f = %7.1f cycles" % (cl, cnt[cl], COST[cl], cyc[cl]))
+print("   sum %.0f SIMD cycles per move (static main line, executed fractions as above; cold pieces -- second hand-over 15 %% of the probes, "
+      "near-wall passes, further rounds -- not included)" % sum(cyc.values()))
+print("   32-bit VALU: %.1f fast + %.1f slow forms (the PMC classes cannot split them: this is the split behind the line's bracket)" % (cnt.get("fast", 0), cnt.get("slow", 0)))
