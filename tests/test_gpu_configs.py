@@ -310,6 +310,21 @@ def test_last_particle_in_the_top_corner_cell(S, O, N, lat, slots, waves, kernel
     assert np.all(rel(ob["E_last"], Erec, 1.0) < TOL.INCREMENTAL)
 
 
+def test_incremental_energy_equals_recomputed_energy_over_long_runs_of_every_kernel_family():
+    """tools/soak_energy.py --quick: twelve cases (mc64 into the walls, ml16, mc16 ragged, mc32, mb64, mc32x4, mt64x8, mc64x4,
+    mc32x8, a dense gas in a small box, no walls, a replica count that runs as windows of units), 60-800 sweeps each in chunks:
+    after every chunk the energy carried along the chain (SMC.c:340-341) equals the energy recomputed from the positions
+    (SMC.c:626-646, 822-859) to 1e-9 relative for EVERY replica.  The invariant that found the z sort's bug in round 5; the full
+    length (3000 sweeps at 4096 x 4096, 4.2e7 replica-sweeps in all: worst 6e-13) is profiles/r05_soak_energy.txt."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "soak_energy.py"), "--quick"], capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stderr[-1500:]
+    rows = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(rows) == 13 and rows[-1]["ok"], rows[-1]
+    for row in rows[:-1]:
+        assert row["kernel"] == row["expected_kernel"], row
+        assert row["count_beyond_1e-9"] == 0 and row["max_relative_incremental_minus_recomputed"] < TOL.INCREMENTAL, row
+
+
 # ------------------------------------------------------------------ BASELINE config 2: N = 1024 x 1024
 def test_config2_N1024_x1024(S, O):
     """BASELINE configs[1] at its real replica count: N=1024 + wall, 1024 replicas on one GPU.
