@@ -100,14 +100,14 @@ def issue_roofline(kname, sweep_ms_per_sweep, nrep, N, clock_ghz, start=None):
     out = {"bound": "valu_issue", "achieved": achieved, "peak": peak, "unit": "G SIMD-cycles/s of VALU issue",
            "frac": achieved / peak,
            # all executed instructions at the per-kind costs measured inside this kernel, 32-bit VALU all-fast .. all-slow
-           "frac_all_instruction_kinds_at_measured_costs_range": [all_lo * wave_moves_per_s / 1e9 / peak,
+           "frac_all_kinds": [all_lo * wave_moves_per_s / 1e9 / peak,
                                                                   all_hi * wave_moves_per_s / 1e9 / peak],
-           "wave_instr_per_move_all_kinds": m["SQ_INSTS_VALU"] + other,
+           "instr_per_move": m["SQ_INSTS_VALU"] + other,
            "clock_ghz": clock_ghz, "waves_per_replica": wpr,
            "valu_per_move": m["SQ_INSTS_VALU"], "fp64_per_move": f64, "fp64_trans_per_move": tr,
            "salu_per_move": m.get("SQ_INSTS_SALU"), "branch_per_move": m.get("SQ_INSTS_BRANCH"), "lds_per_move": m.get("SQ_INSTS_LDS"),
            "vmem_per_move": (m.get("SQ_INSTS_VMEM_RD") or 0) + (m.get("SQ_INSTS_VMEM_WR") or 0),
-           "simd_cycles_per_wave_move": peak * 1e9 / wave_moves_per_s,
+           "cycles_per_move": peak * 1e9 / wave_moves_per_s,
            "wait_any_frac": kc.get("wait_any_frac"), "wait_inst_any_frac": kc.get("wait_inst_any_frac")}
     hb = kc.get("hbm_bytes_per_sweep")
     if hb:
@@ -177,13 +177,13 @@ def executed_work(kname, N, lattice, slots, waves, device, nrep=64, sweeps=2, st
     if d["name"] != kname:
         return {"note": "diagnostic build ran %s, not %s" % (d["name"], kname)}
     moves = float(nrep) * sweeps * N
-    return {"groups_screened_per_pass": d["groups"] / max(d["passes"], 1), "groups_per_wavefront": slots // 4,
+    return {"groups_per_pass": d["groups"] / max(d["passes"], 1), "groups_per_wavefront": slots // 4,
             "wavefronts_per_replica": waves, "passes_per_move": d["passes"] / moves,
-            "cells_screened_per_move": d["groups"] * 256.0 / moves, "cells_per_move_all_pairs": 2.0 * (N - 1),
-            "fraction_of_all_pairs_screened": d["groups"] * 256.0 / moves / (2.0 * (N - 1)),
-            "candidate_bits_per_probe": d["cand"] / (2.0 * moves), "pairs_inside_cutoff_per_probe": d["inside"] / (2.0 * moves),
-            "pairs_inside_cutoff_missed": d["miss"], "handed_over_without_working_lane": d.get("unworked", 0),
-            "further_rounds_per_probe": d.get("more_rounds", 0) / (2.0 * moves),
+            "cells_per_move": d["groups"] * 256.0 / moves, "cells_per_move_all_pairs": 2.0 * (N - 1),
+            "fraction_screened": d["groups"] * 256.0 / moves / (2.0 * (N - 1)),
+            "candidate_bits": d["cand"] / (2.0 * moves), "pairs_in_cutoff": d["inside"] / (2.0 * moves),
+            "missed": d["miss"], "unworked": d.get("unworked", 0),
+            "further_rounds": d.get("more_rounds", 0) / (2.0 * moves),
             "sample": "%d replicas x %d sweeps" % (nrep, sweeps)}
 
 
@@ -302,12 +302,12 @@ def compact(o, digits=5):
     return o
 
 
-SIDE_ROOFLINE_KEYS = ("bound", "frac", "frac_all_instruction_kinds_at_measured_costs_range", "clock_ghz", "valu_per_move", "fp64_per_move",
-                      "salu_per_move", "branch_per_move", "wave_instr_per_move_all_kinds", "simd_cycles_per_wave_move", "wait_any_frac",
+SIDE_ROOFLINE_KEYS = ("frac", "frac_all_kinds", "valu_per_move", "fp64_per_move",
+                      "salu_per_move", "branch_per_move", "instr_per_move", "cycles_per_move", "wait_any_frac",
                       "wait_inst_any_frac", "note")
-SIDE_EXECUTED_KEYS = ("groups_screened_per_pass", "groups_per_wavefront", "cells_screened_per_move", "candidate_bits_per_probe",
-                      "pairs_inside_cutoff_per_probe", "pairs_inside_cutoff_missed", "handed_over_without_working_lane",
-                      "further_rounds_per_probe", "note")
+SIDE_EXECUTED_KEYS = ("groups_per_pass", "cells_per_move", "candidate_bits",
+                      "pairs_in_cutoff", "missed", "unworked",
+                      "further_rounds", "note")
 
 
 def z_profile_width(ob, p):
@@ -541,7 +541,7 @@ def main():
             eng.close()
             progress("executed-work counters (diagnostic build)")
             ex = executed_work(kname, N, lattice, S_, W_, local_rank, nrep=64 if N <= 4096 else 8)
-            out["executed"] = {k: ex[k] for k in SIDE_EXECUTED_KEYS + ("fraction_of_all_pairs_screened", "sample") if k in ex}
+            out["executed"] = {k: ex[k] for k in SIDE_EXECUTED_KEYS + ("fraction_screened", "sample") if k in ex}
         if world == 1 and not a.no_cpu and N == 4096:
             # the like-for-like kernel: the same workload through sweep_kernel_ma64, whose screen visits EVERY cell for
             # every probe as the reference's loops do (SMC.c:563-578, 597-612)

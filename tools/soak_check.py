@@ -17,7 +17,8 @@ os.environ["SMCX_LIB"] = os.path.join(ROOT, "montecarlo-surfacer_amd", "libsmcx_
 os.environ["SMCX_CHECK_MB"] = "2"
 spec = importlib.util.spec_from_file_location("smcx_chk", os.path.join(ROOT, "montecarlo-surfacer_amd", "__init__.py"))
 K = importlib.util.module_from_spec(spec); spec.loader.exec_module(K)
-SCALE = int(sys.argv[1]) if len(sys.argv) > 1 else 1     # replicas x SCALE
+LONG = "long" in sys.argv                                 # round 5: thousands of sweeps, into the walls (the states production runs sit in)
+SCALE = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 1     # replicas x SCALE
 CASES = [  # N, lattice, replicas, thermalisation sweeps (at 2A), production sweeps, gather lapse, slots, waves
     (4096, (8, 16), 128, 10, 30, 10, 64, 1),     # the benchmark's kernel, config 3's start
     (4096, (16, 4), 32, 5, 10, 5, 64, 1),        # dense film
@@ -35,6 +36,14 @@ CASES = [  # N, lattice, replicas, thermalisation sweeps (at 2A), production swe
     (8192, (16, 8), 8, 4, 8, 4, 32, 4),          # 4096 < N <= 8192
     (4800, (10, 12), 8, 6, 12, 4, 32, 4),
 ]
+if LONG:
+    CASES = [
+        (4096, (8, 16), 64, 0, 2500, 100, 64, 1),    # the benchmark's kernel until the gas fills the box and sits at both walls
+        (1024, (8, 4), 128, 0, 3000, 100, 16, 1),    # ml16
+        (2048, (8, 8), 64, 0, 2000, 100, 32, 1),     # mc32
+        (16384, (16, 16), 8, 0, 300, 50, 64, 8),     # two teams while the slab evaporates
+        (6144, (16, 6), 8, 0, 600, 50, 32, 4),       # mc32x4
+    ]
 bad = 0
 for N, lat, nrep, eq, nsw, gl, slots, waves in CASES:
     nrep *= SCALE
