@@ -103,6 +103,11 @@ def issue_roofline(kname, sweep_ms_per_sweep, nrep, N, clock_ghz, start=None):
            "frac_all_kinds": [all_lo * wave_moves_per_s / 1e9 / peak,
                                                                   all_hi * wave_moves_per_s / 1e9 / peak],
            "instr_per_move": m["SQ_INSTS_VALU"] + other,
+           # the same with the 32-bit VALU split into fast and slow forms by opcode (static count of the generated steady copy,
+           # tools/phase_table.py; only where the committed counters carry that split): ONE number instead of the bracket
+           "frac_all_kinds_point": (((b32 * (kc["valu32_fast_fraction_static"] * 1.8 + (1.0 - kc["valu32_fast_fraction_static"]) * 3.2)
+                                     + f64 * 3.4 + tr * 8.0 + other * 2.0) * wave_moves_per_s / 1e9 / peak)
+                                    if kc.get("valu32_fast_fraction_static") else None),
            "clock_ghz": clock_ghz, "waves_per_replica": wpr,
            "valu_per_move": m["SQ_INSTS_VALU"], "fp64_per_move": f64, "fp64_trans_per_move": tr,
            "salu_per_move": m.get("SQ_INSTS_SALU"), "branch_per_move": m.get("SQ_INSTS_BRANCH"), "lds_per_move": m.get("SQ_INSTS_LDS"),
@@ -302,7 +307,7 @@ def compact(o, digits=5):
     return o
 
 
-SIDE_ROOFLINE_KEYS = ("frac", "frac_all_kinds", "valu_per_move", "fp64_per_move",
+SIDE_ROOFLINE_KEYS = ("frac", "frac_all_kinds", "frac_all_kinds_point", "valu_per_move", "fp64_per_move",
                       "salu_per_move", "branch_per_move", "instr_per_move", "cycles_per_move", "wait_any_frac",
                       "wait_inst_any_frac", "note")
 SIDE_EXECUTED_KEYS = ("groups_per_pass", "cells_per_move", "candidate_bits",

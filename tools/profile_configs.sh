@@ -1,6 +1,6 @@
 #!/bin/bash
 # PMC instruction mix, activity and HBM counters of the sweep kernel of BASELINE configs 3, 2 and 5 (per-GPU share):
-#   tools/profile_configs.sh <tag>      (through gpurun, from the repo root; 20 rocprofv3 --pmc passes, counters only)
+#   tools/profile_configs.sh <tag>      (through gpurun, from the repo root; 30 rocprofv3 --pmc passes, counters only)
 # Writes gpurun_out/prof_<tag>_c{3,2,5}/ and merges the three kernel_counters.json into
 # gpurun_out/kernel_counters_<tag>.json (copy to profiles/kernel_counters.json to make bench.py use it).
 set -e
@@ -28,6 +28,19 @@ for c in ("c3", "c2", "c5", "dense", "c3eq", "c5eq"):
             tag, "config " + c[1] if c != "dense" else "dense film")
         v["workload"]["start"] = START[c]
         out[k if c in ("c3", "c2", "c5") else k + "@" + START[c]] = v
+# the opcode-level split of the 32-bit VALU instructions of sweep_kernel_mc64 (fast / slow issue forms), from the generated body
+try:
+    import re, subprocess
+    txt = subprocess.run([sys.executable, "tools/phase_table.py", "montecarlo-surfacer_amd/csrc/build/smcx_sweep_mc_body64.inc"],
+                         capture_output=True, text=True).stdout
+    m = re.search(r"32-bit VALU: ([\d.]+) fast \+ ([\d.]+) slow", txt)
+    fast, slow = float(m.group(1)), float(m.group(2))
+    for k, v in out.items():
+        if k.startswith("smcx::sweep_kernel_mc64"):
+            v["valu32_fast_fraction_static"] = round(fast / (fast + slow), 4)
+            v["valu32_fast_fraction_source"] = "tools/phase_table.py over the generated steady copy: %.1f fast + %.1f slow 32-bit VALU forms per move" % (fast, slow)
+except Exception as ex:
+    print("no static fast/slow split:", ex)
 json.dump(out, open("gpurun_out/kernel_counters_%s.json" % tag, "w"), indent=1, sort_keys=True)
 print("kernels:", sorted(out))
 PY
