@@ -66,6 +66,24 @@ def _state(O, case):
         R[::131, 2] += 300.0          # 31 particles between 267 and 333
         R[7::400, 2] = 264.5 + 0.3 * np.arange(len(R[7::400]))          # ten just beyond zsafe, within the cutoff of each other
         return _wrap(R, L).ravel(), L, Lz, "nowalls", case[-4:], {"tune_kernel": S_KERNEL[case[-4:]]}
+    if case in ("unsafe_z_mc32x4", "unsafe_z_mt64x8"):
+        # Round 5: the several-wavefront byte-screen kernels have an unsafe z range INSIDE boxes they serve: zsafe = 32766 L/256 =
+        # 128 L, the upload bound is |z| <= 4 Lz, and they are planned up to Lz < 250 L -- a narrow tall box (L = 12, Lz = 1200:
+        # zsafe = 1536; L = 24, Lz = 2400: 3072) holds particles beyond it.  (The ONE-wavefront mc kernels cannot get there: their
+        # plan needs sweep_kernel_ma's standard z unit below them, i.e. Lz < ~16 L, so 4 Lz < zsafe -- checked on the GPU: at
+        # Lz = 55 L the plan gives sweep_kernel_mi, at 100 L sweep_kernel_mx.)  A film fcc(Na, 96 | 64), no walls, ~60-170 particles
+        # 100-300 beyond zsafe and ten just beyond it within the cutoff of each other: unsafe particles are always candidates, an
+        # unsafe probe tests every real cell of every wave, the cells' z words and the groups' ranges hold clamped values.
+        Na, Nz, kern = {"unsafe_z_mc32x4": (4, 96, "mc32x4"), "unsafe_z_mt64x8": (8, 64, "mt64x8")}[case]
+        L = 3.0 * Na
+        Lz, zs = 100.0 * L, 128.0 * L
+        R = O.fcc(Na, Nz, L=L, Lz=Lz).reshape(-1, 3).copy()
+        R += 0.05 * rs.standard_normal(R.shape)
+        far = R[::131]
+        R[::131, 2] = zs + 100.0 + 3.0 * np.arange(len(far))
+        R[7::400, 2] = zs + 1.0 + 0.3 * np.arange(len(R[7::400]))
+        assert (np.abs(R[:, 2]) > zs).sum() > 40 and np.abs(R[:, 2]).max() < 4 * Lz
+        return _wrap(R, L).ravel(), L, Lz, "nowalls", kern, {}
     if case == "resort_3":            # three sweeps per z sort: group ranges widened by two sweeps of accepted moves
         L, Lz = 33.0, 240.0
         return O.fcc(8, 16, L=L), L, Lz, None, "mc64", {"tune_resort": 3}
@@ -123,6 +141,8 @@ def _tt_state(O, case):
     if case == "mt64x8_two_slabs":
         R0, L, Lz, mode, _, extra = _state(O, "mc64x4_two_slabs")
         return R0, L, Lz, mode, "mt64x8", extra
+    if case == "mt64x8_unsafe_z":
+        return _state(O, "unsafe_z_mt64x8")
     if case in ("mt64x8_condensed", "mt64x8_condensed_no_walls", "mt64x8_overfull", "mt64x8_overfull_no_walls"):
         # Round 5: a CONDENSED state, which is what a thermalised film becomes.  fcc(16,16) with the lattice
         # constant of the Lennard-Jones crystal (a = 1.6, rho = 0.98: L = 25.6; ~160 candidate bits per probe, 40 per wavefront)
@@ -148,9 +168,9 @@ def _tt_state(O, case):
 
 
 TT_CASES = ["ml16_benchmark", "ml16_ragged_no_walls", "ml16_at_wall", "mt64x8_benchmark", "mt64x8_two_slabs", "mt64x8_at_wall",
-            "mt64x8_condensed", "mt64x8_condensed_no_walls", "mt64x8_overfull", "mt64x8_overfull_no_walls"]
+            "mt64x8_condensed", "mt64x8_condensed_no_walls", "mt64x8_overfull", "mt64x8_overfull_no_walls", "mt64x8_unsafe_z"]
 
-CASES = ["dense_film", "dense_film_at_wall", "thin_film", "two_slabs_ragged", "unsafe_z_mb64", "unsafe_z_ma64", "resort_3", "mc16_dense",
+CASES = ["dense_film", "dense_film_at_wall", "thin_film", "two_slabs_ragged", "unsafe_z_mb64", "unsafe_z_ma64", "unsafe_z_mc32x4", "resort_3", "mc16_dense",
          "ml16_dense", "mc32_two_slabs", "mc32x4_dense", "mc64x4_two_slabs"]
 
 
