@@ -874,6 +874,47 @@ def test_ragged_sizes_with_padding(S, O, N):
     eng.close()
 
 
+@pytest.mark.parametrize("N,lat,kw,kernel", [
+    (4096, (8, 16), dict(cutoff=2.5, T=0.9, A=0.5, a0=2.0e-8, b0=4.0e-5, Ncx=20, Ncz=50), "mc64"),
+    (1024, (8, 4), dict(cutoff=3.5, T=1.4, A=2.0, Ncx=33, Ncz=17), "ml16"),
+    (16384, (16, 16), dict(cutoff=2.2, T=2.0, A=0.05, a0=1.0e-8, b0=1.0e-5, tune_slots=64, tune_waves=8), "mt64x8"),
+    (6144, (16, 6), dict(cutoff=2.6, T=1.0, A=0.3), "mc32x4"),
+    (256, (4, 4), dict(cutoff=4.0, T=0.7, A=1.5, L=20.0, Lz=100.0, Ncx=12, Ncz=40), None),
+])
+def test_runtime_parameters_other_than_the_references_macros(S, O, N, lat, kw, kernel):
+    """What the reference fixes at compile time (SMC.h:26-58: LJ_CUTOFF, a0, b0, Ncx, Ncz; main.c:18, 48-51: T, gamma) are run-time
+    fields of smcx_params.  Every other test runs the reference's values; here cutoff, temperature, step size, plane
+    coefficients, cell counts and (last case) the box differ: the screens' thresholds, the groups' reach, the near-wall bound and
+    the histogram must all follow.  Two sweeps with a gather before each against the oracle built with the same numbers."""
+    rs = np.random.RandomState(N)
+    L, Lz = kw.get("L", 33.0), kw.get("Lz", 240.0)
+    R0 = O.fcc(lat[0], lat[1], L=L, Lz=Lz).reshape(-1, 3).copy()
+    R0 += 0.05 * rs.standard_normal(R0.shape)
+    R0[:, 2] += -(Lz / 2 - 1.3) - R0[:, 2].min()          # the film against the lower wall: sites and plane act
+    R0[:, 0] -= L * np.rint(R0[:, 0] / L); R0[:, 1] -= L * np.rint(R0[:, 1] / L)
+    R0 = R0.ravel()
+    nrep, nsw = 3, 2
+    p = S.default_params(N, nrep, flags=S.FLAGS_REFERENCE | S.FLAG_SERIES, **kw)
+    with S.Engine(p) as eng:
+        if kernel:
+            assert eng.kernel_form[1] == "smcx::sweep_kernel_" + kernel, eng.kernel_form
+        eng.upload(R0, O.W_FIXTURE)
+        E0 = eng.total_energy()
+        eng.run(0, nsw, 1)
+        Es, jj = eng.series(nsw)
+        ob = eng.observables()
+        Rg = eng.positions()
+    s = sys_of(O, p)
+    assert s.cutoff == kw["cutoff"] and s.Ncz == p.Ncz
+    for r in range(nrep):
+        ref = O.chain(s, 12345 + r, R0, O.W_FIXTURE, p.T, p.A, 0, nsw, 1)
+        assert np.array_equal(jj[r], ref["jj"]) and ref["jj"].sum() > 0, (r, jj[r], ref["jj"])
+        TOL.assert_energy(E0[r], ref["E"][0], 0)
+        TOL.assert_series(Es[r], ref["E"], what="replica %d" % r)
+        TOL.assert_positions(Rg[r], ref["R"], nsw)
+        assert np.array_equal(ob["zhist"][r], ref["zhist"]) and len(ref["zhist"]) == p.Ncz
+
+
 def test_upload_rejects_unwrapped_positions(S, O):
     R0 = O.fcc(4, 4)
     R0[0] = 20.0  # outside [-L/2, L/2]
