@@ -180,7 +180,18 @@ TL = TT and os.environ.get("SMCX_GEN_TTLIST", "1") != "0"
 # its team mates; on separate waves each fits into that slack.
 TT_WALLB = int(os.environ.get("SMCX_GEN_TT_WALLB_SLAB", "0"))
 TT_SIDE = int(os.environ.get("SMCX_GEN_TT_SIDE_SLAB", "0"))
-TTCAP = int(os.environ.get("SMCX_GEN_TTCAP", "63"))       # working lanes of a two-team wave's list (64 = round 4's value: drops items, see tt_assign)
+TTCAP = int(os.environ.get("SMCX_GEN_TTCAP", "63"))
+# round 5, the one-wavefront merged kernels (mc64/32/16, ml16): five small trims of the steady move, built, correct (192 GPU tests) and
+# NOT adopted (switch SMCX_GEN_TRIM5=1 builds them) -- the accept path's energy update by one fma + two lane reads (was 7
+# instructions), its position registers by three 64-bit moves (6), the unsafe-z bit update behind a "some particle is unsafe" flag
+# in s100 (8 -> 2), the group range with RZ in place, the log-uniform's load with register + immediate offset: 424 -> 417
+# instructions per move on the main line, predicted -1.8 %; measured (profiles/r05_trim5_ab.txt, A/B/A/B/A/B in one session)
+# config 3 8.611 -> 8.577 ms per sweep (-0.4 %) and config 2 1.203 -> 1.221 (+1.4 %: its lone wavefront pays for the longer
+# dependent chain of the one-instruction energy update).  The accept path is not where the issue port is short of slots.
+# (A build with the switch on must also list "s100" among the clobbers of sweep_kernel_mc64/32/16/ml16 in smcx_sweep_ma.hip.)
+TRIM5 = os.environ.get("SMCX_GEN_TRIM5", "0") == "1"
+T5 = TRIM5 and MG and not W4
+ANYU = "s100"      # T5: 1 while some cell of this replica carries the unsafe-z bit (set where the cells are built and on acceptance)       # working lanes of a two-team wave's list (64 = round 4's value: drops items, see tt_assign)
 # "XC" (merged pass, steady copy of the move): the cells that are no neighbours of a probe -- the moving particle n
 # for both, particle n+1 itself for probe B -- keep their candidate bits and travel through the hand-over list like any other; the
 # working lane that reads one of them as its item is taken out of the pass by a compare of the item with the cell (4 instructions
@@ -758,6 +769,14 @@ s_cmp_lt_u32 {st(0)}, {NS}
 s_cbranch_scc1 L_init
 s_waitcnt lgkmcnt(0)
 """)
+if T5:   # some cell of this replica beyond the safe z range?
+    E(f"""
+    v_or_b32 v14, {v('uns0')}, {v('uns1')}
+    v_cmp_ne_u32 vcc, 0, v14
+    s_nop 1
+    s_cmp_lg_u64 vcc, 0
+    s_cselect_b32 {ANYU}, 1, 0
+    """)
 if ZB:
     # lane g < NG: (lowest z - RZ, highest z + RZ) of group g; an empty group and the other lanes: never reached
     E(f"""
@@ -2934,10 +2953,17 @@ if MG:
     s_cmp_eq_u32 {s('hasB')}, 0
     s_cbranch_scc1 L_nolu
     """)
-    E(f"""
+    (G if (T5 and PEEL) else E)(f"""
     s_add_u32 {st(1)}, {s('i')}, 1
     s_lshl_b32 {st(0)}, {st(1)}, 3
     s_load_dwordx2 {sp('nxy')}, {sp('uK')}, {st(0)}
+    """)
+    if T5 and PEEL:   # steady copy (i >= 0): register + immediate offset
+        SO(f"""
+        s_lshl_b32 {st(0)}, {s('i')}, 3
+        s_load_dwordx2 {sp('nxy')}, {sp('uK')}, {st(0)} offset:8
+        """)
+    E(f"""
     L_nolu:
     s_or_b32 {st(0)}, {s('nearA')}, {s('nearB')}
     s_cbranch_scc1 L_mgN
@@ -3250,13 +3276,14 @@ MUTE[0] = False
 E(f"""
 // accepted: E += Un - Um = 4 (eA - eB) (row 0 of g; mg: the e group, lane 0 either way), particle n takes the proposal
 {f"s_mov_b32 {s('accf')}, 1" if (TT or MG) else ""}
-v_readlane_b32 {st(0)}, {v('D',0)}, 0
-v_readlane_b32 {st(1)}, {v('D',1)}, 0
+{"" if T5 else f"v_readlane_b32 {st(0)}, {v('D',0)}, 0"}
+{"" if T5 else f"v_readlane_b32 {st(1)}, {v('D',1)}, 0"}
+{f"v_fma_f64 {vp('T')}, {vp('D',0)}, 4.0, {sp('E')}" if T5 else ""}
 s_add_u32 {s('jacc')}, {s('jacc')}, 1
-s_nop 0
-v_mov_b32 {v('T')}, {st(0)}
-v_mov_b32 {v('T',1)}, {st(1)}
-v_fma_f64 {vp('T')}, {vp('T')}, 4.0, {sp('E')}
+{"" if T5 else "s_nop 0"}
+{"" if T5 else f"v_mov_b32 {v('T')}, {st(0)}"}
+{"" if T5 else f"v_mov_b32 {v('T',1)}, {st(1)}"}
+{"" if T5 else f"v_fma_f64 {vp('T')}, {vp('T')}, 4.0, {sp('E')}"}
 s_lshl_b64 {stp(0)}, 1, {s('tl')}
 s_add_u32 {st(2)}, {s('first')}, {s('i')}
 {"" if ZB else f"s_mul_i32 {st(2)}, {st(2)}, 24"}
@@ -3293,12 +3320,12 @@ else:
     E(f"""
     {f"s_and_b32 {st(3)}, {s('locA')}, {NS * 64 - 1}" if W4 else ""}
     s_mov_b64 exec, {stp(0)}
-    v_mov_b32 v50, {s('Q',0)}
-    v_mov_b32 v51, {s('Q',1)}
-    v_mov_b32 v52, {s('Q',2)}
-    v_mov_b32 v53, {s('Q',3)}
-    v_mov_b32 v54, {s('Q',4)}
-    v_mov_b32 v55, {s('Q',5)}
+    {f"v_mov_b64 v[50:51], {sp('Q',0)}" if T5 else f"v_mov_b32 v50, {s('Q',0)}"}
+    {f"v_mov_b64 v[52:53], {sp('Q',1)}" if T5 else f"v_mov_b32 v51, {s('Q',1)}"}
+    {f"v_mov_b64 v[54:55], {sp('Q',2)}" if T5 else f"v_mov_b32 v52, {s('Q',2)}"}
+    {"" if T5 else f"v_mov_b32 v53, {s('Q',3)}"}
+    {"" if T5 else f"v_mov_b32 v54, {s('Q',4)}"}
+    {"" if T5 else f"v_mov_b32 v55, {s('Q',5)}"}
     v_mad_u32_u24 {v('T',1)}, {st(2)}, 24, 0
     v_mad_u32_u24 {v('T')}, {st(3) if W4 else s('locA')}, 24, 0
     {f"v_mad_u32_u24 {v('S6')}, {LANE}, 24, v1" if W4 else f"v_mul_u32_u24 {v('S6')}, 24, {LANE}"}
@@ -3323,6 +3350,8 @@ else:
     {f"ds_write_b64 {v('T')}, v[54:55] offset:{LDS_RS + 16}" if LP else ""}
     {f"s_bfe_u32 {st(1)}, {s('locA')}, {SLOTF}" if W4 else f"s_lshr_b32 {st(1)}, {s('locA')}, 6"}
     s_lshl_b64 {stp(2)}, 1, {s('locA')}
+    """)
+    uns = f"""
     s_lshl_b64 {stp(4)}, 1, {st(1)}
     s_not_b64 {stp(6)}, {stp(4)}
     s_cmp_eq_u32 {s('ua')}, 0
@@ -3336,7 +3365,26 @@ else:
     s_set_gpr_idx_off
     v_or_b32 {v('uns0')}, {st(4)}, {v('uns0')}
     v_or_b32 {v('uns1')}, {st(5)}, {v('uns1')}
-""")
+    """
+    if T5:   # the unsafe-z bit of the cell changes only if the proposal is unsafe or some cell already is: cold piece
+        E(f"""
+        s_or_b32 {st(4)}, {s('ua')}, {ANYU}
+        s_cbranch_scc1 L_unsC
+        s_mov_b64 exec, {stp(2)}
+        v_mov_b32 {v('T')}, {s('axys')}
+        s_set_gpr_idx_on {st(1)}, gpr_idx(DST)
+        v_mov_b32 {xy(0)}, {v('T')}
+        s_set_gpr_idx_off
+        L_unsR:
+        """)
+        COLD(f"""
+        L_unsC:
+        s_mov_b32 {ANYU}, 1
+        {uns}
+        s_branch L_unsR
+        """)
+    else:
+        E(uns)
     if not Z8:
         E(f"""
         s_lshr_b32 {st(2)}, {st(1)}, 1
@@ -3351,11 +3399,11 @@ else:
     E(f"""
     s_lshr_b32 {st(1)}, {st(1)}, {GSH}
     s_lshl_b64 {stp(2)}, 1, {st(1)}
-    {f"v_readfirstlane_b32 {st(6)}, {KRZ}" if TT else f"s_mov_b32 {st(6)}, {s('RZ')}" if (Z8 and not W4) else f"s_load_dword {st(6)}, {KARG}, {K_RZ}"}
+    {"" if T5 else f"v_readfirstlane_b32 {st(6)}, {KRZ}" if TT else f"s_mov_b32 {st(6)}, {s('RZ')}" if (Z8 and not W4) else f"s_load_dword {st(6)}, {KARG}, {K_RZ}"}
     s_sext_i32_i16 {st(0)}, {s('axys') if Z8 else s('az16')}
     {"" if (TT or (Z8 and not W4)) else "s_waitcnt lgkmcnt(0)"}
-    s_sub_i32 {st(4)}, {st(0)}, {st(6)}
-    s_add_i32 {st(5)}, {st(0)}, {st(6)}
+    s_sub_i32 {st(4)}, {st(0)}, {s('RZ') if T5 else st(6)}
+    s_add_i32 {st(5)}, {st(0)}, {s('RZ') if T5 else st(6)}
     s_mov_b64 exec, {stp(2)}
     v_min_i32 {v('gloR')}, {st(4)}, {v('gloR')}
     v_max_i32 {v('ghiR')}, {st(5)}, {v('ghiR')}
