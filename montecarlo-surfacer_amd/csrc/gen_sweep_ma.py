@@ -191,6 +191,10 @@ TTCAP = int(os.environ.get("SMCX_GEN_TTCAP", "63"))
 # (A build with the switch on must also list "s100" among the clobbers of sweep_kernel_mc64/32/16/ml16 in smcx_sweep_ma.hip.)
 TRIM5 = os.environ.get("SMCX_GEN_TRIM5", "0") == "1"
 T5 = TRIM5 and MG and not W4
+# TIMING experiments only (WRONG results; VARIANT builds): what a phase of the move costs, by leaving it out -- SMCX_GEN_ABL = a
+# comma-separated list of noaccept (every move rejected), nobody (the fp64 body of round 0 jumped over), noscreenA / noscreenB (a probe's
+# screen jumped over: no candidates), nosides (no side pair).  tools/sessions/r05_session17.sh, profiles/r05_ablation_mc64.txt
+ABL = set(x for x in os.environ.get("SMCX_GEN_ABL", "").split(",") if x)
 ANYU = "s100"      # T5: 1 while some cell of this replica carries the unsafe-z bit (set where the cells are built and on acceptance)       # working lanes of a two-team wave's list (64 = round 4's value: drops items, see tt_assign)
 # "XC" (merged pass, steady copy of the move): the cells that are no neighbours of a probe -- the moving particle n
 # for both, particle n+1 itself for probe B -- keep their candidate bits and travel through the hand-over list like any other; the
@@ -1481,7 +1485,7 @@ def screen_ranged8(tag, pws, w0, w1):
     v_cmp_ge_i32 vcc, {st(0)}, {v('gloR')}
     v_cmp_le_i32 {stp(2)}, {st(0)}, {v('ghiR')}
     s_and_b32 {st(1)}, vcc_lo, {st(2)}
-    s_cbranch_scc0 L_sdone_{tag}
+    {"s_branch" if ("noscreen" + tag) in ABL else "s_cbranch_scc0"} L_sdone_{tag}
     s_ff1_i32_b32 {st(4)}, {st(1)}
     s_flbit_i32_b32 {st(5)}, {st(1)}
     {f"s_add_u32 {st(1)}, {st(4)}, {st(5)}" if Z8C else ""}
@@ -2823,6 +2827,8 @@ def mg_round0(near):
     else:   # the candidates' positions; the displacement asked for behind them may still travel
         G("s_waitcnt vmcnt(0)")
         SO("s_waitcnt vmcnt(1)")
+    if "nobody" in ABL and not near:
+        E(f"s_branch L_nolj_{tag}")
     body(tag, PV, XA_, CA_, stp(6), True, wl, pl)
     (E if near else G)(f"""
     s_cmp_eq_u32 {s('sidesHi')}, 0
@@ -3011,7 +3017,7 @@ if MG:
     v_cmp_lt_f64 vcc, {sp('lu')}, {vp('D',2)}
     s_nop 0
     s_bitcmp1_b32 vcc_lo, 31
-    s_cbranch_scc0 L_reject
+    {"s_branch" if "noaccept" in ABL else "s_cbranch_scc0"} L_reject
     """)
 MUTE[0] = MG
 
@@ -3329,11 +3335,11 @@ else:
     v_mad_u32_u24 {v('T',1)}, {st(2)}, 24, 0
     v_mad_u32_u24 {v('T')}, {st(3) if W4 else s('locA')}, 24, 0
     {f"v_mad_u32_u24 {v('S6')}, {LANE}, 24, v1" if W4 else f"v_mul_u32_u24 {v('S6')}, 24, {LANE}"}
-    global_store_dwordx4 {v('T',1)}, v[50:53], {sp('Rg')}{NT}
-    global_store_dwordx2 {v('T',1)}, v[54:55], {sp('Rg')} offset:16{NT}
-    ds_write_b64 {v('S6')}, v[50:51] offset:{LDS_P0}
-    ds_write_b64 {v('S6')}, v[52:53] offset:{LDS_P0 + 8}
-    ds_write_b64 {v('S6')}, v[54:55] offset:{LDS_P0 + 16}
+    {"" if "nostoreR" in ABL else f"global_store_dwordx4 {v('T',1)}, v[50:53], {sp('Rg')}{NT}"}
+    {"" if "nostoreR" in ABL else f"global_store_dwordx2 {v('T',1)}, v[54:55], {sp('Rg')} offset:16{NT}"}
+    {"" if "nop0" in ABL else f"ds_write_b64 {v('S6')}, v[50:51] offset:{LDS_P0}"}
+    {"" if "nop0" in ABL else f"ds_write_b64 {v('S6')}, v[52:53] offset:{LDS_P0 + 8}"}
+    {"" if "nop0" in ABL else f"ds_write_b64 {v('S6')}, v[54:55] offset:{LDS_P0 + 16}"}
     """)
     if W4:   # the cell, its copy in Rs and its group's range belong to one wave
         E(f"""
@@ -3343,8 +3349,8 @@ else:
         s_cbranch_scc1 L_notmine
         """)
     E(f"""
-    global_store_dwordx4 {v('T')}, v[50:53], {sp('Rs')}
-    global_store_dwordx2 {v('T')}, v[54:55], {sp('Rs')} offset:16
+    {"" if "nostoreRs" in ABL else f"global_store_dwordx4 {v('T')}, v[50:53], {sp('Rs')}"}
+    {"" if "nostoreRs" in ABL else f"global_store_dwordx2 {v('T')}, v[54:55], {sp('Rs')} offset:16"}
     {f"ds_write_b64 {v('T')}, v[50:51] offset:{LDS_RS}" if LP else ""}
     {f"ds_write_b64 {v('T')}, v[52:53] offset:{LDS_RS + 8}" if LP else ""}
     {f"ds_write_b64 {v('T')}, v[54:55] offset:{LDS_RS + 16}" if LP else ""}
@@ -3360,9 +3366,9 @@ else:
     v_mov_b32 {v('T')}, {s('axys')}
     v_and_b32 {v('uns0')}, {st(6)}, {v('uns0')}
     v_and_b32 {v('uns1')}, {st(7)}, {v('uns1')}
-    s_set_gpr_idx_on {st(1)}, gpr_idx(DST)
-    v_mov_b32 {xy(0)}, {v('T')}
-    s_set_gpr_idx_off
+    {"" if "nogpridx" in ABL else f"s_set_gpr_idx_on {st(1)}, gpr_idx(DST)"}
+    {"" if "nogpridx" in ABL else f"v_mov_b32 {xy(0)}, {v('T')}"}
+    {"" if "nogpridx" in ABL else "s_set_gpr_idx_off"}
     v_or_b32 {v('uns0')}, {st(4)}, {v('uns0')}
     v_or_b32 {v('uns1')}, {st(5)}, {v('uns1')}
     """
