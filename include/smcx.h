@@ -216,6 +216,13 @@ int smcx_last_clock(smcx_handle *h, double *ghz, double *wave_cycles);
 int smcx_debug_wave_spread(smcx_handle *h, double *out4);
 /* diagnostics: the raw stamps behind smcx_last_clock / smcx_debug_wave_spread, out[nrep][4] */
 int smcx_debug_clk_rows(smcx_handle *h, uint64_t *out);
+/* diagnostics (host only, no GPU needed): the launches a group of `nsweeps` sweeps of `nrep` replicas is cut into when the device
+ * holds `granule` of them at once and a z sort covers `every` sweeps -- plain launches (one per block over all replicas) when
+ * nrep <= granule or nrep is a multiple of it, otherwise windows of `granule` consecutive (replica, block) units
+ * (smcx_replica_granule).  out[k] = {workgroups, first unit u0, nrep or 0, block of the first unit, 1 if a window, first sweep
+ * and sweep count of that block, first sweep and sweep count of the next block}; returns the number of launches (at most max
+ * are written) or a negative status.  What the tests check the schedule's invariants on. */
+int smcx_debug_window_schedule(int nrep, int granule, int nsweeps, int every, int32_t *out /*[max][9]*/, int max);
 /* device time of the whole last smcx_run (RNG pre-pass and bookkeeping kernels included) */
 int smcx_last_run_ms(smcx_handle *h, double *ms);
 /* the launch geometry chosen for this handle */

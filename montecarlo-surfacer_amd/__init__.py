@@ -61,7 +61,7 @@ EXPORTS = [
     "smcx_rng_seed", "smcx_one_particle_moves",
     "smcx_cluster_counts", "smcx_cluster_update", "smcx_cluster_analysis", "smcx_kernel_form", "smcx_screen_bound",
     "smcx_screen_bound_int", "smcx_screen_bound_byte", "smcx_last_clock", "smcx_debug_wave_spread",
-    "smcx_debug_clk_rows", "smcx_kernel_source_id", "smcx_replica_granule",
+    "smcx_debug_clk_rows", "smcx_kernel_source_id", "smcx_replica_granule", "smcx_debug_window_schedule",
 ]
 HOST_EXPORTS = ["smcx_host_sMC", "smcx_host_sMC_multi", "smcx_host_multi_error", "smcx_host_sim_free", "smcx_host_fcc_init",
                 "smcx_host_initialize_box", "smcx_host_initialize_walls", "smcx_host_box_for_N", "smcx_host_write_csv",
@@ -144,6 +144,18 @@ def kernel_source_id(kernel):
     f.argtypes = [C.c_char_p, C.c_char_p, C.c_int]
     f.restype = C.c_int
     return buf.value.decode() if f(kernel.encode(), buf, 32) == OK else None
+
+
+def window_schedule(nrep, granule, nsweeps, every, max_launches=4096):
+    """the launches of one launch group (smcx_debug_window_schedule): rows of (workgroups, u0, nmod, blk0, window, sw0, nsw, sw0', nsw')"""
+    out = np.zeros((max_launches, 9), dtype=np.int32)
+    f = _lib().smcx_debug_window_schedule
+    f.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int32), C.c_int]
+    f.restype = C.c_int
+    n = f(nrep, granule, nsweeps, every, _p(out, C.c_int32), max_launches)
+    if n < 0:
+        raise SmcxError(-n, "smcx_debug_window_schedule")
+    return out[:min(n, max_launches)], n
 
 
 def device_count():

@@ -63,6 +63,41 @@ def test_roofline_refuses_instruction_counts_of_another_build(S, tmp_path, monke
             assert r["frac"] is None and "another build" in r["note"]
 
 
+def test_window_schedule_runs_every_sweep_of_every_replica_once_and_in_order(S):
+    """smcx_debug_window_schedule = the schedule launch_sweeps_* follow (csrc/smcx_sweep_ma.hip: unit_launches).  A launch group of
+    `nsweeps` sweeps is cut into blocks of `every`; with a replica count that is no multiple of what the device holds the group runs
+    as windows of `granule` consecutive (replica, block) units.  Whatever the numbers: every replica runs every sweep exactly once
+    and in order, never twice in one launch (a replica's sweeps are sequential: SMC.c:292-347), no window holds more than
+    `granule` workgroups, and there are ceil(nrep x blocks / granule) of them; multiples of the granule and counts below it keep
+    the plain launches (one per block over all replicas)."""
+    rs = np.random.RandomState(3)
+    cases = [(4097, 4096, 9, 2), (4097, 4096, 1, 2), (6144, 4096, 10, 2), (9000, 4096, 11, 2), (261, 256, 7, 1), (300, 256, 1, 1),
+             (5121, 5120, 16, 2), (4096, 4096, 9, 2), (8192, 4096, 10, 2), (100, 4096, 5, 2), (7, 3, 5, 3), (5, 4, 4, 1)]
+    cases += [(int(rs.randint(1, 3000)), int(rs.randint(1, 700)), int(rs.randint(0, 17)), int(rs.randint(1, 5))) for _ in range(60)]
+    for nrep, G, nsw, every in cases:
+        rows, n = S.window_schedule(nrep, G, nsw, every)
+        assert n == len(rows)
+        nb = (nsw + every - 1) // every
+        windows = nrep > G and nrep % G != 0
+        done = np.zeros(nrep, dtype=np.int64)            # sweeps each replica has run so far
+        for grid, u0, nmod, blk0, use, sa, na, sb, nb_ in rows:
+            assert bool(use) == windows and (nmod == nrep if windows else nmod == 0), (nrep, G, nsw, every)
+            assert grid <= (G if windows else nrep)
+            u = u0 + np.arange(grid)
+            rep = u % nrep if windows else np.arange(grid)
+            blk = u // nrep if windows else np.full(grid, blk0)
+            assert len(np.unique(rep)) == grid                      # never twice in one launch
+            assert np.all((blk == blk0) | (blk == blk0 + 1))
+            sw0 = np.where(blk == blk0, sa, sb); cnt = np.where(blk == blk0, na, nb_)
+            assert np.all(sw0 == blk * every) and np.all(cnt == np.minimum(every, nsw - blk * every)) and np.all(cnt > 0)
+            assert np.all(done[rep] == sw0)                         # in order: this block starts where the replica stands
+            done[rep] += cnt
+        assert np.all(done == nsw), (nrep, G, nsw, every)
+        assert n == (-(-nrep * nb // G) if windows else nb), (nrep, G, nsw, every, n)
+    with pytest.raises(S.SmcxError):
+        S.window_schedule(0, 4096, 4, 2)
+
+
 def test_host_library_exports_every_declared_symbol(S):
     """libsmcx_host.so (plain C above the ABI, incl. the RCCL multi-GPU driver) against include/smcx_host.h"""
     hdr = open(os.path.join(ROOT, "include", "smcx_host.h")).read()
