@@ -14,7 +14,7 @@
 //   finalize_kernel       chain bookkeeping of sMC (SMC.c:194-195, 210-211, 244-250)
 //   hist_kernel           localDensityAndMobility (SMC.c:912-927)
 //   pressure_kernel       pressure + wallsPressure of a gather (SMC.c:696-720, 862-895)
-//   total_energy_kernel   energy + wallsEnergy (SMC.c:626-646, 822-859)
+//   total_energy_zk/_kernel  energy + wallsEnergy (SMC.c:626-646, 822-859)
 //   eval_moves_kernel     teacher-forced Um,Fm,Un,Fn for one particle per replica
 #include "smcx_device.hpp"
 #include "smcx_kernels.h"
@@ -26,6 +26,27 @@ namespace smcx {
 // ---------------------------------------------------------------------------------
 // R: random numbers of `nsweeps` sweeps for every replica (256 threads per replica)
 // ---------------------------------------------------------------------------------
+// One block of 31 rand() outputs without the LDS crossbar.  new[j] = old[j] + (j < 3 ? old[j + 28] : new[j - 3]) is an
+// inclusive prefix sum inside each residue class of j mod 3: class k lives in DPP row k (lane 16 k + p holds word 3 p + k,
+// p = 0..10 for k = 0, 0..9 for k = 1, 2), so the sum is four row_shr adds of the vector ALU; the three words that cross
+// classes (old[28], [29], [30] seed new[0], [1], [2]) travel through scalar registers.  The form with lane j = word j
+// (rand_block, smcx_device.hpp: five ds_bpermute per block) was bound by the LDS crossbar its shuffles go through -- 0.26 ms
+// of the pre-pass's 0.49 per sweep at 4096 x 4096 (profiles/r03_helpers_split.txt); build it again with
+// make VARIANT=shfl EXTRA=-DSMCX_PREPASS_SHUFFLE.  Lanes above a class's last word hold sums nobody reads (a row_shr only
+// moves words upwards).
+__device__ __forceinline__ uint32_t rand_block_rows(uint32_t h, uint32_t m0, uint32_t m1, uint32_t m2)
+{
+    const uint32_t s0 = (uint32_t)__builtin_amdgcn_readlane((int)h, 16 + 9);  // old[28]: class 1, p = 9
+    const uint32_t s1 = (uint32_t)__builtin_amdgcn_readlane((int)h, 32 + 9);  // old[29]: class 2, p = 9
+    const uint32_t s2 = (uint32_t)__builtin_amdgcn_readlane((int)h, 10);      // old[30]: class 0, p = 10
+    uint32_t w = h + ((s0 & m0) | (s1 & m1) | (s2 & m2)); // m0, m1, m2: all ones in lane 0, 16, 32 (the classes' first words)
+    w += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w, 0x111, 0xf, 0xf, false); // row_shr:1 (lanes without a source add 0)
+    w += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w, 0x112, 0xf, 0xf, false); // row_shr:2
+    w += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w, 0x114, 0xf, 0xf, false); // row_shr:4
+    w += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w, 0x118, 0xf, 0xf, false); // row_shr:8
+    return w;
+}
+
 __global__ void __launch_bounds__(256)
 rng_prepass_kernel(DevCtx c, int nsweeps, double A)
 {
@@ -60,17 +81,35 @@ rng_prepass_kernel(DevCtx c, int nsweeps, double A)
             uint32_t acc = 0;
 #pragma unroll
             for (int k = 0; k < 31; k++) {
+#ifdef SMCX_PREPASS_SHUFFLE
                 const uint32_t hk = __shfl(hist, k, 64);
+#else
+                const uint32_t hk = (uint32_t)__builtin_amdgcn_readlane((int)hist, k);
+#endif
                 acc += ((lane < 31) ? c.rngJump[k * 31 + lane] : 0u) * hk;
             }
             hist = acc;
         }
         const int b0 = par ? wave * Q : (wave == 0 ? 0 : B);
         const int b1 = par ? (wave == 3 ? B : (wave + 1) * Q) : B;
+#ifdef SMCX_PREPASS_SHUFFLE
         for (int b = b0; b < b1; b++) {
             hist = rand_block(hist, lane);
             if (lane < 31) raw[left + 31 * b + lane] = hist >> 1;
         }
+#else
+        {   // the blocks run in the row layout of rand_block_rows: lane 16 k + p holds word 3 p + k
+            const int word = 3 * (lane & 15) + (lane >> 4);
+            const bool holds = lane < 48 && word < 31;
+            const uint32_t m0 = lane == 0 ? ~0u : 0u, m1 = lane == 16 ? ~0u : 0u, m2 = lane == 32 ? ~0u : 0u;
+            uint32_t hr = __shfl(hist, holds ? word : 0, 64);
+            for (int b = b0; b < b1; b++) {
+                hr = rand_block_rows(hr, m0, m1, m2);
+                if (holds) raw[left + 31 * b + word] = hr >> 1;
+            }
+            hist = __shfl(hr, lane < 31 ? 16 * (lane % 3) + lane / 3 : 0, 64);
+        }
+#endif
         if (wave == (par ? 3 : 0) && lane < 31) sh_hist[lane] = hist;
         left = left + 31 * B - D;
         __syncthreads();
@@ -638,9 +677,31 @@ __global__ void __launch_bounds__(256) pressure_kernel(DevCtx c, int gather)
 }
 
 // ---------------------------------------------------------------------------------
-// K5: energy + wallsEnergy per replica.  Each pair is visited once: thread i
-// walks the N/2 neighbours ahead of it on the ring of indices.
+// K5: energy + wallsEnergy per replica (SMC.c:626-646, 822-859).  Each pair is visited once.
+// N <= 16384 (total_energy_zk): the replica's particles are ranked by z in LDS (18-bit z of the replica's own z range | index,
+// bitonic sort) and rank a tests only the ranks after it whose z key lies within the cutoff -- in the slab geometries of the
+// configurations 1/11 .. 1/40 of the N/2 partners of the plain walk (every smcx_upload and every energy check runs this kernel:
+// 33 ms at 4096 x 2048 with the plain walk, 3.5 sweeps' worth).  Larger N (total_energy_kernel): thread i walks the N/2
+// neighbours ahead of it on the ring of indices.  The sum is the same set of terms in another order (1e-13 relative).
 // ---------------------------------------------------------------------------------
+__device__ inline double wall_terms(const DevCtx &c, double xi, double yi, double zi)
+{
+    const double dz = wall_dz(c, zi);
+    const double iz2 = 1.0 / (dz * dz), iz6 = iz2 * iz2 * iz2;
+    double acc = c.a0 * iz6 * iz6 - c.b0 * iz6;
+    const double dw = c.L / c.M;
+    for (int m = 0; m < c.M2; m++) {
+        double dx = xi - (m / c.M) * dw; dx = dx - c.L * __builtin_rint(dx * c.invL);
+        double dy = yi - (m % c.M) * dw; dy = dy - c.L * __builtin_rint(dy * c.invL);
+        const double dr2 = dx * dx + dy * dy + dz * dz;
+        if (dr2 < c.cutoff2) {
+            const double ir2 = 1.0 / dr2, ir6 = ir2 * ir2 * ir2;
+            acc += c.W[2 * m] * ir6 * ir6 - c.W[2 * m + 1] * ir6;
+        }
+    }
+    return acc;
+}
+
 __global__ void __launch_bounds__(256) total_energy_kernel(DevCtx c, double *out)
 {
     __shared__ double part[4];
@@ -664,26 +725,84 @@ __global__ void __launch_bounds__(256) total_energy_kernel(DevCtx c, double *out
                 acc += ir6 * ir6 - ir6;
             }
         }
-        if (walls) {
-            const double dz = wall_dz(c, zi);
-            const double iz2 = 1.0 / (dz * dz), iz6 = iz2 * iz2 * iz2;
-            acc += c.a0 * iz6 * iz6 - c.b0 * iz6;
-            const double dw = c.L / c.M;
-            for (int m = 0; m < c.M2; m++) {
-                double dx = xi - (m / c.M) * dw; dx = dx - c.L * __builtin_rint(dx * c.invL);
-                double dy = yi - (m % c.M) * dw; dy = dy - c.L * __builtin_rint(dy * c.invL);
-                const double dr2 = dx * dx + dy * dy + dz * dz;
-                if (dr2 < c.cutoff2) {
-                    const double ir2 = 1.0 / dr2, ir6 = ir2 * ir2 * ir2;
-                    acc += c.W[2 * m] * ir6 * ir6 - c.W[2 * m + 1] * ir6;
-                }
-            }
-        }
+        if (walls) acc += wall_terms(c, xi, yi, zi);
     }
     for (int m = 32; m >= 1; m >>= 1) acc += xchg(acc, m);
     if (lane == 0) part[wave] = acc;
     __syncthreads();
     if (tid == 0) out[rep] = 4.0 * (part[0] + part[1] + part[2] + part[3]);
+}
+
+// dynamic LDS: npad keys (npad = the power of two >= N, at least 256); the reductions borrow the first 64 bytes
+__global__ void __launch_bounds__(256) total_energy_zk(DevCtx c, double *out, int npad)
+{
+    extern __shared__ unsigned zkey[];
+    constexpr int IB = 14, ZQ = (1 << 18) - 2; // index bits; the highest z key (a particle's key is never the padding's ~0u)
+    const int rep = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int N = c.N;
+    const double *Rg = c.R + (size_t)rep * 3 * N;
+    const bool walls = (c.flags & 0x1u) != 0;
+    double *red = reinterpret_cast<double *>(zkey);
+
+    // the replica's z range (without walls nothing confines z)
+    double lo = 1e300, hi = -1e300;
+    for (int i = tid; i < N; i += 256) { const double z = Rg[3 * i + 2]; lo = fmin(lo, z); hi = fmax(hi, z); }
+    for (int m = 32; m >= 1; m >>= 1) { lo = fmin(lo, xchg(lo, m)); hi = fmax(hi, xchg(hi, m)); }
+    if (lane == 0) { red[wave] = lo; red[4 + wave] = hi; }
+    __syncthreads();
+    lo = fmin(fmin(red[0], red[1]), fmin(red[2], red[3]));
+    hi = fmax(fmax(red[4], red[5]), fmax(red[6], red[7]));
+    __syncthreads();
+    const double scale = (double)ZQ / fmax(hi - lo, 1e-300);
+    // key differences above `reach` mean dz > cutoff: floor() moves a difference by less than one unit
+    const double reachd = sqrt(c.cutoff2) * scale + 1.0;
+    const unsigned reach = reachd < (double)ZQ ? (unsigned)reachd : (unsigned)ZQ;
+    for (int i = tid; i < npad; i += 256) {
+        unsigned k = ~0u;
+        if (i < N) {
+            const double q = (Rg[3 * i + 2] - lo) * scale;
+            const unsigned zq = q > 0.0 ? (q < (double)ZQ ? (unsigned)q : (unsigned)ZQ) : 0u; // (a NaN ranks first: the sum is NaN anyway)
+            k = (zq << IB) | (unsigned)i;
+        }
+        zkey[i] = k;
+    }
+    __syncthreads();
+    for (int k = 2; k <= npad; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = tid; t < npad / 2; t += 256) {
+                const int i = 2 * t - (t & (j - 1)), q = i + j;
+                const unsigned a = zkey[i], b = zkey[q];
+                if ((a > b) == ((i & k) == 0)) { zkey[i] = b; zkey[q] = a; }
+            }
+            __syncthreads();
+        }
+
+    double acc = 0.0;
+    for (int a = tid; a < N; a += 256) { // the N particles hold the ranks below N
+        const unsigned ka = zkey[a];
+        const int i = (int)(ka & ((1u << IB) - 1u));
+        const unsigned za = ka >> IB;
+        const double xi = Rg[3 * i], yi = Rg[3 * i + 1], zi = Rg[3 * i + 2];
+        for (int b = a + 1; b < N; b++) {
+            const unsigned kb = zkey[b];
+            if ((kb >> IB) - za > reach) break;
+            const int l = (int)(kb & ((1u << IB) - 1u));
+            double dx = Rg[3 * l] - xi; dx = dx - c.L * __builtin_rint(dx * c.invL);
+            double dy = Rg[3 * l + 1] - yi; dy = dy - c.L * __builtin_rint(dy * c.invL);
+            const double dz = Rg[3 * l + 2] - zi;
+            const double dr2 = dx * dx + dy * dy + dz * dz;
+            if (dr2 < c.cutoff2) {
+                const double ir2 = 1.0 / dr2, ir6 = ir2 * ir2 * ir2;
+                acc += ir6 * ir6 - ir6;
+            }
+        }
+        if (walls) acc += wall_terms(c, xi, yi, zi);
+    }
+    __syncthreads(); // every rank has been read: the keys' first bytes take the partial sums
+    for (int m = 32; m >= 1; m >>= 1) acc += xchg(acc, m);
+    if (lane == 0) red[wave] = acc;
+    __syncthreads();
+    if (tid == 0) out[rep] = 4.0 * (red[0] + red[1] + red[2] + red[3]);
 }
 
 // ---------------------------------------------------------------------------------
@@ -899,7 +1018,12 @@ hipError_t launch_pressure(const DevCtx &c, int gather, hipStream_t st)
 
 hipError_t launch_total_energy(const DevCtx &c, double *out, hipStream_t st)
 {
-    hipLaunchKernelGGL(total_energy_kernel, dim3(c.nrep), dim3(256), 0, st, c, out);
+    if (c.N <= 16384) {
+        int npad = 256;
+        while (npad < c.N) npad <<= 1;
+        hipLaunchKernelGGL(total_energy_zk, dim3(c.nrep), dim3(256), npad * sizeof(unsigned), st, c, out, npad);
+    } else
+        hipLaunchKernelGGL(total_energy_kernel, dim3(c.nrep), dim3(256), 0, st, c, out);
     return hipGetLastError();
 }
 

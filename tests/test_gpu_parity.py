@@ -115,6 +115,54 @@ def test_total_energy_dense_state(S, O):
     eng.close()
 
 
+@pytest.mark.parametrize("case", ["unconfined_gas", "one_plane", "N4000", "N16384", "N2", "last_index_on_top", "per_replica"])
+def test_total_energy_of_states_that_stress_the_z_ranking(S, O, case):
+    """smcx_total_energy ranks a replica's particles by an 18-bit z of the replica's OWN z range and tests only ranks within the
+    cutoff: states whose range is far wider than the box (no walls: nothing confines z, SMC.c:626-646 has no z wrap), zero (one
+    plane), N not a power of two, the largest N of the ranked kernel, the last index on top of the range (its key is the highest
+    a particle can have, next to the padding's), and replicas whose ranges differ."""
+    rs = np.random.RandomState(11)
+    walls, per = True, None
+    if case == "unconfined_gas":
+        N, walls = 1024, False
+        R = O.fcc(8, 4).reshape(-1, 3) + 0.05 * rs.standard_normal((N, 3))       # the lattice keeps pairs inside the cutoff ...
+        R[300:, 2] = rs.uniform(-950.0, 950.0, N - 300)                          # ... most particles are far outside the box
+        R[:, :2] -= 33.0 * np.rint(R[:, :2] / 33.0)                              # (smcx_upload takes |z| <= 4 Lz = 960)
+    elif case == "one_plane":
+        N = 256
+        g = (np.arange(16) + 0.5) * (33.0 / 16) - 16.5
+        R = np.c_[np.stack(np.meshgrid(g, g), -1).reshape(-1, 2) + 0.05 * rs.standard_normal((N, 2)), np.full(N, 7.25)]
+    elif case == "N4000":
+        N = 4000
+        R = O.fcc(10, 10).reshape(-1, 3) + 0.05 * rs.standard_normal((N, 3))
+    elif case == "N16384":
+        N = 16384
+        R = O.fcc(16, 16).reshape(-1, 3) + 0.05 * rs.standard_normal((N, 3))
+    elif case == "N2":
+        N = 2
+        R = np.array([[0.0, 0.0, 0.0], [0.7, 0.8, 0.9]])
+    elif case == "last_index_on_top":
+        N = 16384
+        R = O.fcc(16, 16).reshape(-1, 3).copy()
+        R[N - 1] = [1.0, 1.0, R[:, 2].max() + 1.05]
+        R[N - 2] = [1.6, 1.0, R[N - 1, 2] - 1e-9]
+    else:
+        N = 1024
+        per = np.stack([O.fcc(8, 4).reshape(-1, 3) * [1.0, 1.0, f] + 0.05 * rs.standard_normal((N, 3)) for f in (1.0, 0.25, 0.02, 1.0)])
+    nrep = 4 if per is not None else 2
+    p = S.default_params(N, nrep, flags=S.FLAGS_REFERENCE if walls else S.FLAG_E0_RESTART)
+    eng = S.Engine(p)
+    states = per if per is not None else np.stack([R] * nrep)
+    eng.upload(states.reshape(nrep, -1) if per is not None else R.ravel(), O.W_FIXTURE if walls else None)
+    E = eng.total_energy()
+    s = sys_of(O, p)
+    for r in range(nrep):
+        X = np.ascontiguousarray(states[r].ravel())
+        ref = O.total_energy(s, X, O.W_FIXTURE) if walls else O.lib().orc_energy(O.C.byref(s), O._ptr(X))
+        assert abs(ref) > 1e-3 and rel(E[r], ref) < TOL.SINGLE, (case, r, E[r], ref)
+    eng.close()
+
+
 # ------------------------------------------------------------------ S1: one sweep
 @pytest.mark.parametrize("case", ["N256", "N1024", "N108_padded", "N1024_dense_x2waves", "N4096"])
 def test_single_sweep_matches_oracle(S, O, case):
