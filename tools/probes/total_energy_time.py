@@ -10,7 +10,7 @@ import importlib
 S = importlib.import_module("montecarlo-surfacer_amd")
 import oracle_lib as O
 
-for name, Na, Nz, nrep in (("config 2", 8, 4, 1024), ("config 3", 8, 16, 2048), ("headline", 16, 4, 2048), ("config 5", 16, 16, 256)):
+for name, Na, Nz, nrep in (("config 2", 8, 4, 1024), ("config 3", 8, 16, 2048), ("dense film", 16, 4, 2048), ("config 5", 16, 16, 256)):
     R0 = O.fcc(Na, Nz)
     N = R0.size // 3
     p = S.default_params(N, nrep, flags=S.FLAGS_REFERENCE)
@@ -26,7 +26,7 @@ for name, Na, Nz, nrep in (("config 2", 8, 4, 1024), ("config 3", 8, 16, 2048), 
         ref = O.total_energy(s, np.ascontiguousarray(eng.positions()[0]), O.W_FIXTURE)
         ob = eng.observables()
         inc = np.max(np.abs(ob["E_last"] - E) / np.abs(E)) if label != "lattice" else 0.0
-        print("%-9s %-17s N=%5d x %4d  total_energy %7.3f ms  rel. to oracle (replica 0) %.1e  carried vs recomputed (max over replicas) %.1e%s"
+        print("%-10s %-17s N=%5d x %4d  total_energy %7.3f ms  rel. to oracle (replica 0) %.1e  carried vs recomputed (max over replicas) %.1e%s"
               % (name, label, N, nrep, best * 1e3, abs(E[0] - ref) / abs(ref), inc,
                  "  (upload incl. its energy %.1f ms)" % (t_up * 1e3) if label == "lattice" else ""), flush=True)
     eng.close()
