@@ -128,6 +128,15 @@ PRIO = MODE not in ("z8w", "z8wc", "z8t", "z8tc")         # issue priority from 
 PRIO_MODE = os.environ.get("SMCX_GEN_PRIO_MODE", "rotate")
 NT = " nt" if os.environ.get("SMCX_GEN_NT") == "1" else ""   # experiment: streaming hint on once-per-sweep data
 STAMPS = os.environ.get("SMCX_GEN_TT_STAMPS") == "1"        # z8t diagnostic: where a move's time goes (before / at the barrier)
+# one-wave kernels, measurement only: SMCX_GEN_IVAL=list puts a label L_ivp<k>_<n> at every mark(k) (their order in the generated
+# move is read off the body); SMCX_GEN_IVAL=a:b sums, per replica, the cycles from mark a to mark b of every move in m0 (which these kernels
+# use only as the index register of s_set_gpr_idx_on on the accept path: saved in s101 around it in these builds) and returns the sum in the end stamp's s_memrealtime slot (smcx_debug_clk_rows column 3).  Either stamp drains the
+# LDS / scalar-memory counter (s_memtime's result is awaited there): a few cycles of perturbation per move.  Needs s100, s101
+# among the kernel's clobbers (tools/probes/ival_phases.sh builds the variants).
+IVAL = os.environ.get("SMCX_GEN_IVAL", "")
+IVA, IVB = (int(x) for x in IVAL.split(":")) if (":" in IVAL and not IVAL.startswith("count")) else (None, None)
+IVC = int(IVAL.split(":")[1]) if IVAL.startswith("count:") else None      # count:k -- m0 counts the executions of mark k
+IVN = [0]
 FAKE = os.environ.get("SMCX_GEN_FAKEFETCH") == "1"          # TIMING experiment only (wrong results): every candidate fetch reads cell 0
 PRIO_SHIFT = int(os.environ.get("SMCX_GEN_PRIO_SHIFT", "14"))   # ... every 2^14 ticks of the 100 MHz clock (164 us)
 Z8C = MODE in ("z8c", "z8wc", "z8tc", "z8lc")
@@ -463,6 +472,7 @@ else:
     s_mov_b64 exec, 1
     global_store_dwordx4 v14, v[16:19], {CLK0}
     s_mov_b64 exec, -1
+    {"s_mov_b32 m0, 0" if (IVA is not None or IVC is not None) else ""}
     """)
 if not ZB:
     E(f"""
@@ -614,11 +624,27 @@ if TT:
     """)
 
 
-def mark(k):
-    """z8t stamps variant: the cycles since this wave's previous mark are added to its LDS word k (1..15); word 0 = the
+def mark(k, iv=None):
+    """(one-wave kernels with SMCX_GEN_IVAL: point `iv`, or k, of the interval measurement described at the switch.)
+    z8t stamps variant: the cycles since this wave's previous mark are added to its LDS word k (1..15); word 0 = the
     time of the previous mark.  Uses st(4..6), v46, v47 and drains the LDS/scalar counter: only where those are dead and
     exec is full.  A mark costs about 100 cycles itself, charged to the interval that follows it."""
-    if not (TT and STAMPS):
+    if IVAL and not TT:
+        k = k if iv is None else iv
+        IVN[0] += 1
+        if IVAL == "list":
+            E(f"L_ivp{k}_{IVN[0]}:")
+        if IVC is not None and k == IVC:
+            E("s_add_u32 m0, m0, 1")
+        for point, op in ((IVA, "s_sub_u32"), (IVB, "s_add_u32")):
+            if k == point:
+                E(f"""
+                s_memtime s[100:101]
+                s_waitcnt lgkmcnt(0)
+                {op} m0, m0, s100
+                """)
+        return
+    if k is None or not (TT and STAMPS):
         return
     E(f"""
     s_memtime {stp(4)}
@@ -2361,7 +2387,7 @@ if TT:   # team A screens and fetches for probe A only, team B for probe B only
     """)
 if Z8:
     screen_ranged8("A", s('axys'), v('wa0'), v('wa1'))
-    mark(1)
+    mark(1, 31)
 elif ZB:
     screen_ranged("A", s('axys'), s('azz'), v('wa0'), v('wa1'))
     if ZBC:
@@ -2427,7 +2453,7 @@ if TT:
     """)
 if Z8:
     screen_ranged8("B", s('bxys'), v('wb0'), v('wb1'))
-    mark(1)
+    mark(1, 32)
 elif ZB:
     screen_ranged("B", s('bxys'), s('bzz'), v('wb0'), v('wb1'))
     if ZBC:
@@ -2773,6 +2799,7 @@ def mg_round0(near):
     {f"ds_read_b64 v[{XA_+4}:{XA_+5}], v45 offset:16" if LP else f"global_load_dwordx2 v[{XA_+4}:{XA_+5}], v45, {SRC} offset:16"}
     s_mov_b64 exec, -1
     """)
+    mark(None, 21)       # (IVAL: the hand-overs are done, the candidates' fetch is on its way)
     if near:   # table rows of the wall lanes of a near probe: row = lane within its half
         E(f"""
         s_bitcmp1_b32 {s('nearA')}, 0
@@ -2827,6 +2854,7 @@ def mg_round0(near):
     else:   # the candidates' positions; the displacement asked for behind them may still travel
         G("s_waitcnt vmcnt(0)")
         SO("s_waitcnt vmcnt(1)")
+    mark(None, 22)       # (IVAL: the candidates' positions have arrived)
     if "nobody" in ABL and not near:
         E(f"s_branch L_nolj_{tag}")
     body(tag, PV, XA_, CA_, stp(6), True, wl, pl)
@@ -2983,10 +3011,12 @@ if MG:
     s_bitcmp1_b32 {s('nearB')}, 1
     s_cbranch_scc1 L_mgMore
     """)
+    mark(None, 23)       # (IVAL: the fp64 bodies of all rounds and the side capture are done)
     REDIR[0] = cold
     mg_more()
     REDIR[0] = None
     FnG = mg_reduce()
+    mark(None, 24)       # (IVAL: the eight sums are reduced)
     # ---- Metropolis step in group layout (SMC.c:326-335); FmV, DdV: this move's Fm and displacement per group
     E(f"s_mov_b32 {s('accf')}, 0")
     G(f"""
@@ -3366,9 +3396,11 @@ else:
     v_mov_b32 {v('T')}, {s('axys')}
     v_and_b32 {v('uns0')}, {st(6)}, {v('uns0')}
     v_and_b32 {v('uns1')}, {st(7)}, {v('uns1')}
+    {"s_mov_b32 s101, m0" if (IVAL and not TT) else ""}
     {"" if "nogpridx" in ABL else f"s_set_gpr_idx_on {st(1)}, gpr_idx(DST)"}
     {"" if "nogpridx" in ABL else f"v_mov_b32 {xy(0)}, {v('T')}"}
     {"" if "nogpridx" in ABL else "s_set_gpr_idx_off"}
+    {"s_mov_b32 m0, s101" if (IVAL and not TT) else ""}
     v_or_b32 {v('uns0')}, {st(4)}, {v('uns0')}
     v_or_b32 {v('uns1')}, {st(5)}, {v('uns1')}
     """
@@ -3799,7 +3831,8 @@ if TT and STAMPS:   # add this wave's 16 words to clk[rep][wave * 16 + k] (up to
 E(f"""
 // end stamp
 s_memtime {stp(4)}
-s_memrealtime {stp(6)}
+{f"s_mov_b32 {st(6)}, m0" if (IVA is not None or IVC is not None) else f"s_memrealtime {stp(6)}"}
+{f"s_mov_b32 {st(7)}, 0" if (IVA is not None or IVC is not None) else ""}
 s_waitcnt lgkmcnt(0)
 v_mov_b32 v14, 16
 v_mov_b32 v16, {st(4)}
