@@ -204,6 +204,16 @@ T5 = TRIM5 and MG and not W4
 # comma-separated list of noaccept (every move rejected), nobody (the fp64 body of round 0 jumped over), noscreenA / noscreenB (a probe's
 # screen jumped over: no candidates), nosides (no side pair).  tools/sessions/r05_session17.sh, profiles/r05_ablation_mc64.txt
 ABL = set(x for x in os.environ.get("SMCX_GEN_ABL", "").split(",") if x)
+# "PS" (one-wave z-ordered kernels, steady copy of the move): probe B's screen of the NEXT move -- particle n+2 against the cells,
+# which does not depend on this move's outcome except through the moving particle's own cell -- runs between the issue of the
+# candidates' fetch and the wait for it (profiles/r05_ival_phases_mc64.txt: that wait is 770 cycles of a wavefront's 4850 per move
+# with 12 instructions in it; a screen is 620), into the flag words wb0/wb1 that this move's hand-over has emptied.  psv (the high
+# word of the hand-over's scratch pair hB, dead between the hand-over and the next one) says the next move finds them set and skips
+# its own screen B.  Not done -- psv = 0, the next move screens as before -- when further rounds still need the flag words, in the
+# near-wall form of the pass, when the order crosses into the next row of 64 (tl = 63), when particle n+2 is beyond the safe z range,
+# and in the generic copy.  On acceptance the moving particle's cell gets its bit set in the pre-screened words (its bytes, its
+# group's range and its unsafe bit may have changed under them: a candidate too many costs one evaluation, one too few a pair).
+PS_ON = os.environ.get("SMCX_GEN_PS", "1") == "1"          # (A/B: make VARIANT=nops GENENV="SMCX_GEN_PS=0")
 ANYU = "s100"      # T5: 1 while some cell of this replica carries the unsafe-z bit (set where the cells are built and on acceptance)       # working lanes of a two-team wave's list (64 = round 4's value: drops items, see tt_assign)
 # "XC" (merged pass, steady copy of the move): the cells that are no neighbours of a probe -- the moving particle n
 # for both, particle n+1 itself for probe B -- keep their candidate bits and travel through the hand-over list like any other; the
@@ -218,6 +228,7 @@ XCT = TL and PEEL and os.environ.get("SMCX_GEN_XCMP", "1") != "0"
 PF2 = TT and NS >= 32 and not TL     # z8t with many cells: the first TWO candidates of a lane are fetched together (dense states: the
                           # second round's memory round trip was the longest stretch of the slowest wavefront's move)
 LP = (TT and NS == 16) or ZL
+PS = PS_ON and MG and PEEL and not W4 and not LP      # (sweep_kernel_mc64 / mc32 / mc16 and their diagnostic builds)
 assert not ZL or NS == 16
 LDS_RS, LDS_WT = 0, NS * 64 * 24
 LDS_BASE = LDS_WT + 1024 if LP else 0
@@ -1485,10 +1496,10 @@ def zbc_check(pzz, w0, w1):
     """)
 
 
-def screen_group8(k0, p, w, fill=""):
+def screen_group8(k0, p, w, fill="", tb=None):
     """z8: one probe against slots k0..k0+GS-1, highest first: 3 instructions per slot; a v_dot4 result is read at least
     three instructions later (`fill`: what the caller puts between the dot products and the flag shifts of a 2-slot group)"""
-    a = ["v%d" % (V['t'] + j) for j in range(GS)]
+    a = ["v%d" % ((V['t'] if tb is None else tb) + j) for j in range(GS)]
     X = [xy(k0 + GS - 1 - j) for j in range(GS)]
     for j in range(GS):
         E(f"v_sub_u32 {a[j]}, {p}, {X[j]}")
@@ -1500,30 +1511,39 @@ def screen_group8(k0, p, w, fill=""):
         E(f"v_alignbit_b32 {w}, {w}, {a[j]}, 31")
 
 
-def screen_ranged8(tag, pws, w0, w1):
-    """z8: as screen_ranged, without z words to fetch: the computed jump lands on the highest group in reach"""
+def screen_ranged8(tag, pws, w0, w1, R=None):
+    """z8: as screen_ranged, without z words to fetch: the computed jump lands on the highest group in reach.
+    R (the pre-screen of the next move's probe B, PS): its own registers -- dict(t0, t1, t4, t5: s; p2: (pair, lo, hi); pxy: v; tb:
+    first of the GS temporaries) in place of st(0), st(1), st(4), st(5), stp(2), v('pxy'), V['t']"""
     w = lambda g: w1 if GS * g >= 32 else w0
+    xt, xtp = st, stp
+    if R is not None:
+        xt = lambda i: {0: R['t0'], 1: R['t1'], 2: R['p2'][1], 3: R['p2'][2], 4: R['t4'], 5: R['t5']}[i]
+        xtp = lambda i: {2: R['p2'][0]}[i]
+    pxy = v('pxy') if R is None else R['pxy']
+    tb = None if R is None else R['tb']
+    ca, cv = ("v16", "v14") if R is None else ("v42", "v41")      # z8c: address and value of the counters' LDS adds
     E(f"""
     v_mov_b32 {w0}, 0
     v_mov_b32 {w1}, 0
-    s_sext_i32_i16 {st(0)}, {pws}
-    v_mov_b32 {v('pxy')}, {pws}
-    v_cmp_ge_i32 vcc, {st(0)}, {v('gloR')}
-    v_cmp_le_i32 {stp(2)}, {st(0)}, {v('ghiR')}
-    s_and_b32 {st(1)}, vcc_lo, {st(2)}
+    s_sext_i32_i16 {xt(0)}, {pws}
+    v_mov_b32 {pxy}, {pws}
+    v_cmp_ge_i32 vcc, {xt(0)}, {v('gloR')}
+    v_cmp_le_i32 {xtp(2)}, {xt(0)}, {v('ghiR')}
+    s_and_b32 {xt(1)}, vcc_lo, {xt(2)}
     {"s_branch" if ("noscreen" + tag) in ABL else "s_cbranch_scc0"} L_sdone_{tag}
-    s_ff1_i32_b32 {st(4)}, {st(1)}
-    s_flbit_i32_b32 {st(5)}, {st(1)}
-    {f"s_add_u32 {st(1)}, {st(4)}, {st(5)}" if Z8C else ""}
-    {f"s_sub_u32 {st(1)}, 32, {st(1)}" if Z8C else ""}
-    s_mul_i32 {st(5)}, {st(5)}, L_sg{NG-2}_{tag}-L_sg{NG-1}_{tag}
+    s_ff1_i32_b32 {xt(4)}, {xt(1)}
+    s_flbit_i32_b32 {xt(5)}, {xt(1)}
+    {f"s_add_u32 {xt(1)}, {xt(4)}, {xt(5)}" if Z8C else ""}
+    {f"s_sub_u32 {xt(1)}, 32, {xt(1)}" if Z8C else ""}
+    s_mul_i32 {xt(5)}, {xt(5)}, L_sg{NG-2}_{tag}-L_sg{NG-1}_{tag}
     """)
     # (probe A's pass of the steady copy starts at L_jb: nothing to add)
-    (G if (tag == "A" and PEEL) else E)(f"s_add_u32 {st(5)}, {st(5)}, L_sg{NG-1}_{tag}-L_jb" if (tag != "A" or PEEL) else "")
+    (G if (tag == "A" and PEEL) else E)(f"s_add_u32 {xt(5)}, {xt(5)}, L_sg{NG-1}_{tag}-L_jb" if (tag != "A" or PEEL) else "")
     E(f"""
-    s_add_u32 {st(2)}, {s('nlu')}, {st(5)}
-    s_addc_u32 {st(3)}, {s('nlu',1)}, 0
-    s_setpc_b64 {stp(2)}
+    s_add_u32 {xt(2)}, {s('nlu')}, {xt(5)}
+    s_addc_u32 {xt(3)}, {s('nlu',1)}, 0
+    s_setpc_b64 {xtp(2)}
     """)
     TWO = NS == 64 and GS == 4 and not Z8C    # two exits: a pass that ends in the upper word shifts that one only
     # blocks in descending group order; flbit = 31 - highest group, so block g sits (flbit - (32 - NG)) blocks in
@@ -1533,10 +1553,10 @@ def screen_ranged8(tag, pws, w0, w1):
                                                  # steady copy lies first: every offset is positive)
         E(f"L_sg{g}_{tag}:")
         # (2-slot groups: the exit test and one s_nop stand between the dot products and the shifts that read them)
-        screen_group8(GS * g, v('pxy'), w(g), f"s_cmp_eq_u32 {st(4)}, {g}\ns_nop 0" if (g > 0 and GS < 4) else "")
+        screen_group8(GS * g, pxy, w(g), f"s_cmp_eq_u32 {xt(4)}, {g}\ns_nop 0" if (g > 0 and GS < 4) else "", tb)
         if g > 0:
             if GS == 4:
-                E(f"s_cmp_eq_u32 {st(4)}, {g}")
+                E(f"s_cmp_eq_u32 {xt(4)}, {g}")
             E(f"s_cbranch_scc1 L_sfin{('H' if GS * g >= 32 else 'L') if TWO else ''}_{tag}")
     if TWO:
         # the bits of the groups in reach lie at the bottom of their word: the word that holds the lowest group is shifted to
@@ -1544,41 +1564,41 @@ def screen_ranged8(tag, pws, w0, w1):
         # upper one's bits where they belong
         E(f"""
         L_sfinL_{tag}:
-        s_lshl_b32 {st(0)}, {st(4)}, {GSH}
-        v_lshlrev_b32 {w0}, {st(0)}, {w0}
+        s_lshl_b32 {xt(0)}, {xt(4)}, {GSH}
+        v_lshlrev_b32 {w0}, {xt(0)}, {w0}
         s_branch L_sdone_{tag}
         L_sfinH_{tag}:
-        s_lshl_b32 {st(0)}, {st(4)}, {GSH}
-        v_lshlrev_b32 {w1}, {st(0)}, {w1}
+        s_lshl_b32 {xt(0)}, {xt(4)}, {GSH}
+        v_lshlrev_b32 {w1}, {xt(0)}, {w1}
         L_sdone_{tag}:
         """)
         return
     E(f"L_sfin_{tag}:")
     if Z8C:   # executed work: groups of this pass = highest - lowest + 1 = 32 - flbit - ff1 (in st(1) since the jump)
-        cnt_addr("v16")
+        cnt_addr(ca)
         E(f"""
-        v_mov_b32 v14, {st(1)}
+        v_mov_b32 {cv}, {xt(1)}
         s_mov_b64 exec, 1
-        ds_add_u32 v16, v14 offset:{LDS_CNT + 12}
+        ds_add_u32 {ca}, {cv} offset:{LDS_CNT + 12}
         s_mov_b64 exec, -1
         """)
     E(f"""
-    s_lshl_b32 {st(0)}, {st(4)}, {GSH}
-    v_lshlrev_b32 {w0}, {st(0)}, {w0}
+    s_lshl_b32 {xt(0)}, {xt(4)}, {GSH}
+    v_lshlrev_b32 {w0}, {xt(0)}, {w0}
     """)
     if NS == 64:
         E(f"""
-        s_sub_u32 {st(1)}, {st(0)}, 32
-        s_max_i32 {st(1)}, {st(1)}, 0
-        v_lshlrev_b32 {w1}, {st(1)}, {w1}
+        s_sub_u32 {xt(1)}, {xt(0)}, 32
+        s_max_i32 {xt(1)}, {xt(1)}, 0
+        v_lshlrev_b32 {w1}, {xt(1)}, {w1}
         """)
     E(f"L_sdone_{tag}:")
     if Z8C:   # every pass, also one that found no group in reach
-        cnt_addr("v16")
+        cnt_addr(ca)
         E(f"""
-        v_mov_b32 v14, 1
+        v_mov_b32 {cv}, 1
         s_mov_b64 exec, 1
-        ds_add_u32 v16, v14 offset:{LDS_CNT + 16}
+        ds_add_u32 {ca}, {cv} offset:{LDS_CNT + 16}
         s_mov_b64 exec, -1
         """)
 
@@ -2452,6 +2472,11 @@ if TT:
     {"s_setprio 3" if TTP in ("probe", "red") else ""}
     """)
 if Z8:
+    if PS:
+        SO(f"""
+        s_cmp_lg_u32 {s('hB', 1)}, 0
+        s_cbranch_scc1 L_ub0
+        """)
     screen_ranged8("B", s('bxys'), v('wb0'), v('wb1'))
     mark(1, 32)
 elif ZB:
@@ -2847,6 +2872,9 @@ def mg_round0(near):
     s_or_b64 {stp(6)}, {stp(6)}, {sides}
     """)
     mg_wall_dz(tag)
+    if PS and not near:
+        E(f"s_mov_b32 {s('hB', 1)}, 0")                     # psv (both copies: the hand-over used the pair)
+        pre_screen_b()
     if near:
         E("s_waitcnt vmcnt(0) lgkmcnt(0)")
     elif LP:
@@ -2866,7 +2894,38 @@ def mg_round0(near):
     E(f"L_nsc_{tag}:")
     if near:
         mg_coeff_init(SO)     # (the wall lanes held the table's coefficients)
+        if PS:
+            E(f"s_mov_b32 {s('hB', 1)}, 0")                 # psv: no pre-screen in this form (hB was the planes' mask)
         E("s_branch L_mgR0")
+
+
+def pre_screen_b():
+    """PS (steady copy, far form): probe B's screen of the next move while the candidates' positions travel.  Free here: st(0..2) (the
+    candidates' mask went into stp(6)), the hand-over's scratch pairs hA / hB, vcc, the body's temporaries v36..v40; live: st(3..7),
+    v14..v35, v44..v49.  wb0 / wb1 are empty unless further rounds are pending (bit 1 of nearB)."""
+    save, FORCE_TAG[0] = FORCE_TAG[0], " @S"
+    psv, nxt, R = s('hB', 1), s('hB'), dict(t0=st(0), t1=st(1), t4=st(2), t5=s('hB'), p2=(sp('hA'), s('hA'), s('hA', 1)),
+                                             pxy="v40", tb=36)
+    E(f"""
+    s_bitcmp1_b32 {s('nearB')}, 1
+    s_cbranch_scc1 L_psx
+    s_cmp_eq_u32 {s('tl')}, 63
+    s_cbranch_scc1 L_psx
+    s_add_u32 {st(0)}, {s('tl')}, 1
+    s_nop 3
+    v_readlane_b32 {st(1)}, {v('rzl')}, {st(0)}
+    v_readlane_b32 {nxt}, {v('rxy')}, {st(0)}
+    s_bitcmp1_b32 {st(1)}, 16
+    s_cbranch_scc1 L_psx
+    """)
+    screen_ranged8("P", nxt, v('wb0'), v('wb1'), R)
+    E(f"""
+    v_or_b32 {v('wb0')}, {v('wb0')}, {v('uns0')}
+    v_or_b32 {v('wb1')}, {v('wb1')}, {v('uns1')}
+    s_mov_b32 {psv}, 1
+    L_psx:
+    """)
+    FORCE_TAG[0] = save
 
 
 def mg_more():
@@ -2909,6 +2968,8 @@ def mg_more():
     E("s_waitcnt vmcnt(0) lgkmcnt(0)")
     body("mm", PV, XA_, CA_, stp(0), False)
     mg_coeff_init(SO)         # (the plane lanes worked with 1, 1)
+    if PS:
+        E(f"s_mov_b32 {s('hB', 1)}, 0")                     # psv: the rounds' hand-overs used the pair (and no pre-screen ran)
     E("s_branch L_mgR0")
 
 
@@ -3423,6 +3484,13 @@ else:
         """)
     else:
         E(uns)
+    if PS:   # the moved particle's cell is a candidate of the pre-screened probe, whatever its old bytes said (exec = its lane)
+        assert not T5
+        SO(f"""
+        s_not_b64 {sp('hA')}, {stp(6)}
+        v_or_b32 {v('wb0')}, {s('hA')}, {v('wb0')}
+        v_or_b32 {v('wb1')}, {s('hA', 1)}, {v('wb1')}
+        """)
     if not Z8:
         E(f"""
         s_lshr_b32 {st(2)}, {st(1)}, 1

@@ -80,19 +80,28 @@ def count(a, b):
 
 
 grp = (at("sg14_A") - at("sg15_A"))
+# round 5: probe B's screen of the NEXT move runs inside the wait for the candidates' fetch (generator switch PS); a move then skips its
+# own screen B unless the pre-screen was not possible (row crossing 1 in 64, near-wall pass, further rounds, unsafe probe)
+HAS_PS = lab("psx") in idx
+ps_frac = (float(sys.argv[4]) if len(sys.argv) > 4 else 0.98) if HAS_PS else 0.0
 phases = [
     ("move head, probe B's compact copy", at("move"), at("nob1"), 1.0),
     ("screen A: range test, computed jump", at("nob1"), at("sg15_A"), 1.0),
     ("screen A: ONE group of 4 slots (x %.2f executed)" % groups_per_pass, at("sg15_A"), at("sg14_A"), groups_per_pass),
     ("screen A: exit (flag words to their slots)", at("sfinL_A"), at("sdone_A"), 0.6),
     ("fix A: unsafe probe test", at("sdone_A"), at("nofa"), 1.0),
-    ("screen B: range test, computed jump", at("nofa"), at("sg15_B"), 1.0),
-    ("screen B: ONE group of 4 slots (x %.2f executed)" % groups_per_pass, at("sg15_B"), at("sg14_B"), groups_per_pass),
-    ("screen B: exit", at("sfinL_B"), at("sdone_B"), 0.6),
+    ] + ([("screen B: is it pre-screened?", at("nofa"), at("nofa") + 3, 1.0)] if HAS_PS else []) + [
+    ("screen B%s: range test, computed jump" % (" (x %.2f: not pre-screened)" % (1 - ps_frac) if HAS_PS else ""),
+     at("nofa") + (3 if HAS_PS else 0), at("sg15_B"), 1.0 - ps_frac),
+    ("screen B: ONE group of 4 slots (x %.2f executed)" % groups_per_pass, at("sg15_B"), at("sg14_B"), groups_per_pass * (1.0 - ps_frac)),
+    ("screen B: exit", at("sfinL_B"), at("sdone_B"), 0.6 * (1.0 - ps_frac)),
     ("fix B: unsafe probe test", at("sdone_B"), at("nofb"), 1.0),
     ("pass set-up: log-uniform asked for, near-wall test, two hand-overs through the list, probes, side sources, "
      "displacement asked for, exclusions by compare, wall dz", at("nofb"), at("wdz_mf"), 1.0),
-    ("fp64 body (both probes, one pass)", at("wdz_mf"), at("nolj_mf"), 1.0),
+    ] + ([("pre-screen of the next move's probe B: tests, range test, jump", at("wdz_mf"), at("sg15_P"), 1.0),
+          ("pre-screen: ONE group of 4 slots (x %.2f x %.2f)" % (groups_per_pass, ps_frac), at("sg15_P"), at("sg14_P"), groups_per_pass * ps_frac),
+          ("pre-screen: exit, unsafe cells, flag", at("sfinL_P"), at("psx"), 0.6 * ps_frac)] if HAS_PS else []) + [
+    ("fp64 body (both probes, one pass)", at("psx") if HAS_PS else at("wdz_mf"), at("nolj_mf"), 1.0),
     ("side pair captured", at("nolj_mf"), at("mgR0"), 1.0),
     ("reduction (8 sums) + Metropolis step", at("mgR0"), rej_branch + 1, 1.0),
     ("accept path (x %.2f accepted)" % accept, rej_branch + 1, at("reject"), accept),
