@@ -213,6 +213,11 @@ ABL = set(x for x in os.environ.get("SMCX_GEN_ABL", "").split(",") if x)
 # near-wall form of the pass, when the order crosses into the next row of 64 (tl = 63), when particle n+2 is beyond the safe z range,
 # and in the generic copy.  On acceptance the moving particle's cell gets its bit set in the pre-screened words (its bytes, its
 # group's range and its unsafe bit may have changed under them: a candidate too many costs one evaluation, one too few a pair).
+# "EVM" (steady copy of the merged pass): the wait for the next move's displacement -- asked for a whole pass earlier, long there --
+# stands BEFORE the Metropolis decision instead of behind the accept path, where s_waitcnt vmcnt(0) also waited for the accepted
+# move's four stores to Rs and R to be acknowledged (nothing later in the move reads them back except through the same
+# wavefront's own loads, which the memory pipeline keeps in order behind the stores).
+EVM = os.environ.get("SMCX_GEN_EVM", "1") == "1"          # (A/B: make VARIANT=noevm GENENV="SMCX_GEN_EVM=0")
 PS_ON = os.environ.get("SMCX_GEN_PS", "1") == "1"          # (A/B: make VARIANT=nops GENENV="SMCX_GEN_PS=0")
 ANYU = "s100"      # T5: 1 while some cell of this replica carries the unsafe-z bit (set where the cells are built and on acceptance)       # working lanes of a two-team wave's list (64 = round 4's value: drops items, see tt_assign)
 # "XC" (merged pass, steady copy of the move): the cells that are no neighbours of a probe -- the moving particle n
@@ -3105,6 +3110,7 @@ if MG:
     v_mov_b32_dpp {v('T',1)}, {v('D',5)} row_bcast:15 row_mask:0xa bank_mask:0xf
     v_add_f64 {vp('D',2)}, {vp('D',2)}, {vp('T')}
     v_mul_f64 {vp('D',2)}, {vp('D',2)}, -{sp('invT')}
+    {"s_waitcnt vmcnt(0)" if (EVM and MG and PEEL and not W4) else ""}
     v_cmp_lt_f64 vcc, {sp('lu')}, {vp('D',2)}
     s_nop 0
     s_bitcmp1_b32 vcc_lo, 31
@@ -3560,7 +3566,7 @@ if MG:
     """)
     # (steady copy: one wait for the side result and the displacement, which the next instruction but one needs anyway)
     (G if PEEL else E)("s_waitcnt lgkmcnt(0)")
-    SO("s_waitcnt vmcnt(0) lgkmcnt(0)")
+    SO("s_waitcnt lgkmcnt(0)" if (EVM and MG and not W4) else "s_waitcnt vmcnt(0) lgkmcnt(0)")
     E(f"v_add_f64 {vp('FmV')}, {MGW}, v[46:47]")
     E("L_nsr:")
     (G if PEEL else E)("s_waitcnt vmcnt(0) lgkmcnt(0)")

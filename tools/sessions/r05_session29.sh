@@ -1,4 +1,4 @@
-# round-5 session 29 (through gpurun, repo root): the record on the library with the pre-screen (new bodies of mc64 / mc32 / mc16: new
+# round-5 session 29 (run twice: after the pre-screen and again after the early displacement wait): the record on the final library --
 # source ids) -- PMC passes, smoke, default bench, kernel trace of the default bench, 200-step bench
 set -o pipefail
 mkdir -p gpurun_out
