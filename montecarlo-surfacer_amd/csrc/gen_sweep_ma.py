@@ -217,6 +217,11 @@ ABL = set(x for x in os.environ.get("SMCX_GEN_ABL", "").split(",") if x)
 # stands BEFORE the Metropolis decision instead of behind the accept path, where s_waitcnt vmcnt(0) also waited for the accepted
 # move's four stores to Rs and R to be acknowledged (nothing later in the move reads them back except through the same
 # wavefront's own loads, which the memory pipeline keeps in order behind the stores).
+# "ELDS" (same copy): the two LDS reads behind the decision -- particle n+1's cached position for its proposal and the side pair's
+# result for the outcome -- had their latency in the open (ds_read, s_waitcnt, use).  They are asked for before the Metropolis
+# chain instead (both outcomes of the side result: v[40:41] = "rejected", v[38:39] = "accepted", copied over it on the accept path;
+# the position in v[36:37]): the body's temporaries v36..v41 are free from the reduction to the next move's pre-screen.
+ELDS_ON = os.environ.get("SMCX_GEN_ELDS", "1") == "1"      # (A/B: make VARIANT=noelds GENENV="SMCX_GEN_ELDS=0")
 EVM = os.environ.get("SMCX_GEN_EVM", "1") == "1"          # (A/B: make VARIANT=noevm GENENV="SMCX_GEN_EVM=0")
 PS_ON = os.environ.get("SMCX_GEN_PS", "1") == "1"          # (A/B: make VARIANT=nops GENENV="SMCX_GEN_PS=0")
 ANYU = "s100"      # T5: 1 while some cell of this replica carries the unsafe-z bit (set where the cells are built and on acceptance)       # working lanes of a two-team wave's list (64 = round 4's value: drops items, see tt_assign)
@@ -233,7 +238,9 @@ XCT = TL and PEEL and os.environ.get("SMCX_GEN_XCMP", "1") != "0"
 PF2 = TT and NS >= 32 and not TL     # z8t with many cells: the first TWO candidates of a lane are fetched together (dense states: the
                           # second round's memory round trip was the longest stretch of the slowest wavefront's move)
 LP = (TT and NS == 16) or ZL
-PS = PS_ON and MG and PEEL and not W4 and not LP      # (sweep_kernel_mc64 / mc32 / mc16 and their diagnostic builds)
+ELDS = ELDS_ON and MG and PEEL and not W4
+PS = PS_ON and MG and PEEL and not W4 and (not LP or os.environ.get("SMCX_GEN_PSLP", "0") == "1")      # (sweep_kernel_mc64 / mc32 / mc16
+                                                          # and their diagnostic builds; ml16 -- the fetch is an LDS read there -- with SMCX_GEN_PSLP=1)
 assert not ZL or NS == 16
 LDS_RS, LDS_WT = 0, NS * 64 * 24
 LDS_BASE = LDS_WT + 1024 if LP else 0
@@ -3083,6 +3090,13 @@ if MG:
     REDIR[0] = None
     FnG = mg_reduce()
     mark(None, 24)       # (IVAL: the eight sums are reduced)
+    if ELDS:
+        SO(f"""
+        v_mad_u32_u24 v49, {s('tl')}, 24, {KC}
+        ds_read_b64 v[36:37], v49 offset:{LDS_P0 + 24}
+        ds_read_b64 v[40:41], {KSD} offset:{LDS_SIDEM}
+        ds_read_b64 v[38:39], {KSD} offset:{LDS_SIDEM + 32}
+        """)
     # ---- Metropolis step in group layout (SMC.c:326-335); FmV, DdV: this move's Fm and displacement per group
     E(f"s_mov_b32 {s('accf')}, 0")
     G(f"""
@@ -3376,6 +3390,11 @@ else:
     s_cbranch_scc0 L_reject
     """)
 MUTE[0] = False
+if ELDS:   # the side result of an accepted move takes the place of the rejected move's (both were asked for before the decision)
+    SO("""
+    s_waitcnt lgkmcnt(0)
+    v_mov_b64 v[40:41], v[38:39]
+    """)
 E(f"""
 // accepted: E += Un - Um = 4 (eA - eB) (row 0 of g; mg: the e group, lane 0 either way), particle n takes the proposal
 {f"s_mov_b32 {s('accf')}, 1" if (TT or MG) else ""}
@@ -3543,11 +3562,12 @@ if MG:
     {f"v_add3_u32 v49, {st(2)}, {KC}, v1" if W4 else f"v_add_u32 v49, {st(2)}, {KC}"}
     ds_read_b64 {vp('D',0)}, v49 offset:{LDS_P0}
     """)
-    SO(f"""
-    v_mad_u32_u24 v49, {s('tl')}, 24, {KC}
-    {"v_add_u32 v49, v49, v1" if W4 else ""}
-    ds_read_b64 {vp('D',0)}, v49 offset:{LDS_P0 + 24}
-    """)
+    if not ELDS:
+        SO(f"""
+        v_mad_u32_u24 v49, {s('tl')}, 24, {KC}
+        {"v_add_u32 v49, v49, v1" if W4 else ""}
+        ds_read_b64 {vp('D',0)}, v49 offset:{LDS_P0 + 24}
+        """)
     # (a pass without the side pair -- generic copy only -- takes probe B's sums as they are)
     (G if PEEL else E)(f"""
     v_mov_b32 {v('FmV')}, v20
@@ -3557,7 +3577,7 @@ if MG:
     s_cmp_eq_u32 {s('hasA') if W4 else s('sidesHi')}, 0
     s_cbranch_scc1 L_nsr
     """)
-    E(f"""
+    (G if ELDS else E)(f"""
     {f"s_and_b32 {st(0)}, {s('i')}, 1" if W4 else ""}
     {f"s_lshl_b32 {st(0)}, {st(0)}, 1" if W4 else ""}
     {f"s_add_u32 {st(0)}, {st(0)}, {s('accf')}" if W4 else ""}
@@ -3567,14 +3587,20 @@ if MG:
     # (steady copy: one wait for the side result and the displacement, which the next instruction but one needs anyway)
     (G if PEEL else E)("s_waitcnt lgkmcnt(0)")
     SO("s_waitcnt lgkmcnt(0)" if (EVM and MG and not W4) else "s_waitcnt vmcnt(0) lgkmcnt(0)")
-    E(f"v_add_f64 {vp('FmV')}, {MGW}, v[46:47]")
+    (G if ELDS else E)(f"v_add_f64 {vp('FmV')}, {MGW}, v[46:47]")
+    if ELDS:
+        SO(f"v_add_f64 {vp('FmV')}, {MGW}, v[40:41]")
     E("L_nsr:")
     (G if PEEL else E)("s_waitcnt vmcnt(0) lgkmcnt(0)")
     E(f"""
     v_mov_b32 {v('DdV')}, v12
     v_mov_b32 {v('DdV',1)}, v13
     v_fma_f64 {vp('D',1)}, {vp('FmV')}, {sp('AoT')}, {DdNm}
-    v_add_f64 {vp('D',0)}, {vp('D',0)}, {vp('D',1)}
+    """)
+    (G if ELDS else E)(f"v_add_f64 {vp('D',0)}, {vp('D',0)}, {vp('D',1)}")
+    if ELDS:
+        SO(f"v_add_f64 {vp('D',0)}, v[36:37], {vp('D',1)}")
+    E(f"""
     // wrap x and y (lanes 16..23, 8..15 of a half), fixed point with 256/L ; z (lanes 24..31): fixed point, safe range, near a wall
     s_bfm_b64 exec, 16, 8
     v_mul_f64 {vp('D',1)}, {vp('D',0)}, {sp('invL')}
